@@ -1,0 +1,172 @@
+/*
+ * ohevc_frame.h — the picture work list ("frame command buffer").
+ *
+ * This is the hand-off format between the host CTU loop (openHEVC's hevc.c, which keeps
+ * doing entropy decode, MV derivation, dequant and boundary-strength derivation) and the
+ * MI355X block-reconstruction passes.  Every table call the reference makes per block
+ *  is RECORDED as one fixed-size item; the GPU replays a whole picture
+ * (or a batch of pictures) per pass:
+ *
+ *     pass 1  inter prediction   OhPu[]      <- put_hevc_{qpel,epel}*        hevc.c:1641-1949, 2103-2153
+ *     pass 2  residual           OhTu[]      <- idct[] / transform_add[]     hevc_cabac.c:1868-1949
+ *     pass 3  intra (wavefront)  OhIntra[]   <- hpc.intra_pred[]             hevc.c:1215..1417, hevcpred_template.c:30-344
+ *     pass 4  deblock V, H       BS/QP grids <- deblocking_filter_CTB        hevc_filter.c:345-581
+ *     pass 5  SAO                OhSaoCtb[]  <- sao_filter_CTB               hevc_filter.c:197-322
+ *
+ * Plain C, fixed-width integers, no pointers inside items: the same bytes are consumed by the
+ * CPU oracle (oracle/), by the HIP engine (openhevc_amd/csrc/) and produced by the synthetic
+ * stream generator (openhevc_amd/synth/).  Names follow the HEVC domain (CTB, TU, PU, BS).
+ */
+#ifndef OHEVC_FRAME_H
+#define OHEVC_FRAME_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OH_MAX_REFS   16      /* DPB slots a picture may reference (hevc.h: MAX_REFS 16) */
+#define OH_NO_REF     0xFF
+#define OH_NO_WP      0xFFFFu
+#define OH_NO_COEFF   0xFFFFFFFFu
+
+/* ---- sequence / picture parameters the hot path needs (subset of SPS/PPS, hevc.h:729-920) ---- */
+typedef struct OhPicParams {
+    int32_t width, height;            /* luma samples (sps->width/height)                      */
+    int32_t bit_depth;                /* 8, 10 or 12 (luma == chroma, README.md:16)            */
+    int32_t chroma_format_idc;        /* 0 mono, 1 4:2:0, 2 4:2:2, 3 4:4:4                     */
+    int32_t log2_ctb_size;            /* 4..6                                                  */
+    int32_t log2_min_cb_size;         /* >= 3                                                  */
+    int32_t log2_min_tb_size;         /* >= 2                                                  */
+    int32_t log2_min_pu_size;         /* log2_min_cb_size - 1 (hevc_ps.c)                      */
+    int32_t pcm_loop_filter_disable;  /* sps->pcm_enabled_flag && pcm.loop_filter_disable_flag */
+    int32_t transquant_bypass_enable; /* pps->transquant_bypass_enable_flag                    */
+    int32_t strong_intra_smoothing;   /* sps->sps_strong_intra_smoothing_enable_flag           */
+    int32_t intra_smoothing_disabled; /* sps->spsRext.intra_smoothing_disabled_flag            */
+    int32_t cb_qp_offset, cr_qp_offset; /* pps offsets used by chroma_tc (hevc_filter.c:62-89) */
+    int32_t sao_enabled;              /* sps->sao_enabled                                      */
+    int32_t deblock_enabled;          /* 0: skip pass 4 entirely (all BS would be 0)           */
+    int32_t reserved[4];
+} OhPicParams;
+
+/* ---- pass 1: inter prediction.  One item = one PU rectangle, already cut to <= 64x64 luma. ---- */
+typedef struct OhPu {
+    uint16_t x, y;                /* luma position of the rectangle (hevc.c:2103: x0,y0)            */
+    uint8_t  w, h;                /* luma size, 4..64, multiples of 4 (8x4 / 4x8 are the smallest)  */
+    uint8_t  ref[2];              /* slot in OhFrame.ref_pics per list, OH_NO_REF = list unused     */
+    int16_t  mv[2][2];            /* [list][x,y] quarter-luma-sample units (MvField.mv)             */
+    uint16_t wp;                  /* index into OhFrame.wp[], OH_NO_WP = default weighting          */
+    uint16_t reserved;
+} OhPu;                           /* 20 bytes */
+
+/* explicit weighted prediction parameters for one (ref_idx_l0, ref_idx_l1) pair (hevc.c:1767-1773) */
+typedef struct OhWeights {
+    int16_t w[2][3];              /* [list][plane]  luma_weight_l0/1, chroma_weight_l0/1[..][0..1]  */
+    int16_t o[2][3];              /* [list][plane]  offsets, in 8-bit units (scaled by BD-8 inside) */
+    uint8_t log2_denom[2];        /* [0] luma_log2_weight_denom, [1] chroma_log2_weight_denom       */
+    uint8_t reserved[2];
+} OhWeights;                      /* 28 bytes */
+
+/* ---- pass 2: residual.  One item = one coded transform block of one plane. ---- */
+enum OhTuKind {
+    OH_TU_IDCT   = 0,   /* hevcdsp.idct[log2-2] / idct_dc (DC-only is the same arithmetic)         */
+    OH_TU_DST4   = 1,   /* hevcdsp.idct_4x4_luma (intra 4x4 luma)                                  */
+    OH_TU_SKIP   = 2,   /* hevcdsp.transform_skip                                                  */
+    OH_TU_BYPASS = 3,   /* cu_transquant_bypass: coefficients are the residual                     */
+    OH_TU_PCM    = 4    /* put_pcm: `coeffs` hold final samples, no prediction is added            */
+};
+enum OhTuFlags {
+    OH_TUF_ADD_NOW   = 1,  /* prediction already complete after pass 1 (inter CU): add in pass 2  */
+    OH_TUF_RDPCM     = 2,  /* hevcdsp.transform_rdpcm after skip / on bypass                      */
+    OH_TUF_RDPCM_VER = 4,  /* rdpcm mode 1 (vertical)                                             */
+    OH_TUF_ROTATE    = 8   /* transform_skip_rotation (4x4): coefficients reversed before skip    */
+};
+typedef struct OhTu {
+    uint16_t x, y;                /* position in samples of plane c_idx                             */
+    uint8_t  c_idx;               /* 0 Y, 1 Cb, 2 Cr                                                */
+    uint8_t  log2_size;           /* 2..5                                                           */
+    uint8_t  kind;                /* enum OhTuKind                                                  */
+    uint8_t  flags;               /* enum OhTuFlags                                                 */
+    uint32_t coeff_off;           /* first int16 of the dense N*N block in OhFrame.coeffs           */
+} OhTu;                           /* 12 bytes */
+
+/* ---- pass 3: intra prediction, executed in dependency levels. ---- */
+enum OhIntraAvail {               /* resolved candidate flags (hevcpred_template.c:100-109)         */
+    OH_AV_BOTTOM_LEFT = 1, OH_AV_LEFT = 2, OH_AV_UP_LEFT = 4, OH_AV_UP = 8, OH_AV_UP_RIGHT = 16
+};
+typedef struct OhIntra {
+    uint16_t x, y;                /* position in samples of plane c_idx                             */
+    uint8_t  c_idx;
+    uint8_t  log2_size;           /* 2..5                                                           */
+    uint8_t  mode;                /* 0 planar, 1 DC, 2..34 angular                                  */
+    uint8_t  avail;               /* enum OhIntraAvail bits                                         */
+    uint32_t tu;                  /* index of this block's OhTu (residual added right after the
+                                     prediction), OH_NO_COEFF when cbf == 0                        */
+} OhIntra;                        /* 12 bytes */
+
+/* ---- pass 4: deblocking side arrays ---- */
+typedef struct OhDeblockCtb { int8_t beta_offset, tc_offset; } OhDeblockCtb;   /* hevc.h:1083 */
+
+/* ---- pass 5: SAO parameters per CTB (hevc.h:514-523, only what the filter reads) ---- */
+typedef struct OhSaoCtb {
+    int16_t offset_val[3][5];     /* SaoOffsetVal, [plane][0..4], [0] is always 0                   */
+    uint8_t band_position[3];
+    uint8_t eo_class[3];          /* 0 horiz, 1 vert, 2 135deg, 3 45deg                             */
+    uint8_t type_idx[3];          /* 0 off, 1 band, 2 edge                                          */
+    uint8_t edge_flags;           /* non-filterable CTB edges (slice/tile), hevc_filter.c:206-252:
+                                     bit0 left, bit1 right (vert_edge[0..1]); bit2 up, bit3 bottom
+                                     (horiz_edge[0..1]); bits 4..7 diag_edge[0..3]                  */
+} OhSaoCtb;                       /* 40 bytes */
+
+/* ---- one picture's work list (host pointers; the engine copies them at submit) ---- */
+typedef struct OhFrame {
+    OhPicParams p;
+    int32_t  cur_pic;                 /* picture id reconstructed by this work list                */
+    int32_t  ref_pics[OH_MAX_REFS];   /* picture ids OhPu.ref[] indexes                             */
+
+    uint32_t n_pu;      const OhPu      *pu;
+    uint32_t n_wp;      const OhWeights *wp;
+
+    uint32_t n_tu;      const OhTu      *tu;
+    uint64_t n_coeff;   const int16_t   *coeffs;
+
+    uint32_t n_intra;   const OhIntra   *intra;       /* sorted by dependency level               */
+    uint32_t n_levels;  const uint32_t  *level_start; /* n_levels+1 offsets into intra[]          */
+
+    /* (width>>2) x (height>>2) grids, index (x + y*bs_width)>>2 exactly as hevc_filter.c:388,487;
+       bs_size bytes each, bs_size >= the reference's padded allocation (hevc.c:170-171)          */
+    uint32_t bs_size;   const uint8_t *vertical_bs, *horizontal_bs;
+    const int8_t       *qp_y_tab;     /* min_cb_width x min_cb_height (hevc.c:158)                */
+    const uint8_t      *is_pcm;       /* min_pu_width x min_pu_height, may be NULL (hevc.c:147)   */
+    const OhDeblockCtb *deblock;      /* ctb_width x ctb_height                                   */
+    const OhSaoCtb     *sao;          /* ctb_width x ctb_height, may be NULL when !sao_enabled    */
+} OhFrame;
+
+/* ---- derived geometry helpers (all integer, shared by every consumer) ---- */
+static inline int oh_hshift(const OhPicParams *p, int c) { return c && (p->chroma_format_idc == 1 || p->chroma_format_idc == 2); }
+static inline int oh_vshift(const OhPicParams *p, int c) { return c && p->chroma_format_idc == 1; }
+static inline int oh_ctb_width(const OhPicParams *p)  { return (p->width  + (1 << p->log2_ctb_size) - 1) >> p->log2_ctb_size; }
+static inline int oh_ctb_height(const OhPicParams *p) { return (p->height + (1 << p->log2_ctb_size) - 1) >> p->log2_ctb_size; }
+static inline int oh_min_cb_width(const OhPicParams *p)  { return p->width  >> p->log2_min_cb_size; }
+static inline int oh_min_cb_height(const OhPicParams *p) { return p->height >> p->log2_min_cb_size; }
+static inline int oh_min_pu_width(const OhPicParams *p)  { return p->width  >> p->log2_min_pu_size; }
+static inline int oh_min_pu_height(const OhPicParams *p) { return p->height >> p->log2_min_pu_size; }
+/* the reference's padded BS allocation: max of hevc.c:170 and :171 so one size serves both grids */
+static inline uint32_t oh_bs_size(const OhPicParams *p)
+{
+    uint32_t bw = (uint32_t)p->width >> 2, bh = (uint32_t)p->height >> 2;
+    uint32_t a = (bw + 4u * (1u << oh_hshift(p, 1))) * bh;
+    uint32_t b = bw * (bh + 4u * (1u << oh_vshift(p, 1)));
+    return (a > b ? a : b) + 64u;
+}
+/* qp_y_tab is allocated one row/column larger than the picture (hevc.c:118-119: +1) */
+static inline uint32_t oh_qp_tab_size(const OhPicParams *p)
+{
+    return (uint32_t)(oh_min_cb_width(p) + 1) * (uint32_t)(oh_min_cb_height(p) + 1);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OHEVC_FRAME_H */

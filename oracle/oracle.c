@@ -1,0 +1,641 @@
+/*
+ * oracle.c — CPU restatement of the block-reconstruction hot path (see oracle.h).
+ * TEST INFRASTRUCTURE ONLY: the checker for the HIP engine, never a fallback for it.
+ * Parity: pinned against the reference's own C kernels (oracle/_ref) and tests/golden/.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+/* ------------------------------------------------------------------------------------------
+ * constant tables (facts of ITU-T H.265; the reference holds the same numbers at the cited lines)
+ * ---------------------------------------------------------------------------------------- */
+
+/* luma 1/4-sample interpolation taps, H.265 table 8-11 (hevcdsp.c:1038-1042); [0] unused */
+static const int8_t oh_qpel_taps[4][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 },
+    { -1, 4, -10, 58, 17, -5, 1, 0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 },
+    { 0, 1, -5, 17, 58, -10, 4, -1 },
+};
+/* chroma 1/8-sample taps, H.265 table 8-12 (hevcdsp.c:1028-1036); [0] unused */
+static const int8_t oh_epel_taps[8][8] = {
+    { 0, 64, 0, 0 },  { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+    { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 },
+};
+/* intraPredAngle for modes 2..34 and invAngle for modes 11..25 (hevcpred_template.c:430-437) */
+static const int8_t oh_intra_angle[33] = {
+    32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+    -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32
+};
+static const int16_t oh_inv_angle[15] = {
+    -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096
+};
+/* deblocking tables, H.265 table 8-12 (hevc_filter.c:50-60) */
+static const uint8_t oh_tc_table[54] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1,
+    1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+    5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24
+};
+static const uint8_t oh_beta_table[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8,
+    9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36,
+    38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64
+};
+
+static inline int oh_clip3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int oh_clip16(int v) { return oh_clip3(v, -32768, 32767); }
+
+/* The 32x32 inverse-DCT matrix (hevcdsp.c:879-944) is the integer cosine table c[m] ~
+ * 64*sqrt(2)*cos(m*pi/64) unfolded by symmetry: M[k][n] = +-c[fold(k*(2n+1) mod 128)]. */
+static int8_t oh_dct[32][32];
+static int oh_dct_ready;
+static void oh_dct_init(void)
+{
+    static const int8_t c[32] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+                                  64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4 };
+    if (oh_dct_ready)
+        return;
+    for (int k = 0; k < 32; k++)
+        for (int n = 0; n < 32; n++) {
+            int m = (k * (2 * n + 1)) & 127;
+            if (m > 64) m = 128 - m;
+            oh_dct[k][n] = (int8_t)(k == 0 ? 64 : (m == 32 ? 0 : (m < 32 ? c[m] : -c[64 - m])));
+        }
+    oh_dct_ready = 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pixel-typed code
+ * ---------------------------------------------------------------------------------------- */
+#define PX uint8_t
+#define FN(x) x##_8
+#include "oracle_px.inc"
+#undef PX
+#undef FN
+#define PX uint16_t
+#define FN(x) x##_16
+#include "oracle_px.inc"
+#undef PX
+#undef FN
+
+#define DISPATCH(bd, call8, call16) do { if ((bd) == 8) { call8; } else { call16; } } while (0)
+
+/* ------------------------------------------------------------------------------------------
+ * residual slots
+ * ---------------------------------------------------------------------------------------- */
+void oh_or_transform_add(int bd, uint8_t *dst, const int16_t *res, ptrdiff_t stride, int log2)
+{
+    DISPATCH(bd, transform_add_8(bd, dst, res, stride, 1 << log2),
+                 transform_add_16(bd, (uint16_t *)dst, res, stride / 2, 1 << log2));
+}
+
+void oh_or_transform_skip(int bd, int16_t *c, int log2)
+{
+    int shift = 15 - bd - log2, n2 = 1 << (2 * log2);
+    for (int i = 0; i < n2; i++)
+        c[i] = shift > 0 ? (int16_t)((c[i] + (1 << (shift - 1))) >> shift) : (int16_t)(c[i] << -shift);
+}
+
+void oh_or_transform_rdpcm(int16_t *c, int log2, int mode)
+{
+    int n = 1 << log2;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            if (mode && y)       c[y * n + x] = (int16_t)(c[y * n + x] + c[(y - 1) * n + x]);
+            else if (!mode && x) c[y * n + x] = (int16_t)(c[y * n + x] + c[y * n + x - 1]);
+        }
+}
+
+/* one 1-D pass of an n-point inverse transform with basis row(k)[i], applied to all n lines;
+ * pass 0 works down the columns, pass 1 along the rows (hevcdsp_template.c:283-300) */
+static void inv_pass(int16_t *c, int n, int pass, int shift, const int8_t *basis, int bstride)
+{
+    int16_t out[32];
+    int add = 1 << (shift - 1);
+    for (int line = 0; line < n; line++) {
+        int16_t *p = pass == 0 ? c + line : c + line * n;
+        int step = pass == 0 ? n : 1;
+        for (int i = 0; i < n; i++) {
+            int acc = 0;
+            for (int k = 0; k < n; k++)
+                acc += basis[k * bstride + i] * p[k * step];
+            out[i] = (int16_t)oh_clip16((acc + add) >> shift);
+        }
+        for (int i = 0; i < n; i++)
+            p[i * step] = out[i];
+    }
+}
+
+void oh_or_idct(int bd, int16_t *c, int log2)
+{
+    int n = 1 << log2;
+    oh_dct_init();
+    /* the n-point basis is every (32/n)-th row of the 32-point matrix */
+    inv_pass(c, n, 0, 7, &oh_dct[0][0], 32 * (32 / n));
+    inv_pass(c, n, 1, 20 - bd, &oh_dct[0][0], 32 * (32 / n));
+}
+
+void oh_or_idct_4x4_luma(int bd, int16_t *c)
+{
+    /* inverse DST-VII basis, H.265 eq. 8-315 (the reference factors it, hevcdsp_template.c:170-183) */
+    static const int8_t dst7[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+    inv_pass(c, 4, 0, 7, &dst7[0][0], 4);
+    inv_pass(c, 4, 1, 20 - bd, &dst7[0][0], 4);
+}
+
+void oh_or_idct_dc(int bd, int16_t *c, int log2)
+{
+    int shift = 14 - bd, add = 1 << (shift - 1);
+    int v = (((c[0] + 1) >> 1) + add) >> shift;
+    for (int i = 0; i < (1 << (2 * log2)); i++)
+        c[i] = (int16_t)v;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * interpolation slots
+ * ---------------------------------------------------------------------------------------- */
+#define MC_INTER(bd, taps, v, src, srcstride, w, h, fx, fy)                                        \
+    DISPATCH(bd, mc_intermediate_8(bd, taps, v, src, srcstride, w, h, fx, fy),                      \
+                 mc_intermediate_16(bd, taps, v, (const uint16_t *)(src), (srcstride) / 2, w, h, fx, fy))
+
+void oh_or_mc_put(int bd, int taps, int16_t *dst, ptrdiff_t dststride, const uint8_t *src,
+                  ptrdiff_t srcstride, int h, int fx, int fy, int w)
+{
+    int32_t v[64 * 64];
+    MC_INTER(bd, taps, v, src, srcstride, w, h, fx, fy);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            dst[y * dststride + x] = (int16_t)v[y * w + x];
+}
+
+void oh_or_mc_uni(int bd, int taps, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src,
+                  ptrdiff_t srcstride, int h, int fx, int fy, int w)
+{
+    int32_t v[64 * 64];
+    if (!fx && !fy) {                                     /* plain copy, hevcdsp_template.c:626-640 */
+        int bpp = bd > 8 ? 2 : 1;
+        for (int y = 0; y < h; y++)
+            memcpy(dst + y * dststride, src + y * srcstride, (size_t)w * bpp);
+        return;
+    }
+    MC_INTER(bd, taps, v, src, srcstride, w, h, fx, fy);
+    DISPATCH(bd, mc_store_uni_8(bd, dst, dststride, v, w, h),
+                 mc_store_uni_16(bd, (uint16_t *)dst, dststride / 2, v, w, h));
+}
+
+void oh_or_mc_bi(int bd, int taps, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src,
+                 ptrdiff_t srcstride, const int16_t *src2, ptrdiff_t src2stride, int h, int fx, int fy, int w)
+{
+    int32_t v[64 * 64];
+    MC_INTER(bd, taps, v, src, srcstride, w, h, fx, fy);
+    DISPATCH(bd, mc_store_bi_8(bd, dst, dststride, v, src2, src2stride, w, h),
+                 mc_store_bi_16(bd, (uint16_t *)dst, dststride / 2, v, src2, src2stride, w, h));
+}
+
+void oh_or_mc_uni_w(int bd, int taps, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src,
+                    ptrdiff_t srcstride, int h, int denom, int wx, int ox, int fx, int fy, int w)
+{
+    int32_t v[64 * 64];
+    MC_INTER(bd, taps, v, src, srcstride, w, h, fx, fy);
+    DISPATCH(bd, mc_store_uni_w_8(bd, dst, dststride, v, w, h, denom, wx, ox),
+                 mc_store_uni_w_16(bd, (uint16_t *)dst, dststride / 2, v, w, h, denom, wx, ox));
+}
+
+void oh_or_mc_bi_w(int bd, int taps, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src,
+                   ptrdiff_t srcstride, const int16_t *src2, ptrdiff_t src2stride, int h, int denom,
+                   int wx0, int wx1, int ox0, int ox1, int fx, int fy, int w)
+{
+    int32_t v[64 * 64];
+    MC_INTER(bd, taps, v, src, srcstride, w, h, fx, fy);
+    DISPATCH(bd, mc_store_bi_w_8(bd, dst, dststride, v, src2, src2stride, w, h, denom, wx0, wx1, ox0, ox1),
+                 mc_store_bi_w_16(bd, (uint16_t *)dst, dststride / 2, v, src2, src2stride, w, h, denom, wx0, wx1, ox0, ox1));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * intra / deblock / SAO slots
+ * ---------------------------------------------------------------------------------------- */
+void oh_or_pred_planar(int bd, uint8_t *dst, const uint8_t *top, const uint8_t *left, ptrdiff_t stride, int log2)
+{
+    DISPATCH(bd, pred_planar_8(dst, top, left, stride, log2),
+                 pred_planar_16((uint16_t *)dst, (const uint16_t *)top, (const uint16_t *)left, stride, log2));
+}
+void oh_or_pred_dc(int bd, uint8_t *dst, const uint8_t *top, const uint8_t *left, ptrdiff_t stride, int log2, int c_idx)
+{
+    DISPATCH(bd, pred_dc_8(dst, top, left, stride, log2, c_idx),
+                 pred_dc_16((uint16_t *)dst, (const uint16_t *)top, (const uint16_t *)left, stride, log2, c_idx));
+}
+void oh_or_pred_angular(int bd, uint8_t *dst, const uint8_t *top, const uint8_t *left, ptrdiff_t stride,
+                        int log2, int c_idx, int mode)
+{
+    DISPATCH(bd, pred_angular_8(bd, dst, top, left, stride, log2, c_idx, mode),
+                 pred_angular_16(bd, (uint16_t *)dst, (const uint16_t *)top, (const uint16_t *)left, stride, log2, c_idx, mode));
+}
+void oh_or_intra_pred(const OhPicParams *p, uint8_t *plane, ptrdiff_t stride, int pw, int ph,
+                      int x, int y, int c_idx, int log2, int mode, int avail)
+{
+    DISPATCH(p->bit_depth, intra_pred_8(p, plane, stride, pw, ph, x, y, c_idx, log2, mode, avail),
+                           intra_pred_16(p, (uint16_t *)plane, stride / 2, pw, ph, x, y, c_idx, log2, mode, avail));
+}
+void oh_or_loop_filter_luma(int bd, uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys, int beta, const int *tc,
+                            const uint8_t *no_p, const uint8_t *no_q)
+{
+    DISPATCH(bd, loop_filter_luma_8(bd, pix, xs, ys, beta, tc, no_p, no_q),
+                 loop_filter_luma_16(bd, (uint16_t *)pix, xs / 2, ys / 2, beta, tc, no_p, no_q));
+}
+void oh_or_loop_filter_chroma(int bd, uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys, const int *tc,
+                              const uint8_t *no_p, const uint8_t *no_q)
+{
+    DISPATCH(bd, loop_filter_chroma_8(bd, pix, xs, ys, tc, no_p, no_q),
+                 loop_filter_chroma_16(bd, (uint16_t *)pix, xs / 2, ys / 2, tc, no_p, no_q));
+}
+void oh_or_sao_band(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t ds, ptrdiff_t ss,
+                    const int16_t *offset_val, int band_position, int w, int h)
+{
+    DISPATCH(bd, sao_band_8(bd, dst, src, ds, ss, offset_val, band_position, w, h),
+                 sao_band_16(bd, (uint16_t *)dst, (const uint16_t *)src, ds / 2, ss / 2, offset_val, band_position, w, h));
+}
+void oh_or_sao_edge(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t ds, ptrdiff_t ss,
+                    const int16_t *offset_val, int eo_class, const int *borders, int w, int h,
+                    int restore, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
+{
+    DISPATCH(bd, sao_edge_8(bd, dst, src, ds, ss, offset_val, eo_class, borders, w, h, restore, ve, he, de),
+                 sao_edge_16(bd, (uint16_t *)dst, (const uint16_t *)src, ds / 2, ss / 2, offset_val, eo_class,
+                             borders, w, h, restore, ve, he, de));
+}
+
+/* ==========================================================================================
+ * picture level
+ * ======================================================================================== */
+
+static inline int px_get(const OhHostPic *pic, int c, int x, int y)
+{
+    const uint8_t *row = pic->data[c] + (ptrdiff_t)y * pic->stride[c];
+    return pic->bit_depth > 8 ? ((const uint16_t *)row)[x] : row[x];
+}
+
+/* ---- pass 1: inter prediction (hevc.c:1641-1949 drivers; videodsp_template.c:26-101 edge
+ * emulation == clamping the source coordinates to the picture) ---- */
+static void fetch_window(const OhHostPic *ref, int c, int x0, int y0, int w, int h, uint16_t *win, int wstride)
+{
+    int pw = ref->width[c], ph = ref->height[c];
+    for (int y = 0; y < h; y++) {
+        int sy = oh_clip3(y0 + y, 0, ph - 1);
+        for (int x = 0; x < w; x++)
+            win[y * wstride + x] = (uint16_t)px_get(ref, c, oh_clip3(x0 + x, 0, pw - 1), sy);
+    }
+}
+
+int oh_or_pass_inter(const OhFrame *f, OhHostPic *pics)
+{
+    const OhPicParams *p = &f->p;
+    OhHostPic *cur = &pics[f->cur_pic];
+    int bd = p->bit_depth;
+    int nplanes = p->chroma_format_idc ? 3 : 1;
+
+    for (uint32_t i = 0; i < f->n_pu; i++) {
+        const OhPu *pu = &f->pu[i];
+        const OhWeights *wp = pu->wp == OH_NO_WP ? NULL : &f->wp[pu->wp];
+        for (int c = 0; c < nplanes; c++) {
+            int hs = oh_hshift(p, c), vs = oh_vshift(p, c);
+            int taps = c ? 4 : 8, before = taps / 2 - 1;
+            int bx = pu->x >> hs, by = pu->y >> vs, bw = pu->w >> hs, bh = pu->h >> vs;
+            int32_t v[2][64 * 64];
+            int16_t v0_16[64 * 64];
+            int used[2] = { pu->ref[0] != OH_NO_REF, pu->ref[1] != OH_NO_REF };
+            for (int l = 0; l < 2; l++) {
+                if (!used[l])
+                    continue;
+                const OhHostPic *ref = &pics[f->ref_pics[pu->ref[l]]];
+                int mvx = pu->mv[l][0], mvy = pu->mv[l][1];
+                int fx, fy, ix, iy;
+                if (c == 0) {
+                    fx = mvx & 3; fy = mvy & 3; ix = mvx >> 2; iy = mvy >> 2;
+                } else {                                   /* hevc.c:1807-1813 */
+                    fx = (mvx & ((1 << (2 + hs)) - 1)) << (1 - hs);
+                    fy = (mvy & ((1 << (2 + vs)) - 1)) << (1 - vs);
+                    ix = mvx >> (2 + hs); iy = mvy >> (2 + vs);
+                }
+                uint16_t win[(64 + 7) * (64 + 8)];
+                int ws = 64 + 8;
+                fetch_window(ref, c, bx + ix - before, by + iy - before, bw + taps - 1, bh + taps - 1, win, ws);
+                mc_intermediate_16(bd, taps, v[l], win + before * ws + before, ws, bw, bh, fx, fy);
+            }
+            uint8_t *dst = cur->data[c] + (ptrdiff_t)by * cur->stride[c] + (ptrdiff_t)bx * (bd > 8 ? 2 : 1);
+            ptrdiff_t ds = cur->stride[c];
+            int denom = wp ? wp->log2_denom[c ? 1 : 0] : 0;
+            if (used[0] && used[1]) {
+                for (int k = 0; k < bw * bh; k++)
+                    v0_16[k] = (int16_t)v[0][k];           /* put_hevc_*pel into int16 tmp, hevc.c:1761 */
+                if (!wp)
+                    DISPATCH(bd, mc_store_bi_8(bd, dst, ds, v[1], v0_16, bw, bw, bh),
+                                 mc_store_bi_16(bd, (uint16_t *)dst, ds / 2, v[1], v0_16, bw, bw, bh));
+                else
+                    DISPATCH(bd, mc_store_bi_w_8(bd, dst, ds, v[1], v0_16, bw, bw, bh, denom,
+                                                 wp->w[0][c], wp->w[1][c], wp->o[0][c], wp->o[1][c]),
+                                 mc_store_bi_w_16(bd, (uint16_t *)dst, ds / 2, v[1], v0_16, bw, bw, bh, denom,
+                                                  wp->w[0][c], wp->w[1][c], wp->o[0][c], wp->o[1][c]));
+            } else if (used[0] || used[1]) {
+                int l = used[0] ? 0 : 1;
+                if (!wp)
+                    DISPATCH(bd, mc_store_uni_8(bd, dst, ds, v[l], bw, bh),
+                                 mc_store_uni_16(bd, (uint16_t *)dst, ds / 2, v[l], bw, bh));
+                else
+                    DISPATCH(bd, mc_store_uni_w_8(bd, dst, ds, v[l], bw, bh, denom, wp->w[l][c], wp->o[l][c]),
+                                 mc_store_uni_w_16(bd, (uint16_t *)dst, ds / 2, v[l], bw, bh, denom, wp->w[l][c], wp->o[l][c]));
+            } else {
+                return -1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ---- pass 2: residual (hevc_cabac.c:1868-1949) ---- */
+static void tu_inverse(int bd, const OhTu *tu, int16_t *c)
+{
+    int log2 = tu->log2_size;
+    switch (tu->kind) {
+    case OH_TU_IDCT:   oh_or_idct(bd, c, log2); break;
+    case OH_TU_DST4:   oh_or_idct_4x4_luma(bd, c); break;
+    case OH_TU_SKIP:
+        if (tu->flags & OH_TUF_ROTATE)                    /* hevc_cabac.c:1879-1882 */
+            for (int i = 0; i < 8; i++) { int16_t t = c[i]; c[i] = c[15 - i]; c[15 - i] = t; }
+        oh_or_transform_skip(bd, c, log2);
+        if (tu->flags & OH_TUF_RDPCM)
+            oh_or_transform_rdpcm(c, log2, !!(tu->flags & OH_TUF_RDPCM_VER));
+        break;
+    case OH_TU_BYPASS:
+        if (tu->flags & OH_TUF_RDPCM)
+            oh_or_transform_rdpcm(c, log2, !!(tu->flags & OH_TUF_RDPCM_VER));
+        break;
+    default: break;
+    }
+}
+
+static void tu_store(const OhFrame *f, OhHostPic *cur, const OhTu *tu, const int16_t *res)
+{
+    int bd = f->p.bit_depth, n = 1 << tu->log2_size;
+    uint8_t *dst = cur->data[tu->c_idx] + (ptrdiff_t)tu->y * cur->stride[tu->c_idx] + (ptrdiff_t)tu->x * (bd > 8 ? 2 : 1);
+    if (tu->kind == OH_TU_PCM) {                           /* put_pcm, hevcdsp_template.c:30-43 */
+        for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++) {
+                if (bd > 8) ((uint16_t *)(dst + y * cur->stride[tu->c_idx]))[x] = (uint16_t)res[y * n + x];
+                else        dst[y * cur->stride[tu->c_idx] + x] = (uint8_t)res[y * n + x];
+            }
+    } else {
+        oh_or_transform_add(bd, dst, res, cur->stride[tu->c_idx], tu->log2_size);
+    }
+}
+
+int oh_or_pass_residual(const OhFrame *f, OhHostPic *pics, int16_t *coeffs)
+{
+    OhHostPic *cur = &pics[f->cur_pic];
+    for (uint32_t i = 0; i < f->n_tu; i++) {
+        const OhTu *tu = &f->tu[i];
+        int16_t *c = coeffs + tu->coeff_off;
+        tu_inverse(f->p.bit_depth, tu, c);
+        if (tu->flags & OH_TUF_ADD_NOW)
+            tu_store(f, cur, tu, c);
+    }
+    return 0;
+}
+
+/* ---- pass 3: intra prediction + deferred residual add, level by level ---- */
+int oh_or_pass_intra(const OhFrame *f, OhHostPic *pics, const int16_t *residuals)
+{
+    OhHostPic *cur = &pics[f->cur_pic];
+    for (uint32_t i = 0; i < f->n_intra; i++) {
+        const OhIntra *it = &f->intra[i];
+        int c = it->c_idx;
+        oh_or_intra_pred(&f->p, cur->data[c], cur->stride[c], cur->width[c], cur->height[c],
+                         it->x, it->y, c, it->log2_size, it->mode, it->avail);
+        if (it->tu != OH_NO_COEFF) {
+            const OhTu *tu = &f->tu[it->tu];
+            tu_store(f, cur, tu, residuals + tu->coeff_off);
+        }
+    }
+    return 0;
+}
+
+/* ---- pass 4: deblocking (hevc_filter.c:345-581), restated as two whole-picture passes:
+ * all vertical edges, then all horizontal edges.  The per-CTB driver's parameter quirks are kept
+ * as functions of the edge position (see DESIGN.md "deblock parameter rules"). ---- */
+static int get_qpy(const OhFrame *f, int x, int y)                       /* hevc_filter.c:143-149 */
+{
+    int l = f->p.log2_min_cb_size;
+    return f->qp_y_tab[(x >> l) + (y >> l) * oh_min_cb_width(&f->p)];
+}
+static int get_pcm(const OhFrame *f, int x, int y)                       /* hevc_filter.c:324-338 */
+{
+    int l = f->p.log2_min_pu_size;
+    if (x < 0 || y < 0)
+        return 2;
+    if ((x >> l) >= oh_min_pu_width(&f->p) || (y >> l) >= oh_min_pu_height(&f->p))
+        return 2;
+    return f->is_pcm ? f->is_pcm[(y >> l) * oh_min_pu_width(&f->p) + (x >> l)] : 0;
+}
+static int luma_tc(int qp, int bs, int tc_offset)                        /* TC_CALC, hevc_filter.c:340-343 */
+{
+    return oh_tc_table[oh_clip3(qp + 2 * (bs - 1) + (tc_offset >> 1 << 1), 0, 53)];
+}
+static int chroma_tc(const OhFrame *f, int qp_y, int c_idx, int tc_offset) /* hevc_filter.c:62-89 */
+{
+    static const uint8_t qp_c[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
+    int qp_i = oh_clip3(qp_y + (c_idx == 1 ? f->p.cb_qp_offset : f->p.cr_qp_offset), 0, 57);
+    int qp;
+    if (f->p.chroma_format_idc == 1)
+        qp = qp_i < 30 ? qp_i : (qp_i > 43 ? qp_i - 6 : qp_c[qp_i - 30]);
+    else
+        qp = oh_clip3(qp_i, 0, 51);
+    return oh_tc_table[oh_clip3(qp + 2 + tc_offset, 0, 53)];
+}
+
+int oh_or_pass_deblock(const OhFrame *f, OhHostPic *pics)
+{
+    const OhPicParams *p = &f->p;
+    OhHostPic *cur = &pics[f->cur_pic];
+    if (!p->deblock_enabled)
+        return 0;
+    int bd = p->bit_depth, bpp = bd > 8 ? 2 : 1;
+    int W = p->width, H = p->height, bsw = W >> 2;
+    int lc = p->log2_ctb_size, ctbw = oh_ctb_width(p);
+    int pcmf = p->pcm_loop_filter_disable || p->transquant_bypass_enable;
+    int hs = oh_hshift(p, 1), vs = oh_vshift(p, 1), hh = 1 << hs, vv = 1 << vs;
+    uint8_t no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+    int tc[2], tc2[2];
+
+    /* vertical edges: every parameter comes from the CTB that contains the edge (the Q side) */
+    for (int y = 0; y < H; y += 8)
+        for (int x = 8; x < W; x += 8) {
+            int bs0 = f->vertical_bs[(x + y * bsw) >> 2], bs1 = f->vertical_bs[(x + (y + 4) * bsw) >> 2];
+            if (!bs0 && !bs1)
+                continue;
+            const OhDeblockCtb *db = &f->deblock[(y >> lc) * ctbw + (x >> lc)];
+            int qp = (get_qpy(f, x - 1, y) + get_qpy(f, x, y) + 1) >> 1;
+            int beta = oh_beta_table[oh_clip3(qp + db->beta_offset, 0, 51)];
+            tc[0] = bs0 ? luma_tc(qp, bs0, db->tc_offset) : 0;
+            tc[1] = bs1 ? luma_tc(qp, bs1, db->tc_offset) : 0;
+            if (pcmf) {
+                no_p[0] = (uint8_t)get_pcm(f, x - 1, y); no_p[1] = (uint8_t)get_pcm(f, x - 1, y + 4);
+                no_q[0] = (uint8_t)get_pcm(f, x, y);     no_q[1] = (uint8_t)get_pcm(f, x, y + 4);
+            }
+            oh_or_loop_filter_luma(bd, cur->data[0] + (ptrdiff_t)y * cur->stride[0] + x * bpp,
+                                   bpp, cur->stride[0], beta, tc, no_p, no_q);
+        }
+    if (p->chroma_format_idc)
+        for (int y = 0; y < H; y += 8 * vv)
+            for (int x = 8 * hh; x < W; x += 8 * hh) {
+                int bs0 = f->vertical_bs[(x + y * bsw) >> 2], bs1 = f->vertical_bs[(x + (y + 4 * vv) * bsw) >> 2];
+                if (bs0 != 2 && bs1 != 2)
+                    continue;
+                const OhDeblockCtb *db = &f->deblock[(y >> lc) * ctbw + (x >> lc)];
+                int qp0 = (get_qpy(f, x - 1, y) + get_qpy(f, x, y) + 1) >> 1;
+                int qp1 = (get_qpy(f, x - 1, y + 4 * vv) + get_qpy(f, x, y + 4 * vv) + 1) >> 1;
+                tc[0]  = bs0 == 2 ? chroma_tc(f, qp0, 1, db->tc_offset) : 0;
+                tc[1]  = bs1 == 2 ? chroma_tc(f, qp1, 1, db->tc_offset) : 0;
+                tc2[0] = bs0 == 2 ? chroma_tc(f, qp0, 2, db->tc_offset) : 0;
+                tc2[1] = bs1 == 2 ? chroma_tc(f, qp1, 2, db->tc_offset) : 0;
+                if (pcmf) {
+                    no_p[0] = (uint8_t)get_pcm(f, x - 1, y); no_p[1] = (uint8_t)get_pcm(f, x - 1, y + 4 * vv);
+                    no_q[0] = (uint8_t)get_pcm(f, x, y);     no_q[1] = (uint8_t)get_pcm(f, x, y + 4 * vv);
+                }
+                oh_or_loop_filter_chroma(bd, cur->data[1] + (ptrdiff_t)(y >> vs) * cur->stride[1] + (x >> hs) * bpp,
+                                         bpp, cur->stride[1], tc, no_p, no_q);
+                oh_or_loop_filter_chroma(bd, cur->data[2] + (ptrdiff_t)(y >> vs) * cur->stride[2] + (x >> hs) * bpp,
+                                         bpp, cur->stride[2], tc2, no_p, no_q);
+            }
+
+    /* horizontal edges.  The reference filters [x0-8, x_end-8) inside CTB (x0,..)'s call, so the
+     * "processing CTB" of an edge at x is the one containing x+8 (x+8h for chroma), capped to the
+     * last column; tc comes from the processing CTB, beta from the CTB that contains x
+     * (hevc_filter.c:481-520), chroma's first segment takes tc from the CTB containing x and its
+     * second segment from the processing CTB (:523-580). */
+    for (int y = 8; y < H; y += 8)
+        for (int x = 0; x < W; x += 8) {
+            int bs0 = f->horizontal_bs[(x + y * bsw) >> 2], bs1 = f->horizontal_bs[((x + 4) + y * bsw) >> 2];
+            if (!bs0 && !bs1)
+                continue;
+            int pcx = (x + 8) >> lc; if (pcx > ctbw - 1) pcx = ctbw - 1;
+            const OhDeblockCtb *dbp = &f->deblock[(y >> lc) * ctbw + pcx];
+            const OhDeblockCtb *dbx = &f->deblock[(y >> lc) * ctbw + (x >> lc)];
+            int qp = (get_qpy(f, x, y - 1) + get_qpy(f, x, y) + 1) >> 1;
+            int beta = oh_beta_table[oh_clip3(qp + dbx->beta_offset, 0, 51)];
+            tc[0] = bs0 ? luma_tc(qp, bs0, dbp->tc_offset) : 0;
+            tc[1] = bs1 ? luma_tc(qp, bs1, dbp->tc_offset) : 0;
+            if (pcmf) {
+                no_p[0] = (uint8_t)get_pcm(f, x, y - 1); no_p[1] = (uint8_t)get_pcm(f, x + 4, y - 1);
+                no_q[0] = (uint8_t)get_pcm(f, x, y);     no_q[1] = (uint8_t)get_pcm(f, x + 4, y);
+            }
+            oh_or_loop_filter_luma(bd, cur->data[0] + (ptrdiff_t)y * cur->stride[0] + x * bpp,
+                                   cur->stride[0], bpp, beta, tc, no_p, no_q);
+        }
+    if (p->chroma_format_idc)
+        for (int y = 8 * vv; y < H; y += 8 * vv)
+            for (int x = 0; x < W; x += 8 * hh) {
+                int bs0 = f->horizontal_bs[(x + y * bsw) >> 2], bs1 = f->horizontal_bs[((x + 4 * hh) + y * bsw) >> 2];
+                if (bs0 != 2 && bs1 != 2)
+                    continue;
+                int pcx = (x + 8 * hh) >> lc; if (pcx > ctbw - 1) pcx = ctbw - 1;
+                int tco_p = f->deblock[(y >> lc) * ctbw + pcx].tc_offset;
+                int tco_x = f->deblock[(y >> lc) * ctbw + (x >> lc)].tc_offset;
+                int qp0 = bs0 == 2 ? (get_qpy(f, x, y - 1) + get_qpy(f, x, y) + 1) >> 1 : 0;
+                int qp1 = bs1 == 2 ? (get_qpy(f, x + 4 * hh, y - 1) + get_qpy(f, x + 4 * hh, y) + 1) >> 1 : 0;
+                tc[0]  = bs0 == 2 ? chroma_tc(f, qp0, 1, tco_x) : 0;
+                tc[1]  = bs1 == 2 ? chroma_tc(f, qp1, 1, tco_p) : 0;
+                tc2[0] = bs0 == 2 ? chroma_tc(f, qp0, 2, tco_x) : 0;
+                tc2[1] = bs1 == 2 ? chroma_tc(f, qp1, 2, tco_p) : 0;
+                if (pcmf) {
+                    no_p[0] = (uint8_t)get_pcm(f, x, y - 1); no_p[1] = (uint8_t)get_pcm(f, x + 4 * hh, y - 1);
+                    no_q[0] = (uint8_t)get_pcm(f, x, y);     no_q[1] = (uint8_t)get_pcm(f, x + 4 * hh, y);
+                }
+                oh_or_loop_filter_chroma(bd, cur->data[1] + (ptrdiff_t)(y >> vs) * cur->stride[1] + (x >> hs) * bpp,
+                                         cur->stride[1], bpp, tc, no_p, no_q);
+                oh_or_loop_filter_chroma(bd, cur->data[2] + (ptrdiff_t)(y >> vs) * cur->stride[2] + (x >> hs) * bpp,
+                                         cur->stride[2], bpp, tc2, no_p, no_q);
+            }
+    return 0;
+}
+
+/* ---- pass 5: SAO (hevc_filter.c:197-322) restated as one whole-picture pass from a copy of the
+ * deblocked picture (the reference keeps that copy CTB by CTB in s->sao_frame) ---- */
+int oh_or_pass_sao(const OhFrame *f, OhHostPic *pics)
+{
+    const OhPicParams *p = &f->p;
+    OhHostPic *cur = &pics[f->cur_pic];
+    if (!p->sao_enabled || !f->sao)
+        return 0;
+    int bd = p->bit_depth, bpp = bd > 8 ? 2 : 1;
+    int ctbw = oh_ctb_width(p), ctbh = oh_ctb_height(p), lc = p->log2_ctb_size;
+    int nplanes = p->chroma_format_idc ? 3 : 1;
+    int tqb = p->transquant_bypass_enable || p->pcm_loop_filter_disable;
+
+    for (int c = 0; c < nplanes; c++) {
+        int hs = oh_hshift(p, c), vs = oh_vshift(p, c);
+        int pw = cur->width[c], ph = cur->height[c];
+        ptrdiff_t st = cur->stride[c];
+        uint8_t *copy = (uint8_t *)malloc((size_t)st * ph);
+        if (!copy)
+            return -1;
+        memcpy(copy, cur->data[c], (size_t)st * ph);
+        for (int cy = 0; cy < ctbh; cy++)
+            for (int cx = 0; cx < ctbw; cx++) {
+                const OhSaoCtb *s = &f->sao[cy * ctbw + cx];
+                int x0 = (cx << lc) >> hs, y0 = (cy << lc) >> vs;
+                int w = (1 << lc) >> hs, h = (1 << lc) >> vs;
+                if (w > pw - x0) w = pw - x0;
+                if (h > ph - y0) h = ph - y0;
+                int borders[4] = { cx == 0, cy == 0, cx == ctbw - 1, cy == ctbh - 1 };
+                uint8_t ve[2] = { (uint8_t)(s->edge_flags & 1), (uint8_t)((s->edge_flags >> 1) & 1) };
+                uint8_t he[2] = { (uint8_t)((s->edge_flags >> 2) & 1), (uint8_t)((s->edge_flags >> 3) & 1) };
+                uint8_t de[4] = { (uint8_t)((s->edge_flags >> 4) & 1), (uint8_t)((s->edge_flags >> 5) & 1),
+                                  (uint8_t)((s->edge_flags >> 6) & 1), (uint8_t)((s->edge_flags >> 7) & 1) };
+                uint8_t *dst = cur->data[c] + (ptrdiff_t)y0 * st + x0 * bpp;
+                const uint8_t *src = copy + (ptrdiff_t)y0 * st + x0 * bpp;
+                if (s->type_idx[c] == 1)
+                    oh_or_sao_band(bd, dst, src, st, st, s->offset_val[c], s->band_position[c], w, h);
+                else if (s->type_idx[c] == 2)
+                    oh_or_sao_edge(bd, dst, src, st, st, s->offset_val[c], s->eo_class[c], borders, w, h,
+                                   s->edge_flags != 0, ve, he, de);
+                else
+                    continue;
+                /* restore_tqb_pixels (hevc_filter.c:163-193): called with the CTB's LUMA origin but
+                 * the COMPONENT's width/height, so for subsampled chroma only the min-PUs of the
+                 * luma rectangle [X0, X0+w) x [Y0, Y0+h) are restored — kept as is. */
+                if (tqb && f->is_pcm) {
+                    int l = p->log2_min_pu_size, mpw = oh_min_pu_width(p);
+                    int X0 = cx << lc, Y0 = cy << lc;
+                    for (int py = Y0 >> l; py < (Y0 + h) >> l; py++)
+                        for (int px = X0 >> l; px < (X0 + w) >> l; px++) {
+                            if (!f->is_pcm[py * mpw + px])
+                                continue;
+                            int sx = (px << l) >> hs, sy = (py << l) >> vs;
+                            int len = (1 << l) >> hs;   /* BYTES, not samples: the reference's memcpy
+                                                           length ignores pixel_shift (:177,:185) */
+                            for (int n = 0; n < (1 << l) >> vs; n++)
+                                memcpy(cur->data[c] + (ptrdiff_t)(sy + n) * st + sx * bpp,
+                                       copy + (ptrdiff_t)(sy + n) * st + sx * bpp, (size_t)len);
+                        }
+                }
+            }
+        free(copy);
+    }
+    return 0;
+}
+
+int oh_or_frame(const OhFrame *f, OhHostPic *pics)
+{
+    int16_t *c = (int16_t *)malloc(sizeof(int16_t) * (size_t)(f->n_coeff ? f->n_coeff : 1));
+    int r = 0;
+    if (!c)
+        return -1;
+    if (f->n_coeff)
+        memcpy(c, f->coeffs, sizeof(int16_t) * (size_t)f->n_coeff);
+    if (!r) r = oh_or_pass_inter(f, pics);
+    if (!r) r = oh_or_pass_residual(f, pics, c);
+    if (!r) r = oh_or_pass_intra(f, pics, c);
+    if (!r) r = oh_or_pass_deblock(f, pics);
+    if (!r) r = oh_or_pass_sao(f, pics);
+    free(c);
+    return r;
+}

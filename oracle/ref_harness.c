@@ -1,0 +1,344 @@
+/*
+ * ref_harness.c — thin C entry points around the REAL reference kernels.
+ * TEST INFRASTRUCTURE ONLY.  Compiled together with hevcdsp.c / hevcpred.c / videodsp.c /
+ * hevc_filter.c taken directly from /root/reference (see oracle/Makefile); the result,
+ * oracle/_ref/libohevc_ref.so, exists only in this container (it is git-ignored and is never
+ * needed on the GPU box: fixtures generated from it are committed under tests/golden/).
+ *
+ * Nothing here re-implements reference arithmetic: the functions fill the reference's own
+ * structs (HEVCContext, HEVCSPS, HEVCPPS, SAOParams ...) from plain arguments / an OhFrame and
+ * call the reference's tables (ff_hevc_dsp_init, ff_hevc_pred_init, ff_videodsp_init) and
+ * drivers (ff_hevc_hls_filters / ff_hevc_hls_filter).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "libavcodec/hevc.h"
+#include "libavcodec/hevcdsp.h"
+#include "libavcodec/hevcpred.h"
+#include "libavcodec/videodsp.h"
+
+#include "../include/ohevc_frame.h"
+
+#define API __attribute__((visibility("default")))
+
+static HEVCDSPContext  g_dsp[15];
+static HEVCPredContext g_pred[15];
+static VideoDSPContext g_vdsp[15];
+static int g_ready[15];
+
+static void tables(int bd)
+{
+    if (g_ready[bd])
+        return;
+    ff_hevc_dsp_init(&g_dsp[bd], bd);          /* hevcdsp.c:1071 */
+    ff_hevc_pred_init(&g_pred[bd], bd);        /* hevcpred.c:47  */
+    ff_videodsp_init(&g_vdsp[bd], bd);         /* videodsp.c:33  */
+    g_ready[bd] = 1;
+}
+
+static int pel_idx(int w)                      /* ff_hevc_pel_weight, hevc.c:42 */
+{
+    switch (w) {
+    case 2: return 0; case 4: return 1; case 6: return 2; case 8: return 3; case 12: return 4;
+    case 16: return 5; case 24: return 6; case 32: return 7; case 48: return 8; default: return 9;
+    }
+}
+
+/* ---------------- residual slots ---------------- */
+API void ref_transform_add(int bd, int log2, uint8_t *dst, int16_t *coeffs, ptrdiff_t stride)
+{ tables(bd); g_dsp[bd].transform_add[log2 - 2](dst, coeffs, stride); }
+API void ref_transform_skip(int bd, int16_t *c, int log2)
+{ tables(bd); g_dsp[bd].transform_skip(c, (int16_t)log2); }
+API void ref_transform_rdpcm(int bd, int16_t *c, int log2, int mode)
+{ tables(bd); g_dsp[bd].transform_rdpcm(c, (int16_t)log2, mode); }
+API void ref_idct_4x4_luma(int bd, int16_t *c)
+{ tables(bd); g_dsp[bd].idct_4x4_luma(c); }
+API void ref_idct(int bd, int log2, int16_t *c, int col_limit)
+{ tables(bd); g_dsp[bd].idct[log2 - 2](c, col_limit); }
+API void ref_idct_dc(int bd, int log2, int16_t *c)
+{ tables(bd); g_dsp[bd].idct_dc[log2 - 2](c); }
+
+/* ---------------- interpolation slots ----------------
+ * variant: 0 put (dst is int16_t*, dststride in elements), 1 uni, 2 bi, 3 uni_w, 4 bi_w */
+API void ref_mc(int bd, int epel, int variant, uint8_t *dst, ptrdiff_t dststride,
+                uint8_t *src, ptrdiff_t srcstride, int16_t *src2, ptrdiff_t src2stride,
+                int h, int denom, int wx0, int wx1, int ox0, int ox1, int mx, int my, int w)
+{
+    HEVCDSPContext *d;
+    int i = pel_idx(w), a = !!my, b = !!mx;
+    tables(bd);
+    d = &g_dsp[bd];
+    switch (variant) {
+    case 0:
+        (epel ? d->put_hevc_epel : d->put_hevc_qpel)[i][a][b]((int16_t *)dst, dststride, src, srcstride, h, mx, my, w);
+        break;
+    case 1:
+        (epel ? d->put_hevc_epel_uni : d->put_hevc_qpel_uni)[i][a][b](dst, dststride, src, srcstride, h, mx, my, w);
+        break;
+    case 2:
+        (epel ? d->put_hevc_epel_bi : d->put_hevc_qpel_bi)[i][a][b](dst, dststride, src, srcstride, src2, src2stride, h, mx, my, w);
+        break;
+    case 3:
+        (epel ? d->put_hevc_epel_uni_w : d->put_hevc_qpel_uni_w)[i][a][b](dst, dststride, src, srcstride, h, denom, wx0, ox0, mx, my, w);
+        break;
+    default:
+        /* argument POSITIONS as at the call sites hevc.c:1767-1773 / 1940-1948 */
+        (epel ? d->put_hevc_epel_bi_w : d->put_hevc_qpel_bi_w)[i][a][b](dst, dststride, src, srcstride, src2, src2stride,
+                                                                      h, denom, wx0, wx1, ox0, ox1, mx, my, w);
+        break;
+    }
+}
+
+API void ref_emulated_edge_mc(int bd, uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize,
+                              ptrdiff_t src_linesize, int block_w, int block_h, int src_x, int src_y, int w, int h)
+{ tables(bd); g_vdsp[bd].emulated_edge_mc(buf, src, buf_linesize, src_linesize, block_w, block_h, src_x, src_y, w, h); }
+
+/* ---------------- intra slots ---------------- */
+API void ref_pred_planar(int bd, int log2, uint8_t *src, const uint8_t *top, const uint8_t *left, ptrdiff_t stride)
+{ tables(bd); g_pred[bd].pred_planar[log2 - 2](src, top, left, stride); }
+API void ref_pred_dc(int bd, int log2, uint8_t *src, const uint8_t *top, const uint8_t *left, ptrdiff_t stride, int c_idx)
+{ tables(bd); g_pred[bd].pred_dc(src, top, left, stride, log2, c_idx); }
+API void ref_pred_angular(int bd, int log2, uint8_t *src, const uint8_t *top, const uint8_t *left,
+                          ptrdiff_t stride, int c_idx, int mode)
+{ tables(bd); g_pred[bd].pred_angular[log2 - 2](src, top, left, stride, c_idx, mode); }
+
+/* ---------------- deblock slots; which: 0 h_luma 1 v_luma 2 h_chroma 3 v_chroma, +4 for _c ---------------- */
+API void ref_loop_filter(int bd, int which, uint8_t *pix, ptrdiff_t stride, int beta, int *tc,
+                         uint8_t *no_p, uint8_t *no_q)
+{
+    HEVCDSPContext *d;
+    tables(bd);
+    d = &g_dsp[bd];
+    switch (which) {
+    case 0: d->hevc_h_loop_filter_luma(pix, stride, beta, tc, no_p, no_q); break;
+    case 1: d->hevc_v_loop_filter_luma(pix, stride, beta, tc, no_p, no_q); break;
+    case 2: d->hevc_h_loop_filter_chroma(pix, stride, tc, no_p, no_q); break;
+    case 3: d->hevc_v_loop_filter_chroma(pix, stride, tc, no_p, no_q); break;
+    case 4: d->hevc_h_loop_filter_luma_c(pix, stride, beta, tc, no_p, no_q); break;
+    case 5: d->hevc_v_loop_filter_luma_c(pix, stride, beta, tc, no_p, no_q); break;
+    case 6: d->hevc_h_loop_filter_chroma_c(pix, stride, tc, no_p, no_q); break;
+    default: d->hevc_v_loop_filter_chroma_c(pix, stride, tc, no_p, no_q); break;
+    }
+}
+
+/* ---------------- SAO slots ---------------- */
+static void fill_sao(SAOParams *s, int c_idx, const int16_t *offset_val, int band_position, int eo_class)
+{
+    memset(s, 0, sizeof(*s));
+    for (int k = 0; k < 5; k++)
+        s->offset_val[c_idx][k] = offset_val[k];
+    s->band_position[c_idx] = (uint8_t)band_position;
+    s->eo_class[c_idx] = (uint8_t)eo_class;
+}
+API void ref_sao_band(int bd, uint8_t *dst, uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const int16_t *offset_val,
+                      int band_position, int *borders, int w, int h, int c_idx)
+{
+    SAOParams s;
+    tables(bd);
+    fill_sao(&s, c_idx, offset_val, band_position, 0);
+    g_dsp[bd].sao_band_filter(dst, src, sd, ss, &s, borders, w, h, c_idx);
+}
+API void ref_sao_edge(int bd, int variant, uint8_t *dst, uint8_t *src, ptrdiff_t sd, ptrdiff_t ss,
+                      const int16_t *offset_val, int eo_class, int *borders, int w, int h, int c_idx,
+                      uint8_t *vert_edge, uint8_t *horiz_edge, uint8_t *diag_edge)
+{
+    SAOParams s;
+    tables(bd);
+    fill_sao(&s, c_idx, offset_val, 0, eo_class);
+    g_dsp[bd].sao_edge_filter[variant](dst, src, sd, ss, &s, borders, w, h, c_idx, vert_edge, horiz_edge, diag_edge);
+}
+
+/* =========================================================================================
+ * picture-level: a synthetic HEVCContext around caller-owned planes
+ * ======================================================================================= */
+typedef struct RefCtx {
+    HEVCContext       s;
+    HEVCLocalContext  lc;
+    HEVCSPS           sps;
+    HEVCPPS           pps;
+    HEVCFrame         ref;
+    AVFrame           frame, sao_frame;
+    int              *zs_tab, *rs_to_ts, *tile_id;
+} RefCtx;
+
+static void ctx_free(RefCtx *r)
+{
+    free(r->zs_tab); free(r->rs_to_ts); free(r->tile_id);
+    free(r->s.filter_slice_edges); free(r->s.tab_slice_address);
+    free(r->s.sao); free(r->s.deblock);
+    free(r);
+}
+
+/* fills sps/pps exactly as hevc_ps.c derives them from the syntax (hevc_ps.c:2001-2011, 2545-2569),
+ * single slice, single tile */
+static RefCtx *ctx_new(const OhPicParams *p, uint8_t *const data[3], const ptrdiff_t stride[3])
+{
+    RefCtx *r = calloc(1, sizeof(*r));
+    HEVCSPS *sps = &r->sps;
+    HEVCPPS *pps = &r->pps;
+    int ctbs, n, d;
+
+    sps->width = p->width; sps->height = p->height;
+    sps->bit_depth = p->bit_depth; sps->pixel_shift = p->bit_depth > 8;
+    sps->chroma_array_type = p->chroma_format_idc; sps->chroma_format_idc = p->chroma_format_idc;
+    sps->hshift[0] = sps->vshift[0] = 0;
+    sps->hshift[1] = sps->hshift[2] = oh_hshift(p, 1);
+    sps->vshift[1] = sps->vshift[2] = oh_vshift(p, 1);
+    sps->log2_ctb_size = p->log2_ctb_size; sps->log2_min_cb_size = p->log2_min_cb_size;
+    sps->log2_min_tb_size = p->log2_min_tb_size; sps->log2_min_pu_size = p->log2_min_pu_size;
+    sps->ctb_width = oh_ctb_width(p); sps->ctb_height = oh_ctb_height(p);
+    sps->ctb_size = sps->ctb_width * sps->ctb_height;
+    sps->min_cb_width = p->width >> p->log2_min_cb_size; sps->min_cb_height = p->height >> p->log2_min_cb_size;
+    sps->min_tb_width = p->width >> p->log2_min_tb_size; sps->min_tb_height = p->height >> p->log2_min_tb_size;
+    sps->min_pu_width = p->width >> p->log2_min_pu_size; sps->min_pu_height = p->height >> p->log2_min_pu_size;
+    sps->tb_mask = (1 << (p->log2_ctb_size - p->log2_min_tb_size)) - 1;
+    sps->qp_bd_offset = 6 * (p->bit_depth - 8);
+    sps->sao_enabled = (uint8_t)p->sao_enabled;
+    sps->pcm_enabled_flag = p->pcm_loop_filter_disable;
+    sps->pcm.loop_filter_disable_flag = (uint8_t)p->pcm_loop_filter_disable;
+    sps->sps_strong_intra_smoothing_enable_flag = (uint8_t)p->strong_intra_smoothing;
+    sps->spsRext.intra_smoothing_disabled_flag = (uint8_t)p->intra_smoothing_disabled;
+
+    pps->cb_qp_offset = p->cb_qp_offset; pps->cr_qp_offset = p->cr_qp_offset;
+    pps->transquant_bypass_enable_flag = (uint8_t)p->transquant_bypass_enable;
+    pps->loop_filter_across_tiles_enabled_flag = 1;
+    ctbs = sps->ctb_size;
+    r->rs_to_ts = malloc(sizeof(int) * (size_t)(ctbs + 1));
+    r->tile_id  = calloc((size_t)(ctbs + 1), sizeof(int));
+    for (int i = 0; i <= ctbs; i++) r->rs_to_ts[i] = i;
+    pps->ctb_addr_rs_to_ts = r->rs_to_ts; pps->ctb_addr_ts_to_rs = r->rs_to_ts; pps->tile_id = r->tile_id;
+    n = sps->tb_mask + 2; d = p->log2_ctb_size - p->log2_min_tb_size;
+    r->zs_tab = malloc(sizeof(int) * (size_t)(n * n));
+    pps->min_tb_addr_zs_tab = r->zs_tab;
+    pps->min_tb_addr_zs = &r->zs_tab[n + 1];
+    for (int y = 0; y < n; y++) { r->zs_tab[y * n] = -1; r->zs_tab[y] = -1; }
+    for (int y = 0; y < sps->tb_mask + 1; y++)
+        for (int x = 0; x < sps->tb_mask + 1; x++) {
+            int tb_x = x >> d, tb_y = y >> d;
+            int val = pps->ctb_addr_rs_to_ts[sps->ctb_width * tb_y + tb_x] << (d * 2);
+            for (int i = 0; i < d; i++) {
+                int m = 1 << i;
+                val += (m & x ? m * m : 0) + (m & y ? 2 * m * m : 0);
+            }
+            pps->min_tb_addr_zs[y * n + x] = val;
+        }
+
+    for (int c = 0; c < 3; c++) {
+        r->frame.data[c] = data[c];
+        r->frame.linesize[c] = (int)stride[c];
+    }
+    r->s.sps = sps; r->s.pps = pps;
+    r->s.HEVClc = &r->lc; r->s.HEVClcList[0] = &r->lc;
+    r->s.frame = &r->frame; r->s.sao_frame = &r->sao_frame;
+    r->ref.frame = &r->frame; r->s.ref = &r->ref;
+    r->s.threads_type = 0;
+    ff_hevc_dsp_init(&r->s.hevcdsp, p->bit_depth);
+    ff_hevc_pred_init(&r->s.hpc, p->bit_depth);
+    ff_videodsp_init(&r->s.vdsp, p->bit_depth);
+    return r;
+}
+
+/* Runs the intra items of an OhFrame through the reference's s->hpc.intra_pred[] slots in list
+ * order, adding the (already inverse-transformed) residual after each block like
+ * hls_transform_unit does (hevc.c:1215-1417).  The candidate flags are derived HERE the way the
+ * reference derives lc->na for a single-slice, single-tile picture (hevc.c:2592-2642 +
+ * hevc_mvs.c:41-58) — they are NOT taken from OhIntra.avail, so the test also checks the
+ * availability computation of whoever built the work list. */
+API int ref_intra_picture(const OhFrame *f, uint8_t *const data[3], const ptrdiff_t stride[3],
+                          const int16_t *residuals)
+{
+    const OhPicParams *p = &f->p;
+    RefCtx *r = ctx_new(p, data, stride);
+    HEVCContext *s = &r->s;
+    HEVCLocalContext *lc = &r->lc;
+    int ctb = 1 << p->log2_ctb_size;
+
+    for (uint32_t i = 0; i < f->n_intra; i++) {
+        const OhIntra *it = &f->intra[i];
+        int c = it->c_idx, hs = oh_hshift(p, c), vs = oh_vshift(p, c);
+        int x0 = it->x << hs, y0 = it->y << vs;                /* luma units, as hevc.c passes them */
+        int n_h = (1 << it->log2_size) << hs, n_v = (1 << it->log2_size) << vs;
+        int x_ctb = x0 & ~(ctb - 1), y_ctb = y0 & ~(ctb - 1);
+        int x0b = x0 & (ctb - 1), y0b = y0 & (ctb - 1);
+        int ctb_addr = (y_ctb >> p->log2_ctb_size) * r->sps.ctb_width + (x_ctb >> p->log2_ctb_size);
+        /* hls_decode_neighbour for slice_addr 0, no tiles */
+        lc->ctb_left_flag     = x_ctb > 0 && ctb_addr > 0;
+        lc->ctb_up_flag       = y_ctb > 0 && ctb_addr >= r->sps.ctb_width;
+        lc->ctb_up_right_flag = y_ctb > 0 && ctb_addr + 1 >= r->sps.ctb_width;
+        lc->ctb_up_left_flag  = x_ctb > 0 && y_ctb > 0 && ctb_addr - 1 >= r->sps.ctb_width;
+        lc->end_of_tiles_x = p->width;
+        lc->end_of_tiles_y = y_ctb + ctb < p->height ? y_ctb + ctb : p->height;
+        /* ff_hevc_set_neighbour_available(s, x0, y0, n_h, n_v) */
+        lc->na.cand_up       = lc->ctb_up_flag || y0b;
+        lc->na.cand_left     = lc->ctb_left_flag || x0b;
+        lc->na.cand_up_left  = (!x0b && !y0b) ? lc->ctb_up_left_flag : lc->na.cand_left && lc->na.cand_up;
+        lc->na.cand_up_right_sap = (x0b + n_h == ctb) ? lc->ctb_up_right_flag && !y0b : lc->na.cand_up;
+        lc->na.cand_up_right = lc->na.cand_up_right_sap && (x0 + n_h) < lc->end_of_tiles_x;
+        lc->na.cand_bottom_left = ((y0 + n_v) >= lc->end_of_tiles_y) ? 0 : lc->na.cand_left;
+        lc->tu.intra_pred_mode = lc->tu.intra_pred_mode_c = it->mode;
+
+        s->hpc.intra_pred[it->log2_size - 2](s, x0, y0, c);
+
+        if (it->tu != OH_NO_COEFF) {
+            const OhTu *tu = &f->tu[it->tu];
+            uint8_t *dst = data[c] + (ptrdiff_t)tu->y * stride[c] + ((ptrdiff_t)tu->x << r->sps.pixel_shift);
+            s->hevcdsp.transform_add[tu->log2_size - 2](dst, (int16_t *)(residuals + tu->coeff_off), stride[c]);
+        }
+    }
+    ctx_free(r);
+    return 0;
+}
+
+/* Runs the reference's in-loop filters over a whole picture in the reference's own order: the
+ * CTU loop of hls_decode_entry (hevc.c:2666-2695) calls ff_hevc_hls_filters after every CTB and
+ * ff_hevc_hls_filter for the last one.  `data` is filtered in place; sao planes are scratch with
+ * the same geometry (the reference's s->sao_frame, hevc.c:369-385). */
+API int ref_filter_picture(const OhFrame *f, uint8_t *const data[3], const ptrdiff_t stride[3],
+                           uint8_t *const sao_data[3])
+{
+    const OhPicParams *p = &f->p;
+    RefCtx *r = ctx_new(p, data, stride);
+    HEVCContext *s = &r->s;
+    int ctb = 1 << p->log2_ctb_size;
+    int ctbs = r->sps.ctb_size;
+    int pic_size_in_ctb = (r->sps.min_cb_width + 1) * (r->sps.min_cb_height + 1);
+
+    for (int c = 0; c < 3; c++) {
+        r->sao_frame.data[c] = sao_data[c];
+        r->sao_frame.linesize[c] = (int)stride[c];
+    }
+    s->bs_width = p->width >> 2; s->bs_height = p->height >> 2;
+    s->vertical_bs = (uint8_t *)f->vertical_bs; s->horizontal_bs = (uint8_t *)f->horizontal_bs;
+    s->qp_y_tab = (int8_t *)f->qp_y_tab;
+    s->is_pcm = (uint8_t *)f->is_pcm;
+    s->deblock = calloc((size_t)ctbs, sizeof(*s->deblock));
+    s->sao = calloc((size_t)ctbs, sizeof(*s->sao));
+    s->filter_slice_edges = malloc((size_t)ctbs);
+    s->tab_slice_address = calloc((size_t)pic_size_in_ctb, sizeof(*s->tab_slice_address));
+    for (int i = 0; i < ctbs; i++) {
+        s->deblock[i].beta_offset = f->deblock[i].beta_offset;
+        s->deblock[i].tc_offset = f->deblock[i].tc_offset;
+        s->filter_slice_edges[i] = 1;
+        if (f->sao)
+            for (int c = 0; c < 3; c++) {
+                for (int k = 0; k < 5; k++)
+                    s->sao[i].offset_val[c][k] = f->sao[i].offset_val[c][k];
+                s->sao[i].band_position[c] = f->sao[i].band_position[c];
+                s->sao[i].eo_class[c] = f->sao[i].eo_class[c];
+                s->sao[i].type_idx[c] = f->sao[i].type_idx[c];
+            }
+    }
+    if (!p->deblock_enabled) {            /* the reference has no such switch: all-zero BS is the same */
+        ctx_free(r);
+        return -1;
+    }
+    for (int y_ctb = 0; y_ctb < p->height; y_ctb += ctb)
+        for (int x_ctb = 0; x_ctb < p->width; x_ctb += ctb) {
+            ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb);                       /* hevc.c:2690 */
+            if (x_ctb + ctb >= p->width && y_ctb + ctb >= p->height)
+                ff_hevc_hls_filter(s, x_ctb, y_ctb, ctb);                    /* hevc.c:2693-2695 */
+        }
+    ctx_free(r);
+    return 0;
+}

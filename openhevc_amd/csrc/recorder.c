@@ -1,0 +1,255 @@
+/*
+ * recorder.c — host-side work-item recorder and intra dependency-level scheduler.
+ * Plain C, no GPU dependency (part of libohevc_host.so and libohevc_hip.so).
+ *
+ * The level scheduler is the GPU counterpart of the reference's WPP progress counters
+ * (pthread_slice.c:238-263, hevc.c:2782/2808): instead of "row r may run CTU k when row r-1
+ * finished k+2", every intra block gets level = 1 + max(level of the blocks whose samples it
+ * reads), and pass 3 runs one level at a time.  Inter blocks are level 0 (complete after
+ * passes 1-2).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/ohevc_recorder.h"
+
+struct OhRecorder {
+    OhFrame  f;
+    /* growable item lists */
+    OhPu      *pu;      uint32_t cap_pu;
+    OhWeights *wp;      uint32_t cap_wp;
+    OhTu      *tu;      uint32_t cap_tu;
+    int16_t   *coeffs;  uint64_t cap_coeff;
+    OhIntra   *intra;   uint32_t cap_intra;     /* in recording order */
+    uint32_t  *intra_level;                     /* level of intra[i]  */
+    OhIntra   *sorted;  uint32_t cap_sorted;
+    uint32_t  *level_start; uint32_t cap_levels;
+    uint32_t   max_level;
+    /* side arrays */
+    uint8_t *vbs, *hbs, *is_pcm;
+    int8_t  *qp;
+    OhDeblockCtb *deblock;
+    OhSaoCtb *sao;
+    /* per-plane level map at 4x4-sample granularity, and the luma "decoded" map (4x4 luma) */
+    uint16_t *lvl[3]; int lw[3], lh[3];
+    uint8_t  *decoded; int dw, dh;
+};
+
+static void *grow(void *p, size_t elem, uint64_t *cap, uint64_t need)
+{
+    if (need <= *cap)
+        return p;
+    uint64_t n = *cap ? *cap : 1024;
+    while (n < need)
+        n *= 2;
+    p = realloc(p, (size_t)(n * elem));
+    *cap = n;
+    return p;
+}
+#define GROW32(ptr, cap, need) do { uint64_t c_ = (cap); (ptr) = grow((ptr), sizeof(*(ptr)), &c_, (need)); (cap) = (uint32_t)c_; } while (0)
+
+OhRecorder *oh_rec_create(const OhPicParams *p)
+{
+    OhRecorder *r = (OhRecorder *)calloc(1, sizeof(*r));
+    if (!r)
+        return NULL;
+    r->f.p = *p;
+    int nplanes = p->chroma_format_idc ? 3 : 1;
+    for (int c = 0; c < nplanes; c++) {
+        int pw = p->width >> oh_hshift(p, c), ph = p->height >> oh_vshift(p, c);
+        r->lw[c] = (pw + 3) >> 2;
+        r->lh[c] = (ph + 3) >> 2;
+        r->lvl[c] = (uint16_t *)calloc((size_t)r->lw[c] * r->lh[c], sizeof(uint16_t));
+    }
+    r->dw = (p->width + 3) >> 2;
+    r->dh = (p->height + 3) >> 2;
+    r->decoded = (uint8_t *)calloc((size_t)r->dw * r->dh, 1);
+    r->f.bs_size = oh_bs_size(p);
+    r->vbs = (uint8_t *)calloc(r->f.bs_size, 1);
+    r->hbs = (uint8_t *)calloc(r->f.bs_size, 1);
+    r->qp = (int8_t *)calloc(oh_qp_tab_size(p), 1);
+    r->is_pcm = (uint8_t *)calloc((size_t)oh_min_pu_width(p) * oh_min_pu_height(p) + 1, 1);
+    r->deblock = (OhDeblockCtb *)calloc((size_t)oh_ctb_width(p) * oh_ctb_height(p), sizeof(OhDeblockCtb));
+    r->sao = (OhSaoCtb *)calloc((size_t)oh_ctb_width(p) * oh_ctb_height(p), sizeof(OhSaoCtb));
+    return r;
+}
+
+const OhPicParams *oh_rec_params(const OhRecorder *r) { return &r->f.p; }
+
+void oh_rec_destroy(OhRecorder *r)
+{
+    if (!r)
+        return;
+    free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->intra_level);
+    free(r->sorted); free(r->level_start);
+    free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->qp); free(r->deblock); free(r->sao);
+    for (int c = 0; c < 3; c++)
+        free(r->lvl[c]);
+    free(r->decoded);
+    free(r);
+}
+
+void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref_pics)
+{
+    const OhPicParams *p = &r->f.p;
+    r->f.cur_pic = cur_pic;
+    for (int i = 0; i < OH_MAX_REFS; i++)
+        r->f.ref_pics[i] = i < n_ref_pics ? ref_pics[i] : -1;
+    r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = 0;
+    r->f.n_coeff = 0;
+    r->max_level = 0;
+    memset(r->vbs, 0, r->f.bs_size);
+    memset(r->hbs, 0, r->f.bs_size);
+    memset(r->is_pcm, 0, (size_t)oh_min_pu_width(p) * oh_min_pu_height(p));
+    memset(r->sao, 0, (size_t)oh_ctb_width(p) * oh_ctb_height(p) * sizeof(OhSaoCtb));
+    memset(r->deblock, 0, (size_t)oh_ctb_width(p) * oh_ctb_height(p) * sizeof(OhDeblockCtb));
+    for (int c = 0; c < 3; c++)
+        if (r->lvl[c])
+            memset(r->lvl[c], 0, (size_t)r->lw[c] * r->lh[c] * sizeof(uint16_t));
+    memset(r->decoded, 0, (size_t)r->dw * r->dh);
+}
+
+int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,
+              int ref1, int mv1x, int mv1y, const OhWeights *wp)
+{
+    const OhPicParams *p = &r->f.p;
+    if (x < 0 || y < 0 || w < 4 || h < 4 || w > 64 || h > 64 || x + w > p->width || y + h > p->height)
+        return -1;
+    if (ref0 < 0 && ref1 < 0)
+        return -1;
+    GROW32(r->pu, r->cap_pu, (uint64_t)r->f.n_pu + 1);
+    OhPu *it = &r->pu[r->f.n_pu++];
+    memset(it, 0, sizeof(*it));
+    it->x = (uint16_t)x; it->y = (uint16_t)y; it->w = (uint8_t)w; it->h = (uint8_t)h;
+    it->ref[0] = ref0 < 0 ? OH_NO_REF : (uint8_t)ref0;
+    it->ref[1] = ref1 < 0 ? OH_NO_REF : (uint8_t)ref1;
+    it->mv[0][0] = (int16_t)mv0x; it->mv[0][1] = (int16_t)mv0y;
+    it->mv[1][0] = (int16_t)mv1x; it->mv[1][1] = (int16_t)mv1y;
+    it->wp = OH_NO_WP;
+    if (wp) {
+        GROW32(r->wp, r->cap_wp, (uint64_t)r->f.n_wp + 1);
+        r->wp[r->f.n_wp] = *wp;
+        it->wp = (uint16_t)r->f.n_wp++;
+    }
+    return 0;
+}
+
+uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+                   const int16_t *coeffs)
+{
+    uint32_t n2 = 1u << (2 * log2_size);
+    GROW32(r->tu, r->cap_tu, (uint64_t)r->f.n_tu + 1);
+    r->coeffs = (int16_t *)grow(r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
+    OhTu *it = &r->tu[r->f.n_tu];
+    it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
+    it->kind = (uint8_t)kind; it->flags = (uint8_t)flags;
+    it->coeff_off = (uint32_t)r->f.n_coeff;
+    memcpy(r->coeffs + r->f.n_coeff, coeffs, n2 * sizeof(int16_t));
+    r->f.n_coeff += n2;
+    return r->f.n_tu++;
+}
+
+static inline unsigned lvl_at(const OhRecorder *r, int c, int x, int y)
+{
+    return r->lvl[c][(y >> 2) * r->lw[c] + (x >> 2)];
+}
+
+int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
+{
+    const OhPicParams *p = &r->f.p;
+    int n = 1 << log2_size;
+    int pw = p->width >> oh_hshift(p, c_idx), ph = p->height >> oh_vshift(p, c_idx);
+    unsigned lv = 0, t;
+    if (x < 0 || y < 0 || x + n > pw || y + n > ph)
+        return -1;
+    /* the samples intra_pred() gathers (hevcpred_template.c:164-183): one column to the left over
+     * 2N rows, one row above over 2N columns, and the corner — each only where available */
+    if (avail & OH_AV_UP_LEFT) { t = lvl_at(r, c_idx, x - 1, y - 1); if (t > lv) lv = t; }
+    if (avail & OH_AV_UP)
+        for (int i = 0; i < n; i += 4) { t = lvl_at(r, c_idx, x + i, y - 1); if (t > lv) lv = t; }
+    if (avail & OH_AV_UP_RIGHT)
+        for (int i = n; i < 2 * n && x + i < pw; i += 4) { t = lvl_at(r, c_idx, x + i, y - 1); if (t > lv) lv = t; }
+    if (avail & OH_AV_LEFT)
+        for (int i = 0; i < n; i += 4) { t = lvl_at(r, c_idx, x - 1, y + i); if (t > lv) lv = t; }
+    if (avail & OH_AV_BOTTOM_LEFT)
+        for (int i = n; i < 2 * n && y + i < ph; i += 4) { t = lvl_at(r, c_idx, x - 1, y + i); if (t > lv) lv = t; }
+    lv += 1;
+    for (int yy = y; yy < y + n; yy += 4)
+        for (int xx = x; xx < x + n; xx += 4)
+            r->lvl[c_idx][(yy >> 2) * r->lw[c_idx] + (xx >> 2)] = (uint16_t)lv;
+    if (lv > r->max_level)
+        r->max_level = lv;
+
+    uint32_t cap = r->cap_intra;
+    GROW32(r->intra, r->cap_intra, (uint64_t)r->f.n_intra + 1);
+    if (r->cap_intra != cap)
+        r->intra_level = (uint32_t *)realloc(r->intra_level, sizeof(uint32_t) * r->cap_intra);
+    OhIntra *it = &r->intra[r->f.n_intra];
+    it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
+    it->mode = (uint8_t)mode; it->avail = (uint8_t)avail; it->tu = tu;
+    r->intra_level[r->f.n_intra++] = lv;
+    return 0;
+}
+
+uint8_t      *oh_rec_vertical_bs(OhRecorder *r)   { return r->vbs; }
+uint8_t      *oh_rec_horizontal_bs(OhRecorder *r) { return r->hbs; }
+int8_t       *oh_rec_qp_y_tab(OhRecorder *r)      { return r->qp; }
+uint8_t      *oh_rec_is_pcm(OhRecorder *r)        { return r->is_pcm; }
+OhDeblockCtb *oh_rec_deblock(OhRecorder *r)       { return r->deblock; }
+OhSaoCtb     *oh_rec_sao(OhRecorder *r)           { return r->sao; }
+
+const OhFrame *oh_rec_finish(OhRecorder *r)
+{
+    OhFrame *f = &r->f;
+    uint32_t nl = r->max_level;                        /* levels are 1..max_level */
+    GROW32(r->sorted, r->cap_sorted, (uint64_t)f->n_intra + 1);
+    GROW32(r->level_start, r->cap_levels, (uint64_t)nl + 2);
+    memset(r->level_start, 0, sizeof(uint32_t) * (nl + 2));
+    for (uint32_t i = 0; i < f->n_intra; i++)          /* counting sort, stable */
+        r->level_start[r->intra_level[i]]++;           /* slot l holds count of level l (1-based) */
+    uint32_t acc = 0;
+    for (uint32_t l = 1; l <= nl; l++) {
+        uint32_t cnt = r->level_start[l];
+        r->level_start[l - 1] = acc;                   /* start of 0-based level l-1 */
+        acc += cnt;
+    }
+    r->level_start[nl] = acc;
+    uint32_t *cursor = (uint32_t *)malloc(sizeof(uint32_t) * (nl + 1));
+    memcpy(cursor, r->level_start, sizeof(uint32_t) * (nl + 1));
+    for (uint32_t i = 0; i < f->n_intra; i++)
+        r->sorted[cursor[r->intra_level[i] - 1]++] = r->intra[i];
+    free(cursor);
+
+    f->pu = r->pu; f->wp = r->wp; f->tu = r->tu; f->coeffs = r->coeffs;
+    f->intra = r->sorted; f->n_levels = nl; f->level_start = r->level_start;
+    f->vertical_bs = r->vbs; f->horizontal_bs = r->hbs; f->qp_y_tab = r->qp;
+    f->is_pcm = (f->p.pcm_loop_filter_disable || f->p.transquant_bypass_enable) ? r->is_pcm : NULL;
+    f->deblock = r->deblock;
+    f->sao = f->p.sao_enabled ? r->sao : NULL;
+    return f;
+}
+
+/* ---- availability from the recorder's own decoded map ---- */
+static int dec_at(const OhRecorder *r, int x, int y)
+{
+    if (x < 0 || y < 0 || x >= r->f.p.width || y >= r->f.p.height)
+        return 0;
+    return r->decoded[(y >> 2) * r->dw + (x >> 2)];
+}
+
+int oh_rec_avail(const OhRecorder *r, int x, int y, int w, int h)
+{
+    int a = 0;
+    if (dec_at(r, x - 1, y + h)) a |= OH_AV_BOTTOM_LEFT;
+    if (dec_at(r, x - 1, y))     a |= OH_AV_LEFT;
+    if (dec_at(r, x - 1, y - 1)) a |= OH_AV_UP_LEFT;
+    if (dec_at(r, x, y - 1))     a |= OH_AV_UP;
+    if (dec_at(r, x + w, y - 1)) a |= OH_AV_UP_RIGHT;
+    return a;
+}
+
+void oh_rec_mark_decoded(OhRecorder *r, int x, int y, int w, int h)
+{
+    for (int yy = y; yy < y + h && yy < r->f.p.height; yy += 4)
+        for (int xx = x; xx < x + w && xx < r->f.p.width; xx += 4)
+            r->decoded[(yy >> 2) * r->dw + (xx >> 2)] = 1;
+}

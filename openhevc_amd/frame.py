@@ -1,0 +1,219 @@
+"""ctypes mirror of include/ohevc_frame.h / ohevc_recorder.h / ohevc_synth.h and the loader of
+libohevc_host.so (recorder + synthetic-stream generator; plain C, no GPU needed)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+
+OH_MAX_REFS = 16
+OH_NO_REF = 0xFF
+OH_NO_WP = 0xFFFF
+OH_NO_COEFF = 0xFFFFFFFF
+
+TU_IDCT, TU_DST4, TU_SKIP, TU_BYPASS, TU_PCM = range(5)
+TUF_ADD_NOW, TUF_RDPCM, TUF_RDPCM_VER, TUF_ROTATE = 1, 2, 4, 8
+AV_BOTTOM_LEFT, AV_LEFT, AV_UP_LEFT, AV_UP, AV_UP_RIGHT = 1, 2, 4, 8, 16
+
+
+class OhPicParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "bit_depth", "chroma_format_idc", "log2_ctb_size", "log2_min_cb_size",
+        "log2_min_tb_size", "log2_min_pu_size", "pcm_loop_filter_disable", "transquant_bypass_enable",
+        "strong_intra_smoothing", "intra_smoothing_disabled", "cb_qp_offset", "cr_qp_offset",
+        "sao_enabled", "deblock_enabled")] + [("reserved", C.c_int32 * 4)]
+
+
+class OhPu(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("w", C.c_uint8), ("h", C.c_uint8),
+                ("ref", C.c_uint8 * 2), ("mv", (C.c_int16 * 2) * 2), ("wp", C.c_uint16), ("reserved", C.c_uint16)]
+
+
+class OhWeights(C.Structure):
+    _fields_ = [("w", (C.c_int16 * 3) * 2), ("o", (C.c_int16 * 3) * 2), ("log2_denom", C.c_uint8 * 2),
+                ("reserved", C.c_uint8 * 2)]
+
+
+class OhTu(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("c_idx", C.c_uint8), ("log2_size", C.c_uint8),
+                ("kind", C.c_uint8), ("flags", C.c_uint8), ("coeff_off", C.c_uint32)]
+
+
+class OhIntra(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("c_idx", C.c_uint8), ("log2_size", C.c_uint8),
+                ("mode", C.c_uint8), ("avail", C.c_uint8), ("tu", C.c_uint32)]
+
+
+class OhDeblockCtb(C.Structure):
+    _fields_ = [("beta_offset", C.c_int8), ("tc_offset", C.c_int8)]
+
+
+class OhSaoCtb(C.Structure):
+    _fields_ = [("offset_val", (C.c_int16 * 5) * 3), ("band_position", C.c_uint8 * 3), ("eo_class", C.c_uint8 * 3),
+                ("type_idx", C.c_uint8 * 3), ("edge_flags", C.c_uint8)]
+
+
+class OhFrame(C.Structure):
+    _fields_ = [
+        ("p", OhPicParams), ("cur_pic", C.c_int32), ("ref_pics", C.c_int32 * OH_MAX_REFS),
+        ("n_pu", C.c_uint32), ("pu", C.POINTER(OhPu)),
+        ("n_wp", C.c_uint32), ("wp", C.POINTER(OhWeights)),
+        ("n_tu", C.c_uint32), ("tu", C.POINTER(OhTu)),
+        ("n_coeff", C.c_uint64), ("coeffs", C.POINTER(C.c_int16)),
+        ("n_intra", C.c_uint32), ("intra", C.POINTER(OhIntra)),
+        ("n_levels", C.c_uint32), ("level_start", C.POINTER(C.c_uint32)),
+        ("bs_size", C.c_uint32), ("vertical_bs", C.POINTER(C.c_uint8)), ("horizontal_bs", C.POINTER(C.c_uint8)),
+        ("qp_y_tab", C.POINTER(C.c_int8)), ("is_pcm", C.POINTER(C.c_uint8)),
+        ("deblock", C.POINTER(OhDeblockCtb)), ("sao", C.POINTER(OhSaoCtb)),
+    ]
+
+
+class OhSynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in (
+        "slice_type", "n_refs", "intra_pct", "skip_pct", "bi_pct", "frac_mv_pct", "mv_range", "cbf_pct",
+        "weighted_pct", "split_pct", "qp_base", "qp_var", "sao_pct", "tskip_pct", "pcm_pct", "bypass_pct",
+        "vary_deblock_offsets")] + [("reserved", C.c_int32 * 8)]
+
+
+assert C.sizeof(OhPu) == 20 and C.sizeof(OhWeights) == 28 and C.sizeof(OhTu) == 12
+assert C.sizeof(OhIntra) == 12 and C.sizeof(OhSaoCtb) == 40 and C.sizeof(OhDeblockCtb) == 2
+
+
+def pic_params(width, height, bit_depth=8, chroma_format_idc=1, log2_ctb_size=6, log2_min_cb_size=3,
+               log2_min_tb_size=2, sao=1, deblock=1, strong_intra_smoothing=1, pcm_loop_filter_disable=0,
+               transquant_bypass_enable=0, cb_qp_offset=0, cr_qp_offset=0, intra_smoothing_disabled=0):
+    p = OhPicParams()
+    p.width, p.height, p.bit_depth, p.chroma_format_idc = width, height, bit_depth, chroma_format_idc
+    p.log2_ctb_size, p.log2_min_cb_size, p.log2_min_tb_size = log2_ctb_size, log2_min_cb_size, log2_min_tb_size
+    p.log2_min_pu_size = log2_min_cb_size - 1
+    p.sao_enabled, p.deblock_enabled, p.strong_intra_smoothing = sao, deblock, strong_intra_smoothing
+    p.pcm_loop_filter_disable, p.transquant_bypass_enable = pcm_loop_filter_disable, transquant_bypass_enable
+    p.cb_qp_offset, p.cr_qp_offset, p.intra_smoothing_disabled = cb_qp_offset, cr_qp_offset, intra_smoothing_disabled
+    assert width % (1 << log2_min_cb_size) == 0 and height % (1 << log2_min_cb_size) == 0
+    return p
+
+
+def hshift(p, c):
+    return int(bool(c) and p.chroma_format_idc in (1, 2))
+
+
+def vshift(p, c):
+    return int(bool(c) and p.chroma_format_idc == 1)
+
+
+def plane_dims(p, c):
+    return p.width >> hshift(p, c), p.height >> vshift(p, c)
+
+
+def n_planes(p):
+    return 3 if p.chroma_format_idc else 1
+
+
+_host = None
+
+
+def build_host():
+    subprocess.check_call(["make", "-s", "-C", PKG_DIR, "libohevc_host.so"])
+
+
+def host():
+    """libohevc_host.so: recorder + synth (host-only C)."""
+    global _host
+    if _host is None:
+        path = os.path.join(PKG_DIR, "libohevc_host.so")
+        if not os.path.exists(path):
+            build_host()
+        lib = C.CDLL(path)
+        V, I = C.c_void_p, C.c_int
+        lib.oh_rec_create.restype = V
+        lib.oh_rec_create.argtypes = [C.POINTER(OhPicParams)]
+        lib.oh_rec_destroy.argtypes = [V]
+        lib.oh_rec_begin.argtypes = [V, I, C.POINTER(C.c_int32), I]
+        lib.oh_rec_pu.argtypes = [V] + [I] * 10 + [C.POINTER(OhWeights)]
+        lib.oh_rec_tu.argtypes = [V, I, I, I, I, I, I, C.POINTER(C.c_int16)]
+        lib.oh_rec_tu.restype = C.c_uint32
+        lib.oh_rec_intra.argtypes = [V, I, I, I, I, I, I, C.c_uint32]
+        lib.oh_rec_finish.argtypes = [V]
+        lib.oh_rec_finish.restype = C.POINTER(OhFrame)
+        lib.oh_rec_avail.argtypes = [V, I, I, I, I]
+        lib.oh_rec_mark_decoded.argtypes = [V, I, I, I, I]
+        for n, t in (("oh_rec_vertical_bs", C.c_uint8), ("oh_rec_horizontal_bs", C.c_uint8), ("oh_rec_qp_y_tab", C.c_int8),
+                     ("oh_rec_is_pcm", C.c_uint8), ("oh_rec_deblock", OhDeblockCtb), ("oh_rec_sao", OhSaoCtb)):
+            getattr(lib, n).argtypes = [V]
+            getattr(lib, n).restype = C.POINTER(t)
+        lib.oh_synth_defaults.argtypes = [C.POINTER(OhSynthParams), I, C.c_uint64]
+        lib.oh_synth_picture.argtypes = [V, C.POINTER(OhSynthParams), I, C.POINTER(C.c_int32), I]
+        lib.oh_synth_picture.restype = C.POINTER(OhFrame)
+        _host = lib
+    return _host
+
+
+class Recorder:
+    """Owns one OhRecorder; `frame` is the last finished OhFrame (valid until the next begin)."""
+
+    def __init__(self, params):
+        self.lib = host()
+        self.params = params
+        self.h = self.lib.oh_rec_create(C.byref(params))
+        self.frame = None
+
+    def close(self):
+        if self.h:
+            self.lib.oh_rec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def synth(self, sp, cur_pic, ref_pics=()):
+        refs = (C.c_int32 * OH_MAX_REFS)(*([int(r) for r in ref_pics] + [-1] * (OH_MAX_REFS - len(ref_pics))))
+        f = self.lib.oh_synth_picture(self.h, C.byref(sp), int(cur_pic), refs, len(ref_pics))
+        if not f:
+            raise RuntimeError("oh_synth_picture failed")
+        self.frame = f.contents
+        return self.frame
+
+
+def synth_params(slice_type, seed, **kw):
+    sp = OhSynthParams()
+    host().oh_synth_defaults(C.byref(sp), slice_type, seed)
+    for k, v in kw.items():
+        if not hasattr(sp, k):
+            raise AttributeError(k)
+        setattr(sp, k, v)
+    return sp
+
+
+# ---- host pictures (numpy planes) ----
+class HostPic:
+    """planes as numpy arrays with a row stride >= width (stride in samples is plane.shape[1])"""
+
+    def __init__(self, params, fill=None, rng=None, pad=0):
+        self.params = params
+        self.bd = params.bit_depth
+        dt = np.uint8 if self.bd == 8 else np.uint16
+        self.planes = []
+        for c in range(n_planes(params)):
+            w, h = plane_dims(params, c)
+            st = (w + pad + 63) // 64 * 64
+            if rng is not None:
+                a = rng.integers(0, 1 << self.bd, size=(h, st)).astype(dt)
+            else:
+                a = np.full((h, st), (1 << (self.bd - 1)) if fill is None else fill, dt)
+            self.planes.append(a)
+
+    def copy(self):
+        o = HostPic.__new__(HostPic)
+        o.params, o.bd = self.params, self.bd
+        o.planes = [p.copy() for p in self.planes]
+        return o
+
+    def visible(self, c):
+        w, h = plane_dims(self.params, c)
+        return self.planes[c][:h, :w]
+
+    def equal(self, other):
+        return all(np.array_equal(self.visible(c), other.visible(c)) for c in range(len(self.planes)))

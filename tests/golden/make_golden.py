@@ -1,0 +1,142 @@
+"""Generates tests/golden/*.npz from the reference's OWN kernels (oracle/_ref, built from
+/root/reference by oracle/Makefile).  Run in the container that has the reference tree:
+
+    python tests/golden/make_golden.py
+
+The fixtures are DATA (seeded inputs + the reference's outputs); tests/test_golden.py pins the
+oracle against them wherever the reference tree is absent (e.g. the GPU box).
+"""
+import ctypes as C
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from openhevc_amd import frame as F  # noqa: E402
+from oracle_lib import (host_pic_array, i16p, intp, off_u8p, oracle, plane_ptrs, rand_pixels, ref, u8p)  # noqa: E402
+
+
+def slot_vectors(bd):
+    rng = np.random.default_rng(7000 + bd)
+    r = ref()
+    bpp = 1 if bd == 8 else 2
+    out = {}
+    # residual
+    for log2 in (2, 3, 4, 5):
+        n = 1 << log2
+        cin = np.stack([np.clip(rng.laplace(0, 900, (n, n)) * (rng.random((n, n)) < 0.2), -32768, 32767).astype(np.int16)
+                        for _ in range(6)] + [rng.integers(-32768, 32768, (n, n)).astype(np.int16)])
+        cout = cin.copy()
+        for k in range(len(cout)):
+            r.ref_idct(bd, log2, i16p(cout[k]), n)
+        out[f"idct{log2}_in"], out[f"idct{log2}_out"] = cin, cout
+    cin = rng.integers(-20000, 20000, (8, 4, 4)).astype(np.int16)
+    cout = cin.copy()
+    for k in range(8):
+        r.ref_idct_4x4_luma(bd, i16p(cout[k]))
+    out["dst4_in"], out["dst4_out"] = cin, cout
+    # interpolation: (taps, variant) on one 16x12 block per fractional position
+    for epel in (0, 1):
+        nfrac = 8 if epel else 4
+        src = rand_pixels(rng, (12 + 16, 16 + 16), bd, extreme=True)
+        src2 = rng.integers(-(1 << 13), 1 << 14, size=(12, 64)).astype(np.int16)
+        res = []
+        params = []
+        for fx in range(nfrac):
+            for fy in range(nfrac):
+                denom, wx0, wx1, ox0, ox1 = (int(v) for v in (rng.integers(0, 8), *rng.integers(-100, 128, 2), *rng.integers(-60, 60, 2)))
+                for variant in (0, 1, 2, 3, 4):
+                    if variant == 0:
+                        dst = np.zeros((12, 64), np.int16)
+                        r.ref_mc(bd, epel, 0, C.cast(i16p(dst), C.POINTER(C.c_uint8)), 64, off_u8p(src, 8 * src.strides[0] + 8 * bpp),
+                                 src.strides[0], None, 0, 12, 0, 0, 0, 0, 0, fx, fy, 16)
+                        res.append(dst[:, :16].astype(np.int32))
+                    else:
+                        dst = np.zeros((12, 16), src.dtype)
+                        r.ref_mc(bd, epel, variant, u8p(dst), dst.strides[0], off_u8p(src, 8 * src.strides[0] + 8 * bpp),
+                                 src.strides[0], i16p(src2), 64, 12, denom, wx0, wx1, ox0, ox1, fx, fy, 16)
+                        res.append(dst.astype(np.int32))
+                    params.append((fx, fy, variant, denom, wx0, wx1, ox0, ox1))
+        t = "epel" if epel else "qpel"
+        out[f"{t}_src"], out[f"{t}_src2"] = src, src2
+        out[f"{t}_params"], out[f"{t}_out"] = np.array(params, np.int32), np.stack(res)
+    # intra angular / planar / dc from prepared edges
+    for log2 in (2, 3, 4, 5):
+        n = 1 << log2
+        top = rand_pixels(rng, (2 * n + 8,), bd)
+        left = rand_pixels(rng, (2 * n + 8,), bd)
+        left[3] = top[3]
+        res = []
+        for c_idx in (0, 1):
+            for mode in range(35):
+                dst = np.zeros((n, n), top.dtype)
+                tp, lp = off_u8p(top, 4 * bpp), off_u8p(left, 4 * bpp)
+                if mode == 0:
+                    r.ref_pred_planar(bd, log2, u8p(dst), tp, lp, n)
+                elif mode == 1:
+                    r.ref_pred_dc(bd, log2, u8p(dst), tp, lp, n, c_idx)
+                else:
+                    r.ref_pred_angular(bd, log2, u8p(dst), tp, lp, n, c_idx, mode)
+                res.append(dst)
+        out[f"pred{log2}_top"], out[f"pred{log2}_left"], out[f"pred{log2}_out"] = top, left, np.stack(res)
+    return out
+
+
+def md5_planes(hp):
+    return [hashlib.md5(np.ascontiguousarray(hp.visible(c)).tobytes()).hexdigest() for c in range(len(hp.planes))]
+
+
+PICTURE_CASES = [
+    # name, w, h, bd, chroma, log2_ctb, slice_type, seed, extra synth knobs
+    ("i_8b_420", 416, 240, 8, 1, 6, 0, 11, {}),
+    ("b_8b_420", 416, 240, 8, 1, 6, 2, 12, {"weighted_pct": 20}),
+    ("p_10b_420", 416, 240, 10, 1, 5, 1, 13, {"tskip_pct": 10}),
+    ("b_10b_444", 200, 136, 10, 3, 4, 2, 14, {}),
+    ("b_8b_pcm", 264, 200, 8, 1, 6, 2, 15, {"pcm_pct": 10, "bypass_pct": 10, "vary_deblock_offsets": 1}),
+]
+
+
+def picture_case(name, w, h, bd, chroma, lc, st, seed, knobs):
+    """Reference pictures: seeded noise-on-smooth content.  The reconstruction passes 1-3 of the
+    expected picture come from the oracle (their slots are pinned one by one against the
+    reference above and in test_oracle_vs_ref.py); the in-loop filters then run through the
+    reference's own ff_hevc_hls_filters driver, so the stored MD5s are reference output."""
+    pcm = "pcm" in name
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
+                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm))
+    rec = F.Recorder(p)
+    f = rec.synth(F.synth_params(st, seed, **knobs), 2, [0, 1])
+    rng = np.random.default_rng(seed)
+    pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p)}
+    arr = host_pic_array(pics)
+    o = oracle()
+    co = np.ctypeslib.as_array(f.coeffs, shape=(int(f.n_coeff),)).copy()
+    assert o.oh_or_pass_inter(C.byref(f), arr) == 0
+    assert o.oh_or_pass_residual(C.byref(f), arr, i16p(co)) == 0
+    assert o.oh_or_pass_intra(C.byref(f), arr, i16p(co)) == 0
+    recon = md5_planes(pics[2])
+    scratch = pics[2].copy()
+    d, s = plane_ptrs(pics[2])
+    d2, _ = plane_ptrs(scratch)
+    assert ref().ref_filter_picture(C.byref(f), d, s, d2) == 0
+    return {"recon": recon, "final": md5_planes(pics[2]),
+            "counts": [int(f.n_pu), int(f.n_tu), int(f.n_intra), int(f.n_levels), int(f.n_coeff)]}
+
+
+def main():
+    for bd in (8, 10):
+        np.savez_compressed(os.path.join(HERE, f"slots_{bd}bit.npz"), **slot_vectors(bd))
+    import json
+    pics = {c[0]: picture_case(*c) for c in PICTURE_CASES}
+    with open(os.path.join(HERE, "pictures.json"), "w") as fh:
+        json.dump({"cases": [list(c[:8]) + [c[8]] for c in PICTURE_CASES], "expected": pics}, fh, indent=1)
+    print("wrote", os.listdir(HERE))
+
+
+if __name__ == "__main__":
+    main()

@@ -141,3 +141,38 @@ def rand_pixels(rng, shape, bd, extreme=False):
         m = rng.integers(0, 4, size=shape)
         a = np.where(m == 0, 0, np.where(m == 1, mx, a))
     return a.astype(pix_dtype(bd))
+
+
+# ---- picture-level helpers -------------------------------------------------------------------
+class OhHostPicC(C.Structure):
+    _fields_ = [("data", C.c_void_p * 3), ("stride", C.c_ssize_t * 3), ("width", C.c_int32 * 3),
+                ("height", C.c_int32 * 3), ("bit_depth", C.c_int32)]
+
+
+def host_pic_array(pics):
+    """pics: dict picture-id -> openhevc_amd.frame.HostPic.  Returns (ctypes array indexed by id, keepalive)."""
+    from openhevc_amd import frame as F
+    n = max(pics) + 1
+    arr = (OhHostPicC * n)()
+    for pid, hp in pics.items():
+        for c, pl in enumerate(hp.planes):
+            w, h = F.plane_dims(hp.params, c)
+            arr[pid].data[c] = pl.ctypes.data
+            arr[pid].stride[c] = pl.strides[0]
+            arr[pid].width[c], arr[pid].height[c] = w, h
+        arr[pid].bit_depth = hp.bd
+    return arr
+
+
+def oracle_frame(frame, pics):
+    """run the whole oracle pipeline for one work list; pics[frame.cur_pic] is overwritten"""
+    arr = host_pic_array(pics)
+    rc = oracle().oh_or_frame(C.byref(frame), arr)
+    assert rc == 0
+    return pics[frame.cur_pic]
+
+
+def plane_ptrs(hp):
+    d = (C.c_void_p * 3)(*[pl.ctypes.data for pl in hp.planes] + [None] * (3 - len(hp.planes)))
+    s = (C.c_ssize_t * 3)(*[pl.strides[0] for pl in hp.planes] + [0] * (3 - len(hp.planes)))
+    return d, s

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — decoded Mpixels/s of the MI355X block-reconstruction engine on a synthetic stream.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One STEP is one wave-scheduled group of pictures per GPU (openhevc_amd/parallel.py): 1 I picture,
+3 reference B pictures and 12 non-reference B pictures of the workload's geometry, work lists
+already resident in HBM (uploaded before the timed region; the PCIe-inclusive rate is a separate
+figure in DESIGN.md).  With N GPUs every rank decodes its own 16 pictures per step and the four
+reference pictures of every rank are replicated with one RCCL all-gather per wave (weak scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "1080p_main8": dict(width=1920, height=1080, bit_depth=8, chroma_format_idc=1),
+    # configs[2] / configs[3] geometry (single GPU fits; used for profiling sweeps)
+    "2160p_main8": dict(width=3840, height=2160, bit_depth=8, chroma_format_idc=1),
+    "2160p_main10": dict(width=3840, height=2160, bit_depth=10, chroma_format_idc=1),
+    "480p_main8": dict(width=832, height=480, bit_depth=8, chroma_format_idc=1),
+}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+# kernel that implements each pass (name as rocprofv3 reports it, without template arguments)
+PASS_KERNEL = dict(inter="mc_kernel", residual="residual_kernel", intra="intra_ctu_kernel", deblock_v="deblock_luma_kernel<0>+deblock_chroma_kernel<0>",
+                   deblock_h="deblock_luma_kernel<1>+deblock_chroma_kernel<1>", sao="sao_kernel")
+
+
+def cpu_baseline(params, plan_kwargs, budget_s=12.0):
+    """the CPU checker (oracle/, kind "port") on this host, one thread, on the SAME step plan"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from openhevc_amd import parallel as P
+    from oracle_backend import OracleBackend
+    plan = P.make_step_plan(1, 0, **plan_kwargs)
+    be = OracleBackend(params, plan)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        P.run_step(plan, be, None)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or steps >= 50:
+            break
+    pics = steps * P.pictures_per_step(plan)
+    return dict(value=round(pics * params.width * params.height / dt / 1e6, 2), unit="Mpixels/s", cores=1, kind="port",
+                sample=f"{steps} step(s) = {pics} pictures of the same synthetic stream in {dt:.1f} s, single thread, gcc -O2 oracle/oracle.c")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="1080p_main8", choices=sorted(WORKLOADS))
+    ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
+    ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from openhevc_amd import frame as F
+    from openhevc_amd import parallel as P
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the engine has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    params = F.pic_params(**WORKLOADS[args.workload])
+    plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643)
+    plan = P.make_step_plan(world, rank, **plan_kwargs)
+    be = P.EngineBackend(torch, local_rank, params, plan)
+    pics_per_step = P.pictures_per_step(plan)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        P.run_step(plan, be, dist if world > 1 else None)
+    be.engine.pass_times(reset=True)
+    be.engine.profile(not args.no_profile)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        P.run_step(plan, be, dist if world > 1 else None)
+    barrier()
+    dt = time.perf_counter() - t0
+    be.engine.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    luma_px = params.width * params.height
+    total_pics = world * pics_per_step * args.steps
+    value = total_pics * luma_px / dt / 1e6
+
+    out = None
+    if rank == 0:
+        b = 2 if params.bit_depth > 8 else 1
+        pass_ms, n_exec = be.engine.pass_times()
+        roofline = None
+        if n_exec:
+            # algorithmic bytes of this rank's step, per pass (openhevc_amd/parallel.py)
+            abytes = {k: 0.0 for k in pass_ms}
+            launches = {k: 0 for k in pass_ms}
+            for pic in plan.pictures():
+                st = be.stats[pic.name]
+                for k, v in P.algorithmic_bytes(st, b).items():
+                    abytes[k] += v
+                launches["inter"] += 1 if st["n_pu"] else 0
+                launches["residual"] += 1 if st["n_tu"] else 0
+                launches["intra"] += st["n_levels"]
+                launches["deblock_v"] += 2
+                launches["deblock_h"] += 2
+                launches["sao"] += 1
+            dom = max(pass_ms, key=lambda k: pass_ms[k])
+            steps_timed = n_exec / float(pics_per_step)
+            ms_per_step_pass = pass_ms[dom] / steps_timed
+            n_launch = max(launches[dom], 1)
+            avg_launch_us = ms_per_step_pass * 1e3 / n_launch
+            achieved = (abytes[dom] / n_launch) / (avg_launch_us * 1e-6) / 1e9
+            roofline = dict(bound="hbm", kernel=PASS_KERNEL[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                            launches_per_step=n_launch, avg_launch_us=round(avg_launch_us, 3),
+                            algorithmic_bytes_per_launch=round(abytes[dom] / n_launch, 1),
+                            pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
+                            pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms})
+        knobs = P.default_synth_knobs()
+        out = {
+            "metric": "decoded Mpixels/s (luma), synthetic stream, bit-exact vs reference-pinned oracle",
+            "value": round(value, 2), "unit": "Mpixels/s", "fps": round(total_pics / dt, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if params.bit_depth == 8 else "u16", "data": "synthetic",
+            "config": {"workload": args.workload, "width": params.width, "height": params.height, "bit_depth": params.bit_depth,
+                       "chroma_format_idc": params.chroma_format_idc, "pictures_per_step_per_gpu": pics_per_step,
+                       "step": f"1 I + {args.waves - 1} reference B + {args.tail} non-reference B pictures per GPU, one picture in flight per GPU",
+                       "exchange": "one RCCL all-gather of the finished reference pictures per wave" if world > 1 else "none (1 GPU)",
+                       "generator": dict(knobs, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
+            "roofline": roofline,
+        }
+    be.close()
+    if rank == 0:
+        out["cpu_baseline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, plan_kwargs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,17 @@ typedef struct OhIntra {
                                      prediction), OH_NO_COEFF when cbf == 0                        */
 } OhIntra;                        /* 12 bytes */
 
+/* Pass 3 is scheduled as a CTU WAVEFRONT (the GPU form of the reference's WPP rows,
+ * hevc.c:2751-2832): a CTU that contains intra blocks may start once the CTUs whose samples its
+ * blocks read (left, up-left, up, up-right) are done — that is its LEVEL; inside the CTU the
+ * blocks are ordered in SUB-LEVELS (block b's sub-level = 1 + max sub-level of the same-CTU
+ * blocks it reads).  One workgroup reconstructs one CTU, sub-level after sub-level. */
+typedef struct OhIntraCtu {
+    uint32_t sub_first;           /* first entry of this CTU in OhFrame.sub_start                   */
+    uint16_t n_sub;               /* number of sub-levels                                           */
+    uint16_t ctu;                 /* raster index of the CTU                                        */
+} OhIntraCtu;                     /* 8 bytes */
+
 /* ---- pass 4: deblocking side arrays ---- */
 typedef struct OhDeblockCtb { int8_t beta_offset, tc_offset; } OhDeblockCtb;   /* hevc.h:1083 */
 
@@ -131,8 +142,13 @@ typedef struct OhFrame {
     uint32_t n_tu;      const OhTu      *tu;
     uint64_t n_coeff;   const int16_t   *coeffs;
 
-    uint32_t n_intra;   const OhIntra   *intra;       /* sorted by dependency level               */
-    uint32_t n_levels;  const uint32_t  *level_start; /* n_levels+1 offsets into intra[]          */
+    uint32_t n_intra;   const OhIntra    *intra;      /* sorted by (CTU level, CTU, sub-level): any
+                                                         prefix is closed under dependencies      */
+    uint32_t n_ictu;    const OhIntraCtu *ictu;       /* CTUs holding intra blocks, by CTU level  */
+    uint32_t n_sub;     const uint32_t   *sub_start;  /* n_sub+1 offsets into intra[]: the blocks of
+                                                         sub-level s of ictu[k] are
+                                                         [sub_start[k.sub_first+s], sub_start[k.sub_first+s+1]) */
+    uint32_t n_levels;  const uint32_t   *level_start;/* n_levels+1 offsets into ictu[]           */
 
     /* (width>>2) x (height>>2) grids, index (x + y*bs_width)>>2 exactly as hevc_filter.c:388,487;
        bs_size bytes each, bs_size >= the reference's padded allocation (hevc.c:170-171)          */
@@ -164,6 +180,22 @@ static inline uint32_t oh_bs_size(const OhPicParams *p)
 static inline uint32_t oh_qp_tab_size(const OhPicParams *p)
 {
     return (uint32_t)(oh_min_cb_width(p) + 1) * (uint32_t)(oh_min_cb_height(p) + 1);
+}
+
+/* Layout of one picture buffer ("half", see ohevc_hip.h): planes back to back, every row and
+ * every plane padded to 256 bytes.  Returns the half's size in bytes; stride[] in SAMPLES,
+ * offset[] in bytes.  Shared by the engine, the tests and the multi-GPU exchange code. */
+static inline uint64_t oh_pic_half_layout(const OhPicParams *p, int32_t stride[3], uint64_t offset[3])
+{
+    uint64_t bpp = p->bit_depth > 8 ? 2 : 1, total = 0;
+    for (int c = 0; c < (p->chroma_format_idc ? 3 : 1); c++) {
+        uint64_t w = (uint64_t)(p->width >> oh_hshift(p, c)), h = (uint64_t)(p->height >> oh_vshift(p, c));
+        uint64_t row = (w * bpp + 255) / 256 * 256;
+        stride[c] = (int32_t)(row / bpp);
+        offset[c] = total;
+        total += (row * h + 255) / 256 * 256;
+    }
+    return total;
 }
 
 #ifdef __cplusplus

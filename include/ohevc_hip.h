@@ -1,0 +1,101 @@
+/*
+ * ohevc_hip.h — C ABI of the MI355X block-reconstruction engine (libohevc_hip.so).
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.  The engine owns
+ * the decoded pictures in HBM (the DPB lives on the GPU), replays recorded work lists
+ * (ohevc_frame.h) as whole-picture passes and hands pictures back on request:
+ *
+ *   reference side (kept intact)                       engine entry point
+ *   ------------------------------------------------   -----------------------------------------
+ *   set_sps -> ff_hevc_dsp_init/ff_hevc_pred_init       oh_engine_create        hevc.c:421-423
+ *   ff_hevc_set_new_ref -> ff_thread_get_buffer         oh_pic_alloc            hevc_refs.c:75-147
+ *   hls_slice_data end / frame done                     oh_frame_submit         hevc.c:3017-3090
+ *   libOpenHevcDecode before exposing a picture         oh_engine_sync          openHevcWrapper.c:130-153
+ *   libOpenHevcGetOutput(Cpy), calc_md5                 oh_pic_download         openHevcWrapper.c:338-398, hevc.c:4146-4169
+ *   ff_hevc_unref_frame                                 oh_pic_free             hevc_refs.c:45-65
+ *
+ * All functions return 0 on success and a negative OH_E_* code otherwise; the table slots of the
+ * reference cannot fail (void returns), so recording never reports errors —
+ * they surface here, at submit / sync.  There is NO CPU fallback: every entry point fails with
+ * OH_E_HIP when no gfx950 device is usable.
+ */
+#ifndef OHEVC_HIP_H
+#define OHEVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "ohevc_frame.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    OH_OK = 0,
+    OH_E_HIP = -1,        /* HIP runtime error (see oh_engine_last_error) */
+    OH_E_ARG = -2,        /* invalid argument / inconsistent work list    */
+    OH_E_NOMEM = -3,
+    OH_E_UNSUPPORTED = -4 /* feature not built yet (e.g. 4:2:2)           */
+};
+
+enum OhPass {             /* indices into oh_engine_pass_times()          */
+    OH_PASS_INTER = 0, OH_PASS_RESIDUAL, OH_PASS_INTRA, OH_PASS_DEBLOCK_V, OH_PASS_DEBLOCK_H,
+    OH_PASS_SAO, OH_N_PASSES
+};
+
+typedef struct OhEngine   OhEngine;
+typedef struct OhDevFrame OhDevFrame;
+
+int  oh_engine_create(OhEngine **out, int device);
+/* same, but every kernel and copy is enqueued on the caller's stream (hipStream_t passed as
+ * void*; e.g. torch.cuda.current_stream().cuda_stream) so that RCCL collectives issued by the
+ * caller on that stream are ordered with the engine's passes.  The stream is not destroyed. */
+int  oh_engine_create_on_stream(OhEngine **out, int device, void *hip_stream);
+void oh_engine_destroy(OhEngine *e);
+const char *oh_engine_last_error(const OhEngine *e);
+int  oh_engine_sync(OhEngine *e);                       /* wait for everything enqueued so far */
+
+/* pictures (device resident).  ids are small integers, stable until oh_pic_free */
+int oh_pic_alloc(OhEngine *e, const OhPicParams *p, int *pic_id);
+int oh_pic_free(OhEngine *e, int pic_id);
+/* A picture is two buffers of oh_pic_bytes()/2 bytes each: the reconstruction/deblock planes
+ * ("half 0") and the SAO output planes ("half 1"); layout inside a half: oh_pic_half_layout().
+ * oh_pic_wrap builds a picture over caller-owned device memory (two 256-byte aligned buffers, e.g.
+ * rows of a torch uint8 tensor) so that finished reference pictures of several GPUs sit
+ * contiguously and can be handed to one RCCL all-gather without a copy;
+ * oh_pic_final_half tells which half holds the finished picture, oh_pic_set_final_half marks a
+ * half as finished after the caller filled it (broadcast / all-gather receive side). */
+size_t oh_pic_bytes(const OhPicParams *p);
+int oh_pic_wrap(OhEngine *e, const OhPicParams *p, void *half0, void *half1, size_t half_bytes, int *pic_id);
+int oh_pic_final_half(OhEngine *e, int pic_id);                 /* 0, 1 or a negative error */
+int oh_pic_set_final_half(OhEngine *e, int pic_id, int half);
+/* planes: tightly described by byte strides, sample type uint8_t (8 bit) or uint16_t (>8 bit) */
+int oh_pic_upload(OhEngine *e, int pic_id, const uint8_t *const planes[3], const ptrdiff_t strides[3]);
+int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3], const ptrdiff_t strides[3]);
+
+/* work lists.  OhFrame.cur_pic / ref_pics[] hold engine picture ids.
+ * upload copies every array to HBM (after it returns the host arrays may be reused);
+ * execute enqueues passes 1-5 on the engine stream and may be called repeatedly on the same
+ * device frame (the coefficient pool is never modified). */
+int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out);
+int oh_frame_execute(OhEngine *e, OhDevFrame *df);
+int oh_frame_free(OhEngine *e, OhDevFrame *df);
+int oh_frame_submit(OhEngine *e, const OhFrame *f);     /* upload + execute + deferred free */
+
+/* per-pass device time of the executes since the last reset, measured with HIP events on the
+ * engine stream (enable costs two event records per pass).  ms[] and launches[] hold OH_N_PASSES
+ * entries: accumulated milliseconds and number of timed executes. */
+int oh_engine_profile(OhEngine *e, int enable);
+int oh_engine_pass_times(OhEngine *e, double *ms, uint64_t *executes, int reset);
+
+/* the stream everything is enqueued on (hipStream_t as void*), for callers that need to order
+ * their own work (RCCL broadcasts of reference pictures) against the engine */
+void *oh_engine_stream(OhEngine *e);
+/* device address / geometry of a picture's FINAL planes (valid after the frame that writes it was
+ * executed), for zero-copy exchange between GPUs; stride in samples */
+int oh_pic_device_planes(OhEngine *e, int pic_id, void *planes[3], int32_t stride[3], int32_t width[3], int32_t height[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,657 @@
+/*
+ * engine.hip — host side of the MI355X engine: device-resident pictures (the DPB lives in HBM),
+ * work-list upload, pass scheduling on one HIP stream, per-pass event timing.
+ * C ABI in include/ohevc_hip.h.  No CPU fallback exists: without a usable device every entry
+ * point returns OH_E_HIP.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ohevc_hip.h"
+#include "dev_frame.h"
+#include "kernels.h"
+
+namespace {
+
+struct Pic {
+    bool        used = false;
+    OhPicParams p{};
+    void       *base = nullptr;          /* one allocation: planes A (recon/deblock) then B (SAO out) */
+    bool        owned = true;            /* false: caller-owned memory (oh_pic_wrap)                   */
+    void       *a[3] = {}, *b[3] = {};
+    int32_t     stride[3] = {}, w[3] = {}, h[3] = {};
+    bool        final_b = false;         /* which buffer holds the finished picture */
+};
+
+struct EventSet { hipEvent_t ev[OH_N_PASSES + 1]; };
+
+} // namespace
+
+struct OhDevFrame {
+    void      *arena = nullptr;
+    DevFrame  *d = nullptr;
+    OhPicParams p{};
+    uint32_t   n_tiles = 0, n_tu = 0, n_intra = 0;
+    bool       has_sao = false;
+    std::vector<uint32_t> level_start;
+};
+
+struct OhEngine {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    bool        own_stream = true;
+    std::vector<Pic> pics;
+    std::string err;
+    bool        profile = false;
+    std::vector<EventSet> ev_pool, ev_pending;
+    double      pass_ms[OH_N_PASSES] = {};
+    uint64_t    executes = 0;
+    std::vector<OhDevFrame *> deferred;
+};
+
+#define HIPCHK(e, call)                                                                           \
+    do {                                                                                          \
+        hipError_t rc_ = (call);                                                                  \
+        if (rc_ != hipSuccess) {                                                                  \
+            char buf_[512];                                                                       \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #call, hipGetErrorString(rc_), __FILE__, __LINE__); \
+            (e)->err = buf_;                                                                      \
+            return OH_E_HIP;                                                                      \
+        }                                                                                         \
+    } while (0)
+
+#define FAIL(e, code, ...)                                                                        \
+    do {                                                                                          \
+        char buf_[512];                                                                           \
+        snprintf(buf_, sizeof(buf_), __VA_ARGS__);                                                \
+        (e)->err = buf_;                                                                          \
+        return (code);                                                                            \
+    } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_ext)
+{
+    if (!out)
+        return OH_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        fprintf(stderr, "ohevc_hip: no usable HIP device (count=%d, requested %d); there is no CPU fallback\n", n, device);
+        return OH_E_HIP;
+    }
+    OhEngine *e = new OhEngine();
+    e->device = device;
+    bool ok = hipSetDevice(device) == hipSuccess;
+    if (ok && use_ext) {
+        e->stream = ext;
+        e->own_stream = false;
+    } else if (ok) {
+        ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+    }
+    if (!ok || ohk_init() != 0) {
+        fprintf(stderr, "ohevc_hip: device %d initialisation failed\n", device);
+        delete e;
+        return OH_E_HIP;
+    }
+    *out = e;
+    return OH_OK;
+}
+
+extern "C" int oh_engine_create(OhEngine **out, int device) { return engine_create(out, device, nullptr, false); }
+extern "C" int oh_engine_create_on_stream(OhEngine **out, int device, void *hip_stream)
+{
+    return engine_create(out, device, (hipStream_t)hip_stream, true);
+}
+
+extern "C" const char *oh_engine_last_error(const OhEngine *e) { return e ? e->err.c_str() : "no engine"; }
+extern "C" void *oh_engine_stream(OhEngine *e) { return e ? (void *)e->stream : nullptr; }
+
+static void free_dev_frame(OhDevFrame *df)
+{
+    if (!df)
+        return;
+    if (df->arena)
+        (void)hipFree(df->arena);
+    delete df;
+}
+
+extern "C" int oh_engine_sync(OhEngine *e)
+{
+    if (!e)
+        return OH_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (OhDevFrame *df : e->deferred)
+        free_dev_frame(df);
+    e->deferred.clear();
+    return OH_OK;
+}
+
+extern "C" void oh_engine_destroy(OhEngine *e)
+{
+    if (!e)
+        return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (OhDevFrame *df : e->deferred)
+        free_dev_frame(df);
+    for (Pic &p : e->pics)
+        if (p.used && p.base && p.owned)
+            (void)hipFree(p.base);
+    for (auto &s : e->ev_pool)
+        for (auto &ev : s.ev) (void)hipEventDestroy(ev);
+    for (auto &s : e->ev_pending)
+        for (auto &ev : s.ev) (void)hipEventDestroy(ev);
+    if (e->own_stream)
+        (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+/* ---------------- pictures ---------------- */
+static int check_params(OhEngine *e, const OhPicParams *p)
+{
+    if (!p || p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384)
+        FAIL(e, OH_E_ARG, "bad picture size");
+    if (p->bit_depth != 8 && p->bit_depth != 10 && p->bit_depth != 12)
+        FAIL(e, OH_E_UNSUPPORTED, "bit depth %d not supported (8/10/12)", p->bit_depth);
+    if (p->chroma_format_idc != 0 && p->chroma_format_idc != 1 && p->chroma_format_idc != 3)
+        FAIL(e, OH_E_UNSUPPORTED, "chroma_format_idc %d not supported yet (0, 1, 3)", p->chroma_format_idc);
+    if (p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_cb_size < 3 || p->log2_min_cb_size > p->log2_ctb_size ||
+        p->log2_min_tb_size < 2 || p->log2_min_tb_size > 5 || p->log2_min_pu_size != p->log2_min_cb_size - 1)
+        FAIL(e, OH_E_ARG, "bad block size parameters");
+    if (p->width % (1 << p->log2_min_cb_size) || p->height % (1 << p->log2_min_cb_size))
+        FAIL(e, OH_E_ARG, "picture size must be a multiple of the minimum CB size");
+    return OH_OK;
+}
+
+/* layout of one picture allocation: half 0 = planes A, half 1 = planes B */
+static size_t pic_layout(const OhPicParams *p, Pic *pic, size_t off[6])
+{
+    uint64_t o[3] = { 0, 0, 0 };
+    const size_t half = (size_t)oh_pic_half_layout(p, pic->stride, o);
+    for (int c = 0; c < (p->chroma_format_idc ? 3 : 1); c++) {
+        pic->w[c] = p->width >> oh_hshift(p, c);
+        pic->h[c] = p->height >> oh_vshift(p, c);
+        off[c] = (size_t)o[c];
+        off[3 + c] = half + (size_t)o[c];
+    }
+    return 2 * half;
+}
+
+extern "C" size_t oh_pic_bytes(const OhPicParams *p)
+{
+    Pic tmp;
+    size_t off[6];
+    return p ? pic_layout(p, &tmp, off) : 0;
+}
+
+static int pic_install(OhEngine *e, const OhPicParams *p, void *half0, void *half1, bool owned, int *pic_id)
+{
+    Pic pic;
+    size_t off[6];
+    pic.used = true;
+    pic.p = *p;
+    pic.owned = owned;
+    size_t half = pic_layout(p, &pic, off) / 2;
+    pic.base = half0;
+    for (int c = 0; c < (p->chroma_format_idc ? 3 : 1); c++) {
+        pic.a[c] = (char *)half0 + off[c];
+        pic.b[c] = (char *)half1 + (off[3 + c] - half);
+    }
+    size_t id = 0;
+    while (id < e->pics.size() && e->pics[id].used)
+        id++;
+    if (id == e->pics.size())
+        e->pics.push_back(pic);
+    else
+        e->pics[id] = pic;
+    *pic_id = (int)id;
+    return OH_OK;
+}
+
+extern "C" int oh_pic_alloc(OhEngine *e, const OhPicParams *p, int *pic_id)
+{
+    if (!e || !pic_id)
+        return OH_E_ARG;
+    int rc = check_params(e, p);
+    if (rc)
+        return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    void *mem = nullptr;
+    HIPCHK(e, hipMalloc(&mem, oh_pic_bytes(p)));
+    return pic_install(e, p, mem, (char *)mem + oh_pic_bytes(p) / 2, true, pic_id);
+}
+
+extern "C" int oh_pic_wrap(OhEngine *e, const OhPicParams *p, void *half0, void *half1, size_t half_bytes, int *pic_id)
+{
+    if (!e || !pic_id || !half0 || !half1)
+        return OH_E_ARG;
+    int rc = check_params(e, p);
+    if (rc)
+        return rc;
+    if (half_bytes < oh_pic_bytes(p) / 2 || ((uintptr_t)half0 & 255) || ((uintptr_t)half1 & 255))
+        FAIL(e, OH_E_ARG, "oh_pic_wrap: each half needs %zu bytes, 256-byte aligned", oh_pic_bytes(p) / 2);
+    return pic_install(e, p, half0, half1, false, pic_id);
+}
+
+static Pic *get_pic(OhEngine *e, int id)
+{
+    if (id < 0 || (size_t)id >= e->pics.size() || !e->pics[id].used)
+        return nullptr;
+    return &e->pics[id];
+}
+
+extern "C" int oh_pic_free(OhEngine *e, int pic_id)
+{
+    if (!e)
+        return OH_E_ARG;
+    Pic *p = get_pic(e, pic_id);
+    if (!p)
+        FAIL(e, OH_E_ARG, "oh_pic_free: unknown picture %d", pic_id);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (p->owned)
+        HIPCHK(e, hipFree(p->base));
+    *p = Pic();
+    return OH_OK;
+}
+
+extern "C" int oh_pic_final_half(OhEngine *e, int pic_id)
+{
+    if (!e)
+        return OH_E_ARG;
+    Pic *p = get_pic(e, pic_id);
+    return p ? (p->final_b ? 1 : 0) : OH_E_ARG;
+}
+
+extern "C" int oh_pic_set_final_half(OhEngine *e, int pic_id, int half)
+{
+    if (!e)
+        return OH_E_ARG;
+    Pic *p = get_pic(e, pic_id);
+    if (!p || (half != 0 && half != 1))
+        FAIL(e, OH_E_ARG, "oh_pic_set_final_half: bad picture or half");
+    p->final_b = half == 1;
+    return OH_OK;
+}
+
+extern "C" int oh_pic_upload(OhEngine *e, int pic_id, const uint8_t *const planes[3], const ptrdiff_t strides[3])
+{
+    if (!e || !planes || !strides)
+        return OH_E_ARG;
+    Pic *p = get_pic(e, pic_id);
+    if (!p)
+        FAIL(e, OH_E_ARG, "oh_pic_upload: unknown picture %d", pic_id);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t bpp = p->p.bit_depth > 8 ? 2 : 1;
+    for (int c = 0; c < (p->p.chroma_format_idc ? 3 : 1); c++)
+        HIPCHK(e, hipMemcpy2DAsync(p->a[c], (size_t)p->stride[c] * bpp, planes[c], (size_t)strides[c], (size_t)p->w[c] * bpp,
+                                   (size_t)p->h[c], hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    p->final_b = false;
+    return OH_OK;
+}
+
+extern "C" int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3], const ptrdiff_t strides[3])
+{
+    if (!e || !planes || !strides)
+        return OH_E_ARG;
+    Pic *p = get_pic(e, pic_id);
+    if (!p)
+        FAIL(e, OH_E_ARG, "oh_pic_download: unknown picture %d", pic_id);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t bpp = p->p.bit_depth > 8 ? 2 : 1;
+    for (int c = 0; c < (p->p.chroma_format_idc ? 3 : 1); c++)
+        HIPCHK(e, hipMemcpy2DAsync(planes[c], (size_t)strides[c], p->final_b ? p->b[c] : p->a[c], (size_t)p->stride[c] * bpp,
+                                   (size_t)p->w[c] * bpp, (size_t)p->h[c], hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return OH_OK;
+}
+
+extern "C" int oh_pic_device_planes(OhEngine *e, int pic_id, void *planes[3], int32_t stride[3], int32_t width[3], int32_t height[3])
+{
+    if (!e)
+        return OH_E_ARG;
+    Pic *p = get_pic(e, pic_id);
+    if (!p)
+        FAIL(e, OH_E_ARG, "unknown picture %d", pic_id);
+    for (int c = 0; c < 3; c++) {
+        planes[c] = p->final_b ? p->b[c] : p->a[c];
+        stride[c] = p->stride[c]; width[c] = p->w[c]; height[c] = p->h[c];
+    }
+    return OH_OK;
+}
+
+/* ---------------- work lists ---------------- */
+static void fill_planes(DevPlanes *dp, const Pic *p, bool use_b)
+{
+    for (int c = 0; c < 3; c++) {
+        dp->p[c] = use_b ? p->b[c] : p->a[c];
+        dp->stride[c] = p->stride[c];
+        dp->w[c] = p->w[c];
+        dp->h[c] = p->h[c];
+    }
+}
+
+static bool same_geometry(const OhPicParams &a, const OhPicParams &b)
+{
+    return a.width == b.width && a.height == b.height && a.bit_depth == b.bit_depth && a.chroma_format_idc == b.chroma_format_idc;
+}
+
+/* every index a kernel will follow is checked here: a malformed work list must fail on the host,
+ * never fault on the GPU */
+static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<DevTile> &tiles)
+{
+    const OhPicParams &p = f->p;
+    const int nplanes = p.chroma_format_idc ? 3 : 1;
+    bool ref_ok[OH_MAX_REFS];
+    for (int i = 0; i < OH_MAX_REFS; i++) {
+        Pic *r = get_pic(e, f->ref_pics[i]);
+        ref_ok[i] = r && same_geometry(r->p, p) && r != cur;
+    }
+    if (f->n_pu && !f->pu)
+        FAIL(e, OH_E_ARG, "n_pu without pu[]");
+    for (uint32_t i = 0; i < f->n_pu; i++) {
+        const OhPu &pu = f->pu[i];
+        if (pu.w < 4 || pu.h < 4 || pu.w > 64 || pu.h > 64 || (pu.w & 3) || (pu.h & 3) || pu.x + pu.w > p.width || pu.y + pu.h > p.height ||
+            (pu.x & 3) || (pu.y & 3))
+            FAIL(e, OH_E_ARG, "PU %u: bad rectangle", i);
+        if (pu.ref[0] == OH_NO_REF && pu.ref[1] == OH_NO_REF)
+            FAIL(e, OH_E_ARG, "PU %u: no reference list", i);
+        for (int l = 0; l < 2; l++)
+            if (pu.ref[l] != OH_NO_REF && (pu.ref[l] >= OH_MAX_REFS || !ref_ok[pu.ref[l]]))
+                FAIL(e, OH_E_ARG, "PU %u: reference slot %d is not a usable picture", i, pu.ref[l]);
+        if (pu.wp != OH_NO_WP && pu.wp >= f->n_wp)
+            FAIL(e, OH_E_ARG, "PU %u: weight index out of range", i);
+        for (int oy = 0; oy < pu.h; oy += 16)
+            for (int ox = 0; ox < pu.w; ox += 16) {
+                DevTile t;
+                t.pu = i; t.ox = (uint8_t)ox; t.oy = (uint8_t)oy;
+                t.w = (uint8_t)(pu.w - ox < 16 ? pu.w - ox : 16);
+                t.h = (uint8_t)(pu.h - oy < 16 ? pu.h - oy : 16);
+                tiles.push_back(t);
+            }
+    }
+    for (uint32_t i = 0; i < f->n_wp; i++)
+        if (f->wp[i].log2_denom[0] > 7 || f->wp[i].log2_denom[1] > 7)
+            FAIL(e, OH_E_ARG, "weights %u: log2 denominator out of range", i);
+    for (uint32_t i = 0; i < f->n_tu; i++) {
+        const OhTu &t = f->tu[i];
+        if (t.c_idx >= nplanes || t.log2_size < 2 || t.log2_size > 5 || t.kind > OH_TU_PCM)
+            FAIL(e, OH_E_ARG, "TU %u: bad plane / size / kind", i);
+        int n = 1 << t.log2_size;
+        if (t.x + n > cur->w[t.c_idx] || t.y + n > cur->h[t.c_idx])
+            FAIL(e, OH_E_ARG, "TU %u: outside the plane", i);
+        if ((uint64_t)t.coeff_off + (uint64_t)n * n > f->n_coeff)
+            FAIL(e, OH_E_ARG, "TU %u: coefficients outside the pool", i);
+        if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
+            FAIL(e, OH_E_ARG, "TU %u: rotation is 4x4 only", i);
+    }
+    if (f->n_intra) {
+        /* CTU wavefront tables: levels -> ictu[] -> sub_start[] -> intra[] must nest exactly */
+        if (!f->level_start || !f->n_levels || !f->ictu || !f->n_ictu || !f->sub_start || !f->n_sub ||
+            f->level_start[0] != 0 || f->level_start[f->n_levels] != f->n_ictu ||
+            f->sub_start[0] != 0 || f->sub_start[f->n_sub] != f->n_intra)
+            FAIL(e, OH_E_ARG, "intra wavefront tables inconsistent");
+        for (uint32_t l = 0; l < f->n_levels; l++)
+            if (f->level_start[l] > f->level_start[l + 1])
+                FAIL(e, OH_E_ARG, "intra level table not monotonic");
+        for (uint32_t s = 0; s < f->n_sub; s++)
+            if (f->sub_start[s] > f->sub_start[s + 1])
+                FAIL(e, OH_E_ARG, "intra sub-level table not monotonic");
+        uint32_t expect = 0;
+        for (uint32_t k = 0; k < f->n_ictu; k++) {
+            if (f->ictu[k].sub_first != expect || !f->ictu[k].n_sub)
+                FAIL(e, OH_E_ARG, "intra CTU %u: sub-level range not contiguous", k);
+            expect += f->ictu[k].n_sub;
+        }
+        if (expect != f->n_sub)
+            FAIL(e, OH_E_ARG, "intra CTU table does not cover the sub-level table");
+    }
+    for (uint32_t i = 0; i < f->n_intra; i++) {
+        const OhIntra &it = f->intra[i];
+        if (it.c_idx >= nplanes || it.log2_size < 2 || it.log2_size > 5 || it.mode > 34)
+            FAIL(e, OH_E_ARG, "intra %u: bad plane / size / mode", i);
+        int n = 1 << it.log2_size;
+        if (it.x + n > cur->w[it.c_idx] || it.y + n > cur->h[it.c_idx])
+            FAIL(e, OH_E_ARG, "intra %u: outside the plane", i);
+        if (((it.avail & (OH_AV_LEFT | OH_AV_BOTTOM_LEFT | OH_AV_UP_LEFT)) && it.x == 0) ||
+            ((it.avail & (OH_AV_UP | OH_AV_UP_RIGHT | OH_AV_UP_LEFT)) && it.y == 0) ||
+            ((it.avail & OH_AV_UP_RIGHT) && it.x + n >= cur->w[it.c_idx]) ||
+            ((it.avail & OH_AV_BOTTOM_LEFT) && it.y + n >= cur->h[it.c_idx]))
+            FAIL(e, OH_E_ARG, "intra %u: candidate flags point outside the picture", i);
+        if (it.tu != OH_NO_COEFF) {
+            if (it.tu >= f->n_tu)
+                FAIL(e, OH_E_ARG, "intra %u: TU index out of range", i);
+            const OhTu &t = f->tu[it.tu];
+            if (t.c_idx != it.c_idx || t.x != it.x || t.y != it.y || t.log2_size != it.log2_size || (t.flags & OH_TUF_ADD_NOW))
+                FAIL(e, OH_E_ARG, "intra %u: TU does not match the block", i);
+        }
+    }
+    if (p.deblock_enabled) {
+        if (!f->vertical_bs || !f->horizontal_bs || !f->qp_y_tab || !f->deblock || f->bs_size < oh_bs_size(&p))
+            FAIL(e, OH_E_ARG, "deblock side arrays missing or too small");
+    }
+    if ((p.pcm_loop_filter_disable || p.transquant_bypass_enable) && !f->is_pcm)
+        FAIL(e, OH_E_ARG, "is_pcm map required when pcm loop-filter disable / transquant bypass is on");
+    return OH_OK;
+}
+
+extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
+{
+    if (!e || !f || !out)
+        return OH_E_ARG;
+    *out = nullptr;
+    int rc = check_params(e, &f->p);
+    if (rc)
+        return rc;
+    Pic *cur = get_pic(e, f->cur_pic);
+    if (!cur || !same_geometry(cur->p, f->p))
+        FAIL(e, OH_E_ARG, "cur_pic %d is not an allocated picture of this geometry", f->cur_pic);
+    std::vector<DevTile> tiles;
+    tiles.reserve((size_t)f->n_pu * 2);
+    rc = validate(e, f, cur, tiles);
+    if (rc)
+        return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+
+    const OhPicParams &p = f->p;
+    const size_t n_ctb = (size_t)oh_ctb_width(&p) * oh_ctb_height(&p);
+    const size_t n_pcm = (size_t)oh_min_pu_width(&p) * oh_min_pu_height(&p);
+    const bool has_sao = p.sao_enabled && f->sao;
+    const bool has_db = p.deblock_enabled != 0;
+
+    /* arena layout: [DevFrame][pu][tiles][wp][tu][intra][vbs][hbs][qp][is_pcm][db][sao][coeffs] | [res] */
+    struct Seg { const void *src; size_t bytes, off; };
+    Seg seg[16];
+    int ns = 0;
+    size_t total = 0;
+    auto add = [&](const void *src, size_t bytes) {
+        seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].off = total;
+        total += align_up(bytes ? bytes : 1, 256);
+        return ns++;
+    };
+    DevFrame hd;
+    memset(&hd, 0, sizeof(hd));
+    int s_hdr = add(&hd, sizeof(DevFrame));
+    int s_pu = add(f->pu, (size_t)f->n_pu * sizeof(OhPu));
+    int s_tiles = add(tiles.data(), tiles.size() * sizeof(DevTile));
+    int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
+    int s_tu = add(f->tu, (size_t)f->n_tu * sizeof(OhTu));
+    int s_intra = add(f->intra, (size_t)f->n_intra * sizeof(OhIntra));
+    int s_ictu = add(f->n_intra ? f->ictu : nullptr, f->n_intra ? (size_t)f->n_ictu * sizeof(OhIntraCtu) : 0);
+    int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
+    int s_vbs = add(has_db ? f->vertical_bs : nullptr, has_db ? f->bs_size : 0);
+    int s_hbs = add(has_db ? f->horizontal_bs : nullptr, has_db ? f->bs_size : 0);
+    int s_qp = add(has_db ? f->qp_y_tab : nullptr, has_db ? oh_qp_tab_size(&p) : 0);
+    int s_pcm = add(f->is_pcm, f->is_pcm ? n_pcm : 0);
+    int s_db = add(has_db ? f->deblock : nullptr, has_db ? n_ctb * sizeof(OhDeblockCtb) : 0);
+    int s_sao = add(has_sao ? f->sao : nullptr, has_sao ? n_ctb * sizeof(OhSaoCtb) : 0);
+    int s_coef = add(f->coeffs, (size_t)f->n_coeff * sizeof(int16_t));
+    const size_t copy_bytes = total;
+    const size_t res_off = total;
+    total += align_up((size_t)(f->n_coeff ? f->n_coeff : 1) * sizeof(int16_t), 256);
+
+    OhDevFrame *df = new OhDevFrame();
+    if (hipMalloc(&df->arena, total) != hipSuccess) {
+        delete df;
+        FAIL(e, OH_E_NOMEM, "hipMalloc(%zu) for the work list failed", total);
+    }
+    char *base = (char *)df->arena;
+    hd.pp = p;
+    fill_planes(&hd.cur, cur, false);
+    fill_planes(&hd.out, cur, has_sao);
+    for (int i = 0; i < OH_MAX_REFS; i++) {
+        Pic *r = get_pic(e, f->ref_pics[i]);
+        if (r && same_geometry(r->p, p))
+            fill_planes(&hd.refs[i], r, r->final_b);
+    }
+    hd.pu = (const OhPu *)(base + seg[s_pu].off);
+    hd.tiles = (const DevTile *)(base + seg[s_tiles].off);
+    hd.wp = (const OhWeights *)(base + seg[s_wp].off);
+    hd.tu = (const OhTu *)(base + seg[s_tu].off);
+    hd.coeffs = (const int16_t *)(base + seg[s_coef].off);
+    hd.res = (int16_t *)(base + res_off);
+    hd.intra = (const OhIntra *)(base + seg[s_intra].off);
+    hd.ictu = (const OhIntraCtu *)(base + seg[s_ictu].off);
+    hd.sub_start = (const uint32_t *)(base + seg[s_sub].off);
+    hd.vbs = (const uint8_t *)(base + seg[s_vbs].off);
+    hd.hbs = (const uint8_t *)(base + seg[s_hbs].off);
+    hd.qp = (const int8_t *)(base + seg[s_qp].off);
+    hd.is_pcm = f->is_pcm ? (const uint8_t *)(base + seg[s_pcm].off) : nullptr;
+    hd.db = (const OhDeblockCtb *)(base + seg[s_db].off);
+    hd.sao = has_sao ? (const OhSaoCtb *)(base + seg[s_sao].off) : nullptr;
+    hd.n_pu = f->n_pu; hd.n_tiles = (uint32_t)tiles.size(); hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
+    (void)s_hdr;
+
+    /* stage everything in one host buffer -> one H2D copy */
+    void *stage = nullptr;
+    if (hipHostMalloc(&stage, copy_bytes, hipHostMallocDefault) != hipSuccess) {
+        free_dev_frame(df);
+        FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
+    }
+    for (int i = 0; i < ns; i++)
+        if (seg[i].bytes && seg[i].src)
+            memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
+    hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, e->stream);
+    if (hrc == hipSuccess)
+        hrc = hipStreamSynchronize(e->stream);
+    (void)hipHostFree(stage);
+    if (hrc != hipSuccess) {
+        free_dev_frame(df);
+        FAIL(e, OH_E_HIP, "work-list upload failed: %s", hipGetErrorString(hrc));
+    }
+    df->d = (DevFrame *)base;
+    df->p = p;
+    df->n_tiles = hd.n_tiles; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
+    df->has_sao = has_sao;
+    if (f->n_intra)
+        df->level_start.assign(f->level_start, f->level_start + f->n_levels + 1);
+    cur->final_b = has_sao;
+    *out = df;
+    return OH_OK;
+}
+
+extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
+{
+    if (!e || !df)
+        return OH_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    EventSet es;
+    bool prof = e->profile;
+    if (prof) {
+        if (!e->ev_pool.empty()) {
+            es = e->ev_pool.back();
+            e->ev_pool.pop_back();
+        } else {
+            for (auto &ev : es.ev)
+                HIPCHK(e, hipEventCreate(&ev));
+        }
+        HIPCHK(e, hipEventRecord(es.ev[0], st));
+    }
+#define MARK(k) do { if (prof) HIPCHK(e, hipEventRecord(es.ev[(k) + 1], st)); } while (0)
+    ohk_inter(df->d, &df->p, df->n_tiles, st);
+    MARK(OH_PASS_INTER);
+    ohk_residual(df->d, &df->p, df->n_tu, st);
+    MARK(OH_PASS_RESIDUAL);
+    for (size_t l = 0; l + 1 < df->level_start.size(); l++)
+        ohk_intra_level(df->d, &df->p, df->level_start[l], df->level_start[l + 1] - df->level_start[l], st);
+    MARK(OH_PASS_INTRA);
+    if (df->p.deblock_enabled)
+        ohk_deblock(df->d, &df->p, 0, st);
+    MARK(OH_PASS_DEBLOCK_V);
+    if (df->p.deblock_enabled)
+        ohk_deblock(df->d, &df->p, 1, st);
+    MARK(OH_PASS_DEBLOCK_H);
+    if (df->has_sao)
+        ohk_sao(df->d, &df->p, st);
+    MARK(OH_PASS_SAO);
+#undef MARK
+    HIPCHK(e, hipGetLastError());
+    if (prof)
+        e->ev_pending.push_back(es);
+    return OH_OK;
+}
+
+extern "C" int oh_frame_free(OhEngine *e, OhDevFrame *df)
+{
+    if (!e || !df)
+        return OH_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    free_dev_frame(df);
+    return OH_OK;
+}
+
+extern "C" int oh_frame_submit(OhEngine *e, const OhFrame *f)
+{
+    OhDevFrame *df = nullptr;
+    int rc = oh_frame_upload(e, f, &df);
+    if (rc)
+        return rc;
+    rc = oh_frame_execute(e, df);
+    e->deferred.push_back(df);
+    return rc;
+}
+
+/* ---------------- profiling ---------------- */
+extern "C" int oh_engine_profile(OhEngine *e, int enable)
+{
+    if (!e)
+        return OH_E_ARG;
+    e->profile = enable != 0;
+    return OH_OK;
+}
+
+extern "C" int oh_engine_pass_times(OhEngine *e, double *ms, uint64_t *executes, int reset)
+{
+    if (!e)
+        return OH_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (EventSet &s : e->ev_pending) {
+        for (int k = 0; k < OH_N_PASSES; k++) {
+            float t = 0;
+            HIPCHK(e, hipEventElapsedTime(&t, s.ev[k], s.ev[k + 1]));
+            e->pass_ms[k] += t;
+        }
+        e->executes++;
+        e->ev_pool.push_back(s);
+    }
+    e->ev_pending.clear();
+    if (ms)
+        for (int k = 0; k < OH_N_PASSES; k++) ms[k] = e->pass_ms[k];
+    if (executes)
+        *executes = e->executes;
+    if (reset) {
+        for (double &v : e->pass_ms) v = 0;
+        e->executes = 0;
+    }
+    return OH_OK;
+}

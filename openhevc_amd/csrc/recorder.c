@@ -1,12 +1,17 @@
 /*
- * recorder.c — host-side work-item recorder and intra dependency-level scheduler.
+ * recorder.c — host-side work-item recorder and the intra CTU-wavefront scheduler.
  * Plain C, no GPU dependency (part of libohevc_host.so and libohevc_hip.so).
  *
- * The level scheduler is the GPU counterpart of the reference's WPP progress counters
- * (pthread_slice.c:238-263, hevc.c:2782/2808): instead of "row r may run CTU k when row r-1
- * finished k+2", every intra block gets level = 1 + max(level of the blocks whose samples it
- * reads), and pass 3 runs one level at a time.  Inter blocks are level 0 (complete after
- * passes 1-2).
+ * The scheduler is the GPU counterpart of the reference's WPP progress counters
+ * (pthread_slice.c:238-263, hevc.c:2782/2808: "row r may decode CTU k once row r-1 finished
+ * k+2").  Here the dependency is taken from what the intra blocks actually read:
+ *   - every intra block gets a SUB-LEVEL inside its CTU: 1 + max sub-level of the same-CTU
+ *     intra blocks whose samples it gathers (hevcpred_template.c:164-183);
+ *   - every CTU with intra blocks gets a LEVEL: 1 + max level of the neighbouring CTUs (left,
+ *     up-left, up, up-right) whose intra samples its blocks gather.
+ * Inter-predicted samples never create a dependency: they are complete after passes 1-2.
+ * Pass 3 launches one kernel per CTU level, one workgroup per CTU; sub-levels are separated by
+ * workgroup barriers inside the CU instead of kernel launches.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -20,16 +25,24 @@ struct OhRecorder {
     OhTu      *tu;      uint32_t cap_tu;
     int16_t   *coeffs;  uint64_t cap_coeff;
     OhIntra   *intra;   uint32_t cap_intra;     /* in recording order */
-    uint32_t  *intra_level;                     /* level of intra[i]  */
+    uint32_t  *it_ctu;                          /* CTU raster index of intra[i] */
+    uint16_t  *it_sub;                          /* sub-level (1-based) of intra[i] */
     OhIntra   *sorted;  uint32_t cap_sorted;
-    uint32_t  *level_start; uint32_t cap_levels;
-    uint32_t   max_level;
+    /* schedule */
+    int        n_ctb, ctbw, ctbh;
+    uint8_t   *ctu_dep;                         /* per CTU: bit0 left, bit1 up-left, bit2 up, bit3 up-right */
+    uint16_t  *ctu_nsub;                        /* per CTU: highest sub-level recorded */
+    uint16_t  *ctu_level;                       /* per CTU: wavefront level (1-based, 0 = no intra blocks) */
+    uint32_t  *ctu_entry;                       /* per CTU: index into ictu[] */
+    OhIntraCtu *ictu;
+    uint32_t  *sub_start; uint32_t cap_sub;
+    uint32_t  *level_start;
     /* side arrays */
     uint8_t *vbs, *hbs, *is_pcm;
     int8_t  *qp;
     OhDeblockCtb *deblock;
     OhSaoCtb *sao;
-    /* per-plane level map at 4x4-sample granularity, and the luma "decoded" map (4x4 luma) */
+    /* per-plane sub-level map at 4x4-sample granularity, and the luma "decoded" map (4x4 luma) */
     uint16_t *lvl[3]; int lw[3], lh[3];
     uint8_t  *decoded; int dw, dh;
 };
@@ -63,13 +76,20 @@ OhRecorder *oh_rec_create(const OhPicParams *p)
     r->dw = (p->width + 3) >> 2;
     r->dh = (p->height + 3) >> 2;
     r->decoded = (uint8_t *)calloc((size_t)r->dw * r->dh, 1);
+    r->ctbw = oh_ctb_width(p); r->ctbh = oh_ctb_height(p); r->n_ctb = r->ctbw * r->ctbh;
+    r->ctu_dep = (uint8_t *)calloc((size_t)r->n_ctb, 1);
+    r->ctu_nsub = (uint16_t *)calloc((size_t)r->n_ctb, sizeof(uint16_t));
+    r->ctu_level = (uint16_t *)calloc((size_t)r->n_ctb, sizeof(uint16_t));
+    r->ctu_entry = (uint32_t *)calloc((size_t)r->n_ctb, sizeof(uint32_t));
+    r->ictu = (OhIntraCtu *)calloc((size_t)r->n_ctb, sizeof(OhIntraCtu));
+    r->level_start = (uint32_t *)calloc((size_t)r->n_ctb + 2, sizeof(uint32_t));
     r->f.bs_size = oh_bs_size(p);
     r->vbs = (uint8_t *)calloc(r->f.bs_size, 1);
     r->hbs = (uint8_t *)calloc(r->f.bs_size, 1);
     r->qp = (int8_t *)calloc(oh_qp_tab_size(p), 1);
     r->is_pcm = (uint8_t *)calloc((size_t)oh_min_pu_width(p) * oh_min_pu_height(p) + 1, 1);
-    r->deblock = (OhDeblockCtb *)calloc((size_t)oh_ctb_width(p) * oh_ctb_height(p), sizeof(OhDeblockCtb));
-    r->sao = (OhSaoCtb *)calloc((size_t)oh_ctb_width(p) * oh_ctb_height(p), sizeof(OhSaoCtb));
+    r->deblock = (OhDeblockCtb *)calloc((size_t)r->n_ctb, sizeof(OhDeblockCtb));
+    r->sao = (OhSaoCtb *)calloc((size_t)r->n_ctb, sizeof(OhSaoCtb));
     return r;
 }
 
@@ -79,8 +99,9 @@ void oh_rec_destroy(OhRecorder *r)
 {
     if (!r)
         return;
-    free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->intra_level);
-    free(r->sorted); free(r->level_start);
+    free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->it_ctu); free(r->it_sub);
+    free(r->sorted); free(r->ctu_dep); free(r->ctu_nsub); free(r->ctu_level); free(r->ctu_entry); free(r->ictu);
+    free(r->sub_start); free(r->level_start);
     free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->qp); free(r->deblock); free(r->sao);
     for (int c = 0; c < 3; c++)
         free(r->lvl[c]);
@@ -94,14 +115,15 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     r->f.cur_pic = cur_pic;
     for (int i = 0; i < OH_MAX_REFS; i++)
         r->f.ref_pics[i] = i < n_ref_pics ? ref_pics[i] : -1;
-    r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = 0;
+    r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = r->f.n_ictu = r->f.n_sub = 0;
     r->f.n_coeff = 0;
-    r->max_level = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
     memset(r->is_pcm, 0, (size_t)oh_min_pu_width(p) * oh_min_pu_height(p));
-    memset(r->sao, 0, (size_t)oh_ctb_width(p) * oh_ctb_height(p) * sizeof(OhSaoCtb));
-    memset(r->deblock, 0, (size_t)oh_ctb_width(p) * oh_ctb_height(p) * sizeof(OhDeblockCtb));
+    memset(r->sao, 0, (size_t)r->n_ctb * sizeof(OhSaoCtb));
+    memset(r->deblock, 0, (size_t)r->n_ctb * sizeof(OhDeblockCtb));
+    memset(r->ctu_dep, 0, (size_t)r->n_ctb);
+    memset(r->ctu_nsub, 0, (size_t)r->n_ctb * sizeof(uint16_t));
     for (int c = 0; c < 3; c++)
         if (r->lvl[c])
             memset(r->lvl[c], 0, (size_t)r->lw[c] * r->lh[c] * sizeof(uint16_t));
@@ -148,45 +170,64 @@ uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int ki
     return r->f.n_tu++;
 }
 
-static inline unsigned lvl_at(const OhRecorder *r, int c, int x, int y)
+/* one neighbour cell (plane c, sample position x,y) read by a block of CTU (cx,cy) */
+static inline void visit(OhRecorder *r, int c, int x, int y, int cx, int cy, unsigned *sub, unsigned *dep)
 {
-    return r->lvl[c][(y >> 2) * r->lw[c] + (x >> 2)];
+    const OhPicParams *p = &r->f.p;
+    unsigned v = r->lvl[c][(y >> 2) * r->lw[c] + (x >> 2)];
+    if (!v)
+        return;                                           /* inter / PCM-free sample: no dependency */
+    int nx = (x << oh_hshift(p, c)) >> p->log2_ctb_size, ny = (y << oh_vshift(p, c)) >> p->log2_ctb_size;
+    if (nx == cx && ny == cy) {
+        if (v > *sub) *sub = v;
+    } else if (ny == cy) {
+        *dep |= 1;                                        /* left CTU (also its rows below: bottom-left samples) */
+    } else {
+        *dep |= nx < cx ? 2 : (nx == cx ? 4 : 8);         /* up-left, up, up-right */
+    }
 }
 
 int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
 {
     const OhPicParams *p = &r->f.p;
-    int n = 1 << log2_size;
-    int pw = p->width >> oh_hshift(p, c_idx), ph = p->height >> oh_vshift(p, c_idx);
-    unsigned lv = 0, t;
+    int n = 1 << log2_size, c = c_idx;
+    int pw = p->width >> oh_hshift(p, c), ph = p->height >> oh_vshift(p, c);
     if (x < 0 || y < 0 || x + n > pw || y + n > ph)
         return -1;
+    int cx = (x << oh_hshift(p, c)) >> p->log2_ctb_size, cy = (y << oh_vshift(p, c)) >> p->log2_ctb_size;
+    unsigned sub = 0, dep = 0;
     /* the samples intra_pred() gathers (hevcpred_template.c:164-183): one column to the left over
      * 2N rows, one row above over 2N columns, and the corner — each only where available */
-    if (avail & OH_AV_UP_LEFT) { t = lvl_at(r, c_idx, x - 1, y - 1); if (t > lv) lv = t; }
+    if (avail & OH_AV_UP_LEFT) visit(r, c, x - 1, y - 1, cx, cy, &sub, &dep);
     if (avail & OH_AV_UP)
-        for (int i = 0; i < n; i += 4) { t = lvl_at(r, c_idx, x + i, y - 1); if (t > lv) lv = t; }
+        for (int i = 0; i < n; i += 4) visit(r, c, x + i, y - 1, cx, cy, &sub, &dep);
     if (avail & OH_AV_UP_RIGHT)
-        for (int i = n; i < 2 * n && x + i < pw; i += 4) { t = lvl_at(r, c_idx, x + i, y - 1); if (t > lv) lv = t; }
+        for (int i = n; i < 2 * n && x + i < pw; i += 4) visit(r, c, x + i, y - 1, cx, cy, &sub, &dep);
     if (avail & OH_AV_LEFT)
-        for (int i = 0; i < n; i += 4) { t = lvl_at(r, c_idx, x - 1, y + i); if (t > lv) lv = t; }
+        for (int i = 0; i < n; i += 4) visit(r, c, x - 1, y + i, cx, cy, &sub, &dep);
     if (avail & OH_AV_BOTTOM_LEFT)
-        for (int i = n; i < 2 * n && y + i < ph; i += 4) { t = lvl_at(r, c_idx, x - 1, y + i); if (t > lv) lv = t; }
-    lv += 1;
+        for (int i = n; i < 2 * n && y + i < ph; i += 4) visit(r, c, x - 1, y + i, cx, cy, &sub, &dep);
+    sub += 1;
     for (int yy = y; yy < y + n; yy += 4)
         for (int xx = x; xx < x + n; xx += 4)
-            r->lvl[c_idx][(yy >> 2) * r->lw[c_idx] + (xx >> 2)] = (uint16_t)lv;
-    if (lv > r->max_level)
-        r->max_level = lv;
+            r->lvl[c][(yy >> 2) * r->lw[c] + (xx >> 2)] = (uint16_t)sub;
+    int ctu = cy * r->ctbw + cx;
+    r->ctu_dep[ctu] |= (uint8_t)dep;
+    if (sub > r->ctu_nsub[ctu])
+        r->ctu_nsub[ctu] = (uint16_t)sub;
 
     uint32_t cap = r->cap_intra;
     GROW32(r->intra, r->cap_intra, (uint64_t)r->f.n_intra + 1);
-    if (r->cap_intra != cap)
-        r->intra_level = (uint32_t *)realloc(r->intra_level, sizeof(uint32_t) * r->cap_intra);
+    if (r->cap_intra != cap) {
+        r->it_ctu = (uint32_t *)realloc(r->it_ctu, sizeof(uint32_t) * r->cap_intra);
+        r->it_sub = (uint16_t *)realloc(r->it_sub, sizeof(uint16_t) * r->cap_intra);
+    }
     OhIntra *it = &r->intra[r->f.n_intra];
-    it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
+    it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c; it->log2_size = (uint8_t)log2_size;
     it->mode = (uint8_t)mode; it->avail = (uint8_t)avail; it->tu = tu;
-    r->intra_level[r->f.n_intra++] = lv;
+    r->it_ctu[r->f.n_intra] = (uint32_t)ctu;
+    r->it_sub[r->f.n_intra] = (uint16_t)sub;
+    r->f.n_intra++;
     return 0;
 }
 
@@ -200,27 +241,73 @@ OhSaoCtb     *oh_rec_sao(OhRecorder *r)           { return r->sao; }
 const OhFrame *oh_rec_finish(OhRecorder *r)
 {
     OhFrame *f = &r->f;
-    uint32_t nl = r->max_level;                        /* levels are 1..max_level */
-    GROW32(r->sorted, r->cap_sorted, (uint64_t)f->n_intra + 1);
-    GROW32(r->level_start, r->cap_levels, (uint64_t)nl + 2);
-    memset(r->level_start, 0, sizeof(uint32_t) * (nl + 2));
-    for (uint32_t i = 0; i < f->n_intra; i++)          /* counting sort, stable */
-        r->level_start[r->intra_level[i]]++;           /* slot l holds count of level l (1-based) */
+    const int W = r->ctbw;
+    uint32_t max_level = 0, n_ictu = 0, n_sub = 0;
+
+    /* 1. CTU levels, in raster order (every dependency points to an earlier CTU) */
+    for (int i = 0; i < r->n_ctb; i++) {
+        unsigned lv = 0;
+        if (r->ctu_nsub[i]) {
+            int x = i % W;
+            unsigned d = r->ctu_dep[i], t;
+            lv = 1;
+            if ((d & 1) && x > 0                 && (t = r->ctu_level[i - 1]))     { if (t + 1 > lv) lv = t + 1; }
+            if ((d & 2) && x > 0 && i >= W       && (t = r->ctu_level[i - W - 1])) { if (t + 1 > lv) lv = t + 1; }
+            if ((d & 4) && i >= W                && (t = r->ctu_level[i - W]))     { if (t + 1 > lv) lv = t + 1; }
+            if ((d & 8) && x + 1 < W && i >= W   && (t = r->ctu_level[i - W + 1])) { if (t + 1 > lv) lv = t + 1; }
+            if (lv > max_level) max_level = lv;
+            n_ictu++;
+        }
+        r->ctu_level[i] = (uint16_t)lv;
+    }
+    /* 2. order the CTUs by level (counting sort, raster order inside a level) */
+    memset(r->level_start, 0, sizeof(uint32_t) * (max_level + 2));
+    for (int i = 0; i < r->n_ctb; i++)
+        if (r->ctu_level[i])
+            r->level_start[r->ctu_level[i]]++;
     uint32_t acc = 0;
-    for (uint32_t l = 1; l <= nl; l++) {
+    for (uint32_t l = 1; l <= max_level; l++) {
         uint32_t cnt = r->level_start[l];
-        r->level_start[l - 1] = acc;                   /* start of 0-based level l-1 */
+        r->level_start[l - 1] = acc;
         acc += cnt;
     }
-    r->level_start[nl] = acc;
-    uint32_t *cursor = (uint32_t *)malloc(sizeof(uint32_t) * (nl + 1));
-    memcpy(cursor, r->level_start, sizeof(uint32_t) * (nl + 1));
-    for (uint32_t i = 0; i < f->n_intra; i++)
-        r->sorted[cursor[r->intra_level[i] - 1]++] = r->intra[i];
+    r->level_start[max_level] = acc;
+    uint32_t *cursor = (uint32_t *)malloc(sizeof(uint32_t) * (max_level + 1));
+    memcpy(cursor, r->level_start, sizeof(uint32_t) * (max_level + 1));
+    for (int i = 0; i < r->n_ctb; i++)
+        if (r->ctu_level[i])
+            r->ctu_entry[i] = cursor[r->ctu_level[i] - 1]++;
     free(cursor);
+    /* 3. sub-level ranges: CTU after CTU in schedule order */
+    for (int i = 0; i < r->n_ctb; i++)
+        if (r->ctu_level[i]) {
+            OhIntraCtu *e = &r->ictu[r->ctu_entry[i]];
+            e->ctu = (uint16_t)i;
+            e->n_sub = r->ctu_nsub[i];
+        }
+    for (uint32_t k = 0; k < n_ictu; k++) {
+        r->ictu[k].sub_first = n_sub;
+        n_sub += r->ictu[k].n_sub;
+    }
+    GROW32(r->sub_start, r->cap_sub, (uint64_t)n_sub + 2);
+    memset(r->sub_start, 0, sizeof(uint32_t) * (n_sub + 2));
+    for (uint32_t i = 0; i < f->n_intra; i++)              /* histogram at slot+1 */
+        r->sub_start[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1 + 1]++;
+    for (uint32_t s = 0; s < n_sub; s++)
+        r->sub_start[s + 1] += r->sub_start[s];
+    /* 4. place the blocks (stable: recording order inside one (CTU, sub-level)) */
+    GROW32(r->sorted, r->cap_sorted, (uint64_t)f->n_intra + 1);
+    uint32_t *pos = (uint32_t *)malloc(sizeof(uint32_t) * (n_sub + 1));
+    memcpy(pos, r->sub_start, sizeof(uint32_t) * (n_sub + 1));
+    for (uint32_t i = 0; i < f->n_intra; i++)
+        r->sorted[pos[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1]++] = r->intra[i];
+    free(pos);
 
     f->pu = r->pu; f->wp = r->wp; f->tu = r->tu; f->coeffs = r->coeffs;
-    f->intra = r->sorted; f->n_levels = nl; f->level_start = r->level_start;
+    f->intra = r->sorted;
+    f->n_ictu = n_ictu; f->ictu = r->ictu;
+    f->n_sub = n_sub; f->sub_start = r->sub_start;
+    f->n_levels = max_level; f->level_start = r->level_start;
     f->vertical_bs = r->vbs; f->horizontal_bs = r->hbs; f->qp_y_tab = r->qp;
     f->is_pcm = (f->p.pcm_loop_filter_disable || f->p.transquant_bypass_enable) ? r->is_pcm : NULL;
     f->deblock = r->deblock;

@@ -1,0 +1,183 @@
+"""ctypes binding of libohevc_hip.so (include/ohevc_hip.h).  Plumbing only: no arithmetic here.
+
+There is no CPU fallback: creating an Engine without the built library or without a GPU raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import frame as F
+
+OH_N_PASSES = 6
+PASS_NAMES = ("inter", "residual", "intra", "deblock_v", "deblock_h", "sao")
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(F.PKG_DIR, "libohevc_hip.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", F.PKG_DIR, "libohevc_hip.so", "libohevc_host.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path()):
+            raise EngineError("libohevc_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(lib_path())
+        V, I = C.c_void_p, C.c_int
+        PP = C.POINTER(C.c_void_p)
+        L.oh_engine_create.argtypes = [PP, I]
+        L.oh_engine_create_on_stream.argtypes = [PP, I, V]
+        L.oh_pic_bytes.argtypes = [C.POINTER(F.OhPicParams)]
+        L.oh_pic_bytes.restype = C.c_size_t
+        L.oh_pic_wrap.argtypes = [V, C.POINTER(F.OhPicParams), V, V, C.c_size_t, C.POINTER(I)]
+        L.oh_pic_final_half.argtypes = [V, I]
+        L.oh_pic_set_final_half.argtypes = [V, I, I]
+        L.oh_engine_destroy.argtypes = [V]
+        L.oh_engine_destroy.restype = None
+        L.oh_engine_last_error.argtypes = [V]
+        L.oh_engine_last_error.restype = C.c_char_p
+        L.oh_engine_sync.argtypes = [V]
+        L.oh_pic_alloc.argtypes = [V, C.POINTER(F.OhPicParams), C.POINTER(I)]
+        L.oh_pic_free.argtypes = [V, I]
+        L.oh_pic_upload.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
+        L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
+        L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
+        L.oh_frame_execute.argtypes = [V, V]
+        L.oh_frame_free.argtypes = [V, V]
+        L.oh_frame_submit.argtypes = [V, C.POINTER(F.OhFrame)]
+        L.oh_engine_profile.argtypes = [V, I]
+        L.oh_engine_pass_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
+        L.oh_engine_stream.argtypes = [V]
+        L.oh_engine_stream.restype = V
+        L.oh_pic_device_planes.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        _lib = L
+    return _lib
+
+
+class Engine:
+    def __init__(self, device=0, stream=None):
+        """stream: optional hipStream_t handle (int), e.g. torch.cuda.current_stream().cuda_stream"""
+        self.L = lib()
+        h = C.c_void_p()
+        if stream is None:
+            rc = self.L.oh_engine_create(C.byref(h), device)
+        else:
+            rc = self.L.oh_engine_create_on_stream(C.byref(h), device, C.c_void_p(stream))
+        if rc != 0:
+            raise EngineError(f"oh_engine_create(device={device}) failed with {rc}: no usable MI355X / HIP device")
+        self.h = h
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self.L.oh_engine_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.oh_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.L.oh_engine_sync(self.h), "oh_engine_sync")
+
+    # ---- pictures ----
+    def pic_alloc(self, params):
+        pid = C.c_int(-1)
+        self._chk(self.L.oh_pic_alloc(self.h, C.byref(params), C.byref(pid)), "oh_pic_alloc")
+        return pid.value
+
+    def pic_wrap(self, params, half0_ptr, half1_ptr, half_bytes):
+        pid = C.c_int(-1)
+        self._chk(self.L.oh_pic_wrap(self.h, C.byref(params), C.c_void_p(half0_ptr), C.c_void_p(half1_ptr), half_bytes,
+                                     C.byref(pid)), "oh_pic_wrap")
+        return pid.value
+
+    def pic_final_half(self, pid):
+        r = self.L.oh_pic_final_half(self.h, pid)
+        if r < 0:
+            raise EngineError(f"oh_pic_final_half({pid}) failed")
+        return r
+
+    def pic_set_final_half(self, pid, half):
+        self._chk(self.L.oh_pic_set_final_half(self.h, pid, half), "oh_pic_set_final_half")
+
+    def pic_free(self, pid):
+        self._chk(self.L.oh_pic_free(self.h, pid), "oh_pic_free")
+
+    @staticmethod
+    def _plane_args(hp):
+        n = len(hp.planes)
+        d = (C.c_void_p * 3)(*[pl.ctypes.data for pl in hp.planes] + [None] * (3 - n))
+        s = (C.c_ssize_t * 3)(*[pl.strides[0] for pl in hp.planes] + [0] * (3 - n))
+        return d, s
+
+    def pic_upload(self, pid, hp):
+        d, s = self._plane_args(hp)
+        self._chk(self.L.oh_pic_upload(self.h, pid, d, s), "oh_pic_upload")
+
+    def pic_download(self, pid, params):
+        hp = F.HostPic(params)
+        d, s = self._plane_args(hp)
+        self._chk(self.L.oh_pic_download(self.h, pid, d, s), "oh_pic_download")
+        return hp
+
+    def pic_device_planes(self, pid):
+        p = (C.c_void_p * 3)()
+        st, w, h = (C.c_int32 * 3)(), (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        self._chk(self.L.oh_pic_device_planes(self.h, pid, p, st, w, h), "oh_pic_device_planes")
+        return [(p[c], st[c], w[c], h[c]) for c in range(3)]
+
+    # ---- work lists ----
+    def frame_upload(self, frame):
+        df = C.c_void_p()
+        self._chk(self.L.oh_frame_upload(self.h, C.byref(frame), C.byref(df)), "oh_frame_upload")
+        return df
+
+    def frame_execute(self, df):
+        self._chk(self.L.oh_frame_execute(self.h, df), "oh_frame_execute")
+
+    def frame_free(self, df):
+        self._chk(self.L.oh_frame_free(self.h, df), "oh_frame_free")
+
+    def frame_submit(self, frame):
+        self._chk(self.L.oh_frame_submit(self.h, C.byref(frame)), "oh_frame_submit")
+
+    # ---- profiling ----
+    def profile(self, enable):
+        self._chk(self.L.oh_engine_profile(self.h, int(enable)), "oh_engine_profile")
+
+    def pass_times(self, reset=False):
+        ms = (C.c_double * OH_N_PASSES)()
+        n = C.c_uint64()
+        self._chk(self.L.oh_engine_pass_times(self.h, ms, C.byref(n), int(reset)), "oh_engine_pass_times")
+        return dict(zip(PASS_NAMES, list(ms))), n.value
+
+    def stream(self):
+        return self.L.oh_engine_stream(self.h)
+
+
+def remap_frame(frame, id_map):
+    """copy of an OhFrame header whose picture ids are translated through id_map (host id -> engine id)"""
+    g = F.OhFrame()
+    C.memmove(C.byref(g), C.byref(frame), C.sizeof(F.OhFrame))
+    g.cur_pic = id_map[frame.cur_pic]
+    for i in range(F.OH_MAX_REFS):
+        r = frame.ref_pics[i]
+        g.ref_pics[i] = id_map.get(r, -1)
+    return g

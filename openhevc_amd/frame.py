@@ -47,6 +47,10 @@ class OhIntra(C.Structure):
                 ("mode", C.c_uint8), ("avail", C.c_uint8), ("tu", C.c_uint32)]
 
 
+class OhIntraCtu(C.Structure):
+    _fields_ = [("sub_first", C.c_uint32), ("n_sub", C.c_uint16), ("ctu", C.c_uint16)]
+
+
 class OhDeblockCtb(C.Structure):
     _fields_ = [("beta_offset", C.c_int8), ("tc_offset", C.c_int8)]
 
@@ -64,6 +68,8 @@ class OhFrame(C.Structure):
         ("n_tu", C.c_uint32), ("tu", C.POINTER(OhTu)),
         ("n_coeff", C.c_uint64), ("coeffs", C.POINTER(C.c_int16)),
         ("n_intra", C.c_uint32), ("intra", C.POINTER(OhIntra)),
+        ("n_ictu", C.c_uint32), ("ictu", C.POINTER(OhIntraCtu)),
+        ("n_sub", C.c_uint32), ("sub_start", C.POINTER(C.c_uint32)),
         ("n_levels", C.c_uint32), ("level_start", C.POINTER(C.c_uint32)),
         ("bs_size", C.c_uint32), ("vertical_bs", C.POINTER(C.c_uint8)), ("horizontal_bs", C.POINTER(C.c_uint8)),
         ("qp_y_tab", C.POINTER(C.c_int8)), ("is_pcm", C.POINTER(C.c_uint8)),
@@ -112,6 +118,19 @@ def n_planes(p):
     return 3 if p.chroma_format_idc else 1
 
 
+def half_layout(p):
+    """python twin of oh_pic_half_layout(): (half_bytes, [stride in samples], [plane offset in bytes])"""
+    bpp = 2 if p.bit_depth > 8 else 1
+    total, strides, offs = 0, [], []
+    for c in range(n_planes(p)):
+        w, h = plane_dims(p, c)
+        row = (w * bpp + 255) // 256 * 256
+        strides.append(row // bpp)
+        offs.append(total)
+        total += (row * h + 255) // 256 * 256
+    return total, strides, offs
+
+
 _host = None
 
 
@@ -124,8 +143,8 @@ def host():
     global _host
     if _host is None:
         path = os.path.join(PKG_DIR, "libohevc_host.so")
-        if not os.path.exists(path):
-            build_host()
+        if not os.path.exists(path) or os.path.exists(os.path.join(PKG_DIR, "Makefile")) and os.access(PKG_DIR, os.W_OK):
+            build_host()                     # incremental make; a no-op when up to date
         lib = C.CDLL(path)
         V, I = C.c_void_p, C.c_int
         lib.oh_rec_create.restype = V

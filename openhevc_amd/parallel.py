@@ -1,0 +1,218 @@
+"""Frame-parallel wave schedule across the GPUs of one node (one process per GPU).
+
+The reference parallelises pictures with frame threads that wait on row progress of their
+reference pictures (pthread_frame.c:479-513, hevc.c:1951-1958).  Across GPUs the same
+decomposition is: pictures are the units, decoded reference pictures are the one exchange step.
+Per STEP every rank decodes the same amount of work (weak scaling):
+
+    wave 0      one I picture per rank                         -> all-gather of the finished pictures
+    wave 1..R-1 one reference B picture per rank, predicted    -> all-gather
+                from two pictures of the previous wave, one of
+                them decoded by ANOTHER rank
+    tail        T non-reference B pictures per rank, predicted from pictures of the last two waves
+
+All pictures of one wave are mutually independent, so N GPUs decode a wave concurrently; the
+all-gather (RCCL over xGMI with the NCCL backend; one collective per wave instead of N broadcasts)
+replicates the wave's finished reference pictures into every GPU's DPB.  Non-reference pictures
+are never exchanged.  The collective is issued on the engine's stream, so no host sync is needed.
+
+This module holds only the schedule and the exchange; executing a picture is delegated to a
+backend (the HIP engine in production; tests drive the same schedule with a CPU checker over
+gloo).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+
+@dataclass
+class PicturePlan:
+    name: Tuple            # ("ref", wave, rank) or ("tail", k)
+    slice_type: int        # 0 I, 2 B
+    refs: List[Tuple]      # names of the reference pictures (list index == OhFrame.ref_pics slot)
+    seed: int
+
+
+@dataclass
+class StepPlan:
+    world: int
+    rank: int
+    waves: List[PicturePlan] = field(default_factory=list)     # this rank's reference picture of each wave
+    tail: List[PicturePlan] = field(default_factory=list)      # this rank's non-reference pictures
+
+    def pictures(self):
+        return self.waves + self.tail
+
+
+def make_step_plan(world, rank, n_waves=4, n_tail=12, seed=1):
+    """Deterministic plan; every rank can compute every rank's plan (used for validation)."""
+    plan = StepPlan(world, rank)
+    for w in range(n_waves):
+        s = seed * 1000003 + w * 1009 + rank * 7919
+        if w == 0:
+            plan.waves.append(PicturePlan(("ref", 0, rank), 0, [], s))
+        else:
+            refs = [("ref", w - 1, rank), ("ref", w - 1, (rank + 1) % world)]
+            plan.waves.append(PicturePlan(("ref", w, rank), 2, refs, s))
+    last = n_waves - 1
+    for k in range(n_tail):
+        s = seed * 1000003 + 500 * 1009 + k * 104729 + rank * 7919
+        a = ("ref", last, rank)
+        b = ("ref", last - (k % 2) if last else 0, (rank + 1 + k) % world)
+        plan.tail.append(PicturePlan(("tail", k), 2, [a, b] if a != b else [a, ("ref", last, (rank + 1) % world)], s))
+    return plan
+
+
+class Backend:
+    """What the schedule needs from an executor."""
+
+    def wave_tensor(self, wave):          # torch uint8 tensor [2 halves][world][half_bytes]
+        raise NotImplementedError
+
+    def execute(self, name):              # enqueue the picture's work list
+        raise NotImplementedError
+
+    def final_half(self, name):
+        raise NotImplementedError
+
+    def set_final_half(self, name, half):
+        raise NotImplementedError
+
+
+def run_step(plan: StepPlan, backend: Backend, dist=None):
+    """Enqueue one step.  dist: torch.distributed module (initialised) or None for world == 1."""
+    for w, pic in enumerate(plan.waves):
+        backend.execute(pic.name)
+        if plan.world > 1:
+            half = backend.final_half(pic.name)
+            buf = backend.wave_tensor(w)[half]                    # [world][half_bytes], contiguous
+            dist.all_gather_into_tensor(buf.view(-1), buf[plan.rank])
+            for r in range(plan.world):
+                if r != plan.rank:
+                    backend.set_final_half(("ref", w, r), half)   # same SPS => same half on every rank
+    for pic in plan.tail:
+        backend.execute(pic.name)
+
+
+def pictures_per_step(plan: StepPlan):
+    return len(plan.waves) + len(plan.tail)
+
+
+# ------------------------------------------------------------------------------------------------
+# production backend: HIP engine + torch CUDA tensors (torch is plumbing: memory, stream, RCCL)
+# ------------------------------------------------------------------------------------------------
+def default_synth_knobs():
+    """generator knobs of the benchmark stream (reported with every number)"""
+    return dict(intra_pct=12, skip_pct=35, bi_pct=45, frac_mv_pct=75, mv_range=160, cbf_pct=60, split_pct=45,
+                qp_base=30, qp_var=5, sao_pct=50)
+
+
+class PictureStore:
+    """Names -> picture buffers laid out for the wave all-gather:
+         wave w : uint8 tensor [2 halves][world][half_bytes]   (reference pictures of every rank)
+         tail   : uint8 tensor [n_tail][2][half_bytes]         (this rank's non-reference pictures)"""
+
+    def __init__(self, torch, device, params, plan, n_waves, n_tail):
+        from . import frame as F
+        self.half_bytes, self.strides, self.offsets = F.half_layout(params)
+        self.params, self.plan = params, plan
+        self.waves = [torch.zeros((2, plan.world, self.half_bytes), dtype=torch.uint8, device=device) for _ in range(n_waves)]
+        self.tail = torch.zeros((max(n_tail, 1), 2, self.half_bytes), dtype=torch.uint8, device=device)
+
+    def halves(self, name):
+        """(tensor of half 0, tensor of half 1) of a picture"""
+        if name[0] == "ref":
+            _, w, r = name
+            return self.waves[w][0][r], self.waves[w][1][r]
+        return self.tail[name[1]][0], self.tail[name[1]][1]
+
+    def names(self):
+        out = [("ref", w, r) for w in range(len(self.waves)) for r in range(self.plan.world)]
+        return out + [p.name for p in self.plan.tail]
+
+
+class EngineBackend(Backend):
+    def __init__(self, torch, device_index, params, plan, knobs=None):
+        from . import frame as F
+        from .engine import Engine
+        self.torch, self.params, self.plan = torch, params, plan
+        dev = torch.device("cuda", device_index)
+        torch.cuda.set_device(dev)
+        self.engine = Engine(device_index, stream=torch.cuda.current_stream().cuda_stream)
+        self.store = PictureStore(torch, dev, params, plan, len(plan.waves), len(plan.tail))
+        self.ids: Dict[Tuple, int] = {}
+        for name in self.store.names():
+            h0, h1 = self.store.halves(name)
+            self.ids[name] = self.engine.pic_wrap(params, h0.data_ptr(), h1.data_ptr(), self.store.half_bytes)
+        self.frames: Dict[Tuple, object] = {}
+        self.stats: Dict[Tuple, dict] = {}
+        knobs = dict(default_synth_knobs(), **(knobs or {}))
+        rec = F.Recorder(params)
+        for pic in plan.pictures():
+            sp = F.synth_params(pic.slice_type, pic.seed, n_refs=max(len(pic.refs), 0), **knobs)
+            f = rec.synth(sp, self.ids[pic.name], [self.ids[r] for r in pic.refs])
+            self.stats[pic.name] = frame_stats(f)
+            self.frames[pic.name] = self.engine.frame_upload(f)
+        rec.close()
+
+    def wave_tensor(self, wave):
+        return self.store.waves[wave]
+
+    def execute(self, name):
+        self.engine.frame_execute(self.frames[name])
+
+    def final_half(self, name):
+        return self.engine.pic_final_half(self.ids[name])
+
+    def set_final_half(self, name, half):
+        self.engine.pic_set_final_half(self.ids[name], half)
+
+    def close(self):
+        self.engine.sync()
+        for df in self.frames.values():
+            self.engine.frame_free(df)
+        self.engine.close()
+
+
+def frame_stats(f):
+    """sample counts of one work list that the algorithmic byte model needs:
+    inter samples by number of reference lists, coded (residual) samples, intra samples."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import frame as F
+    p = f.p
+    nplanes = F.n_planes(p)
+    total = sum(F.plane_dims(p, c)[0] * F.plane_dims(p, c)[1] for c in range(nplanes))
+    chroma_factor = total / float(p.width * p.height)           # 1.5 for 4:2:0
+    st = dict(samples=total, luma=p.width * p.height, uni=0.0, bi=0.0, coded=0, intra=0, n_pu=int(f.n_pu),
+              n_tu=int(f.n_tu), n_intra=int(f.n_intra), n_levels=int(f.n_levels))
+    if f.n_pu:
+        pu = np.frombuffer(C.string_at(f.pu, int(f.n_pu) * C.sizeof(F.OhPu)), dtype=np.dtype(
+            [("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("r0", "u1"), ("r1", "u1"), ("mv", "<i2", (4,)), ("wp", "<u2"), ("rs", "<u2")]))
+        area = pu["w"].astype(np.int64) * pu["h"]
+        both = (pu["r0"] != F.OH_NO_REF) & (pu["r1"] != F.OH_NO_REF)
+        st["bi"] = float(area[both].sum()) * chroma_factor
+        st["uni"] = float(area[~both].sum()) * chroma_factor
+    if f.n_tu:
+        tu = np.frombuffer(C.string_at(f.tu, int(f.n_tu) * C.sizeof(F.OhTu)), dtype=np.dtype(
+            [("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("l2", "u1"), ("kind", "u1"), ("fl", "u1"), ("off", "<u4")]))
+        st["coded"] = int((1 << (2 * tu["l2"].astype(np.int64))).sum())
+    if f.n_intra:
+        it = np.frombuffer(C.string_at(f.intra, int(f.n_intra) * C.sizeof(F.OhIntra)), dtype=np.dtype(
+            [("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("l2", "u1"), ("mode", "u1"), ("av", "u1"), ("tu", "<u4")]))
+        st["intra"] = int((1 << (2 * it["l2"].astype(np.int64))).sum())
+    return st
+
+
+def algorithmic_bytes(stats, bytes_per_sample):
+    """per pass, the bytes an ideal implementation must move for this picture.
+       inter     (n_ref + 1)*b per inter-predicted sample (reference reads + prediction write)
+       residual  2 B per coded sample (int16 coefficients)
+       intra     b per intra sample (prediction write)
+       deblock   2b per sample over the V and H launches together (b per launch)
+       sao       2b per sample (read deblocked, write output)
+    Their sum is the survey's 2*f_c + (n_ref + 5)*b per sample."""
+    b = bytes_per_sample
+    return dict(inter=(2 * stats["uni"] + 3 * stats["bi"]) * b, residual=2.0 * stats["coded"], intra=stats["intra"] * b,
+                deblock_v=stats["samples"] * b, deblock_h=stats["samples"] * b, sao=2.0 * stats["samples"] * b)

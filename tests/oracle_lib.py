@@ -106,8 +106,7 @@ def oracle():
     global _oracle
     if _oracle is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
-        if not os.path.exists(path):
-            build_oracle()
+        build_oracle()                       # incremental: keeps the checker in step with include/*.h
         _oracle = _declare(C.CDLL(path), _ORACLE_SIGS)
     return _oracle
 
@@ -121,10 +120,10 @@ def ref():
     global _ref
     if _ref is None:
         path = os.path.join(ORACLE_DIR, "_ref", "libohevc_ref.so")
-        if not os.path.exists(path):
-            if not os.path.isdir(REF_TREE):
-                raise RuntimeError("reference tree not present; use tests/golden fixtures")
-            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+        if os.path.isdir(REF_TREE):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])      # incremental
+        elif not os.path.exists(path):
+            raise RuntimeError("reference tree not present; use tests/golden fixtures")
         _ref = _declare(C.CDLL(path), _REF_SIGS)
     return _ref
 

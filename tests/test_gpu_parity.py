@@ -1,0 +1,195 @@
+"""GPU parity (-m gpu): the HIP engine, called through its C ABI (libohevc_hip.so), must
+reproduce the CPU oracle bit for bit on the same seeded work lists, and the reference-recorded
+MD5s of tests/golden/."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from openhevc_amd import frame as F
+from oracle_lib import host_pic_array, oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from openhevc_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def run_both(eng, p, frame, pics):
+    """pics: {host id: HostPic}; returns (oracle result, engine result) for frame.cur_pic"""
+    from openhevc_amd.engine import remap_frame
+    ids = {}
+    for hid, hp in pics.items():
+        ids[hid] = eng.pic_alloc(p)
+        eng.pic_upload(ids[hid], hp)
+    try:
+        eng.frame_submit(remap_frame(frame, ids))
+        eng.sync()
+        got = eng.pic_download(ids[frame.cur_pic], p)
+    finally:
+        for v in ids.values():
+            eng.pic_free(v)
+    want_pics = {k: v.copy() for k, v in pics.items()}
+    assert oracle().oh_or_frame(C.byref(frame), host_pic_array(want_pics)) == 0
+    return want_pics[frame.cur_pic], got
+
+
+def assert_same(want, got, tag):
+    for c in range(len(want.planes)):
+        a, b = want.visible(c), got.visible(c)
+        if not np.array_equal(a, b):
+            ys, xs = np.nonzero(a != b)
+            raise AssertionError(f"{tag}: plane {c} differs at {len(ys)} samples, first (x={xs[0]}, y={ys[0]}): "
+                                 f"oracle {a[ys[0], xs[0]]} engine {b[ys[0], xs[0]]}")
+
+
+CASES = [
+    # name, w, h, bd, chroma, log2_ctb, slice_type, knobs
+    ("i8", 416, 240, 8, 1, 6, 0, {}),
+    ("p8", 416, 240, 8, 1, 6, 1, {}),
+    ("b8", 416, 240, 8, 1, 6, 2, {}),
+    ("b8_weighted", 416, 240, 8, 1, 6, 2, {"weighted_pct": 50}),
+    ("b8_ctb16", 200, 136, 8, 1, 4, 2, {"intra_pct": 30}),
+    ("i10", 264, 200, 10, 1, 5, 0, {}),
+    ("b10", 264, 200, 10, 1, 6, 2, {"weighted_pct": 25}),
+    ("b12", 136, 88, 12, 1, 5, 2, {}),
+    ("i8_444", 136, 88, 8, 3, 6, 0, {}),
+    ("b10_444", 136, 88, 10, 3, 5, 2, {}),
+    ("i8_mono", 128, 64, 8, 0, 6, 0, {}),
+    ("b8_tskip", 200, 136, 8, 1, 6, 2, {"tskip_pct": 40, "intra_pct": 30}),
+    ("b8_pcm_bypass", 264, 200, 8, 1, 6, 2, {"pcm_pct": 12, "bypass_pct": 12, "intra_pct": 30, "vary_deblock_offsets": 1}),
+    ("b10_pcm_bypass", 264, 200, 10, 1, 5, 2, {"pcm_pct": 12, "bypass_pct": 12, "intra_pct": 30}),
+    ("b8_farmv", 128, 72, 8, 1, 6, 2, {"mv_range": 2000, "skip_pct": 80}),
+    ("b8_dense", 416, 240, 8, 1, 6, 2, {"split_pct": 85, "cbf_pct": 95, "skip_pct": 0}),
+    ("tiny", 8, 8, 8, 1, 4, 0, {}),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_picture_parity(eng, case):
+    name, w, h, bd, chroma, lc, st, knobs = case
+    pcm = "pcm" in name
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
+                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm),
+                     cb_qp_offset=2 if "weighted" in name else 0, cr_qp_offset=-3 if "weighted" in name else 0)
+    rec = F.Recorder(p)
+    for seed in range(2):
+        f = rec.synth(F.synth_params(st, 3000 + seed, **knobs), 2, [0, 1])
+        rng = np.random.default_rng(seed)
+        pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}
+        want, got = run_both(eng, p, f, pics)
+        assert_same(want, got, f"{name} seed {seed}")
+    rec.close()
+
+
+@pytest.mark.parametrize("flavour", ["no_filters", "deblock_only", "sao_only"])
+def test_pass_switches(eng, flavour):
+    """each in-loop filter can be switched off per picture (slice_deblocking_filter_disabled /
+    sao disabled): the remaining passes still match"""
+    p = F.pic_params(264, 200, sao=int(flavour == "sao_only"), deblock=int(flavour == "deblock_only"))
+    rec = F.Recorder(p)
+    f = rec.synth(F.synth_params(2, 77), 2, [0, 1])
+    rng = np.random.default_rng(5)
+    pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}
+    want, got = run_both(eng, p, f, pics)
+    assert_same(want, got, flavour)
+    rec.close()
+
+
+def test_golden_pictures(eng):
+    """the engine reproduces MD5s whose in-loop filter stage was produced by the reference's own
+    ff_hevc_hls_filters driver (tests/golden/make_golden.py)"""
+    from test_golden import build_case, load_picture_cases, md5_planes
+    from openhevc_amd.engine import remap_frame
+    gold = load_picture_cases()
+    for case in gold["cases"]:
+        f, pics, rec = build_case(case)
+        p = f.p
+        ids = {k: eng.pic_alloc(p) for k in pics}
+        for k, hp in pics.items():
+            eng.pic_upload(ids[k], hp)
+        eng.frame_submit(remap_frame(f, ids))
+        got = eng.pic_download(ids[2], p)
+        for v in ids.values():
+            eng.pic_free(v)
+        assert md5_planes(got) == gold["expected"][case[0]]["final"], case[0]
+        rec.close()
+
+
+def test_reference_chain_and_reexecute(eng):
+    """a picture decoded by the engine is used as reference by the next one without leaving HBM;
+    executing an uploaded work list twice gives the same picture (coefficients are not consumed)"""
+    from openhevc_amd.engine import remap_frame
+    p = F.pic_params(416, 240)
+    rec = F.Recorder(p)
+    rng = np.random.default_rng(1)
+    host = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p), 2: F.HostPic(p), 3: F.HostPic(p)}
+    ids = {k: eng.pic_alloc(p) for k in host}
+    eng.pic_upload(ids[0], host[0])
+    arr = host_pic_array(host)
+    plan = [(1, 0, [0]), (2, 1, [0, 1]), (3, 2, [1, 2])]          # (cur, slice_type idx, refs): I? no: P, B, B chain
+    for cur, st, refs in plan:
+        f = rec.synth(F.synth_params(1 if len(refs) == 1 else 2, 500 + cur), cur, refs)
+        assert oracle().oh_or_frame(C.byref(f), arr) == 0
+        df = eng.frame_upload(remap_frame(f, ids))
+        eng.frame_execute(df)
+        first = eng.pic_download(ids[cur], p)
+        eng.frame_execute(df)
+        again = eng.pic_download(ids[cur], p)
+        eng.frame_free(df)
+        assert_same(host[cur], first, f"chain pic {cur}")
+        assert_same(first, again, f"re-execute pic {cur}")
+    for v in ids.values():
+        eng.pic_free(v)
+    rec.close()
+
+
+def test_1080p_b_and_i_pictures(eng):
+    """BASELINE config[1] geometry: 1920x1080 Main 8-bit 4:2:0 (1080 is not a CTB multiple)"""
+    p = F.pic_params(1920, 1080)
+    rec = F.Recorder(p)
+    rng = np.random.default_rng(9)
+    refs = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng)}
+    for st, seed in ((0, 1), (2, 2)):
+        f = rec.synth(F.synth_params(st, seed), 2, [0, 1])
+        pics = dict(refs)
+        pics[2] = F.HostPic(p)
+        want, got = run_both(eng, p, f, pics)
+        assert_same(want, got, f"1080p slice_type {st}")
+    rec.close()
+
+
+def test_malformed_work_lists_fail_on_the_host(eng):
+    from openhevc_amd.engine import EngineError, remap_frame
+    p = F.pic_params(128, 72)
+    rec = F.Recorder(p)
+    f = rec.synth(F.synth_params(2, 3), 2, [0, 1])
+    ids = {k: eng.pic_alloc(p) for k in (0, 1, 2)}
+    good = remap_frame(f, ids)
+    # reference slot pointing at a picture that does not exist
+    bad = remap_frame(f, ids)
+    bad.ref_pics[0] = 99
+    with pytest.raises(EngineError):
+        eng.frame_submit(bad)
+    # current picture used as its own reference
+    bad = remap_frame(f, ids)
+    bad.ref_pics[1] = ids[2]
+    with pytest.raises(EngineError):
+        eng.frame_submit(bad)
+    # coefficient pool shorter than the TUs claim
+    bad = remap_frame(f, ids)
+    bad.n_coeff = 8
+    with pytest.raises(EngineError):
+        eng.frame_submit(bad)
+    eng.frame_submit(good)
+    eng.sync()
+    for v in ids.values():
+        eng.pic_free(v)
+    rec.close()

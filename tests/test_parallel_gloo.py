@@ -1,0 +1,105 @@
+"""The N>1 path on CPU: two processes over gloo run the frame-parallel wave schedule
+(openhevc_amd/parallel.py) with the CPU checker as executor; every rank must end up with the same
+reference pictures as a single process that decodes ALL ranks' pictures itself."""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _digest(planes):
+    h = hashlib.md5()
+    for pl in planes:
+        h.update(np.ascontiguousarray(pl).tobytes())
+    return h.hexdigest()
+
+
+def _worker(rank, world, port, w, h, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from openhevc_amd import frame as F
+    from openhevc_amd import parallel as P
+    from oracle_backend import OracleBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = F.pic_params(w, h)
+    plan = P.make_step_plan(world, rank, n_waves=3, n_tail=2, seed=5)
+    be = OracleBackend(p, plan)
+    for _ in range(2):                                 # two steps: buffers are reused across steps
+        P.run_step(plan, be, dist)
+    res = {str(n): _digest(be.picture(n)) for n in be.store.names()}
+    torch.save(res, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process_expectation(world, w, h):
+    """one process plays every rank in turn (wave by wave), no collectives"""
+    sys.path.insert(0, HERE)
+    from openhevc_amd import frame as F
+    from openhevc_amd import parallel as P
+    from oracle_backend import OracleBackend
+    p = F.pic_params(w, h)
+    plans = [P.make_step_plan(world, r, n_waves=3, n_tail=2, seed=5) for r in range(world)]
+    backs = [OracleBackend(p, pl) for pl in plans]
+    for _ in range(2):
+        for wv in range(3):
+            for r in range(world):
+                backs[r].execute(plans[r].waves[wv].name)
+            for r in range(world):                     # replicate by plain copies
+                half = backs[r].final_half(plans[r].waves[wv].name)
+                for o in range(world):
+                    if o != r:
+                        backs[o].store.waves[wv][half][r].copy_(backs[r].store.waves[wv][half][r])
+                        backs[o].set_final_half(("ref", wv, r), half)
+        for r in range(world):
+            for pic in plans[r].tail:
+                backs[r].execute(pic.name)
+    return [{str(n): _digest(b.picture(n)) for n in b.store.names()} for b in backs]
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_gloo_match_single_process(tmp_path):
+    world, w, h = 2, 128, 72
+    out = str(tmp_path / "res")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    want = _single_process_expectation(world, w, h)
+    for r in range(world):
+        got = torch.load(f"{out}.{r}")
+        assert got == want[r], f"rank {r} pictures differ from the single-process decode"
+    # the exchanged reference pictures are identical on both ranks, the tails are rank-local
+    a, b = torch.load(f"{out}.0"), torch.load(f"{out}.1")
+    for k in a:
+        if k.startswith("('ref'"):
+            assert a[k] == b[k]
+
+
+def test_plan_is_balanced_and_cross_rank():
+    from openhevc_amd import parallel as P
+    for world in (1, 2, 4, 8):
+        plans = [P.make_step_plan(world, r) for r in range(world)]
+        assert len({P.pictures_per_step(p) for p in plans}) == 1          # weak scaling: same work per rank
+        if world > 1:
+            for p in plans:
+                assert any(ref[2] != p.rank for pic in p.waves[1:] for ref in pic.refs)   # needs another GPU's picture
+        for p in plans:
+            for pic in p.pictures():
+                for ref in pic.refs:
+                    assert ref[0] == "ref" and ref != pic.name

@@ -95,6 +95,9 @@ void *oh_engine_stream(OhEngine *e);
  * executed), for zero-copy exchange between GPUs; stride in samples */
 int oh_pic_device_planes(OhEngine *e, int pic_id, void *planes[3], int32_t stride[3], int32_t width[3], int32_t height[3]);
 
+/* diagnostics only: in-kernel cycle stamps of a -DOH_STAMPS build (tools/intra_stamps.py) */
+int oh_debug_read(OhEngine *e, uint64_t *out, size_t n_u64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,20 @@ struct DevTile {
     uint8_t  ox, oy, w, h;        /* offset inside the PU and size, luma samples             */
 };
 
+/* intra block as the kernel wants it: OhIntra with the TU index resolved to its residual offset */
+struct DevIntra {
+    uint16_t x, y;
+    uint8_t  c_idx, log2_size, mode, avail;
+    uint32_t res_off;             /* int16 offset into DevFrame.res, OH_NO_COEFF when cbf == 0  */
+};
+
+/* OhIntraCtu plus the span of the residual pool its blocks use (staged in LDS when it fits) */
+struct DevIntraCtu {
+    uint32_t sub_first;
+    uint16_t n_sub, ctu;
+    uint32_t res_lo, res_cnt;     /* int16 elements; res_cnt == 0: blocks read their residual from HBM */
+};
+
 struct DevFrame {
     OhPicParams pp;
     DevPlanes   cur;              /* reconstruction / deblock buffer of the current picture   */
@@ -32,8 +46,8 @@ struct DevFrame {
     const OhTu      *tu;
     const int16_t   *coeffs;
     int16_t         *res;             /* residual pool (deferred adds of intra blocks)        */
-    const OhIntra   *intra;
-    const OhIntraCtu *ictu;          /* CTUs with intra blocks in wavefront order             */
+    const DevIntra  *intra;
+    const DevIntraCtu *ictu;          /* CTUs with intra blocks in wavefront order             */
     const uint32_t  *sub_start;       /* sub-level ranges into intra[]                         */
     const uint8_t   *vbs, *hbs;
     const int8_t    *qp;
@@ -41,6 +55,7 @@ struct DevFrame {
     const OhDeblockCtb *db;
     const OhSaoCtb  *sao;             /* may be null                                          */
     uint32_t n_pu, n_tiles, n_tu, n_intra;
+    uint64_t *dbg;                    /* diagnostic builds only (OH_STAMPS), null otherwise       */
 };
 
 #endif

@@ -38,6 +38,7 @@ struct OhDevFrame {
     uint32_t   n_tiles = 0, n_tu = 0, n_intra = 0;
     bool       has_sao = false;
     std::vector<uint32_t> level_start;
+    std::vector<uint8_t>  level_staged;   /* 1: every CTU of the level has its residual span staged in LDS */
 };
 
 struct OhEngine {
@@ -51,6 +52,7 @@ struct OhEngine {
     double      pass_ms[OH_N_PASSES] = {};
     uint64_t    executes = 0;
     std::vector<OhDevFrame *> deferred;
+    uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
 };
 
 #define HIPCHK(e, call)                                                                           \
@@ -98,7 +100,25 @@ static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_e
         delete e;
         return OH_E_HIP;
     }
+    if (getenv("OHEVC_STAMPS")) {
+        const size_t bytes = (16 + 4000 * 16) * sizeof(uint64_t);
+        if (hipMalloc((void **)&e->dbg, bytes) == hipSuccess)
+            (void)hipMemset(e->dbg, 0, bytes);
+    }
     *out = e;
+    return OH_OK;
+}
+
+/* diagnostics: copies the in-kernel stamp records (see kernels.hip, OH_STAMPS) and clears them */
+extern "C" int oh_debug_read(OhEngine *e, uint64_t *out, size_t n_u64)
+{
+    if (!e || !e->dbg || !out)
+        return OH_E_ARG;
+    const size_t total = 16 + 4000 * 16;
+    if (n_u64 > total) n_u64 = total;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, e->dbg, n_u64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemset(e->dbg, 0, total * sizeof(uint64_t)));
     return OH_OK;
 }
 
@@ -483,8 +503,38 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_tiles = add(tiles.data(), tiles.size() * sizeof(DevTile));
     int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
     int s_tu = add(f->tu, (size_t)f->n_tu * sizeof(OhTu));
-    int s_intra = add(f->intra, (size_t)f->n_intra * sizeof(OhIntra));
-    int s_ictu = add(f->n_intra ? f->ictu : nullptr, f->n_intra ? (size_t)f->n_ictu * sizeof(OhIntraCtu) : 0);
+    std::vector<DevIntra> dintra(f->n_intra);
+    for (uint32_t i = 0; i < f->n_intra; i++) {
+        const OhIntra &it = f->intra[i];
+        DevIntra &d = dintra[i];
+        d.x = it.x; d.y = it.y; d.c_idx = it.c_idx; d.log2_size = it.log2_size; d.mode = it.mode; d.avail = it.avail;
+        d.res_off = it.tu == OH_NO_COEFF ? OH_NO_COEFF : f->tu[it.tu].coeff_off;
+    }
+    int s_intra = add(dintra.data(), dintra.size() * sizeof(DevIntra));
+    /* per CTU: span of the residual pool used by its intra blocks (the recorder appends TUs CTU by
+     * CTU, so the span is at most the CTU's sample count and fits the kernel's LDS buffer) */
+    std::vector<DevIntraCtu> dictu(f->n_intra ? f->n_ictu : 0);
+    for (size_t k = 0; k < dictu.size(); k++) {
+        const OhIntraCtu &c = f->ictu[k];
+        DevIntraCtu &d = dictu[k];
+        d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu;
+        uint64_t lo = UINT64_MAX, hi = 0;
+        for (uint32_t b = f->sub_start[c.sub_first]; b < f->sub_start[c.sub_first + c.n_sub]; b++) {
+            const DevIntra &it = dintra[b];
+            if (it.res_off == OH_NO_COEFF)
+                continue;
+            uint64_t e = (uint64_t)it.res_off + (1u << (2 * it.log2_size));
+            if (it.res_off < lo) lo = it.res_off;
+            if (e > hi) hi = e;
+        }
+        d.res_lo = 0; d.res_cnt = 0;
+        if (hi > lo && (lo & 3) == 0 && hi - lo <= 3u * 64 * 64) {
+            d.res_lo = (uint32_t)lo;
+            d.res_cnt = (uint32_t)((hi - lo + 3) & ~3ull);
+            if ((uint64_t)d.res_lo + d.res_cnt > f->n_coeff) d.res_cnt = (uint32_t)(hi - lo) & ~3u;
+        }
+    }
+    int s_ictu = add(dictu.data(), dictu.size() * sizeof(DevIntraCtu));
     int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
     int s_vbs = add(has_db ? f->vertical_bs : nullptr, has_db ? f->bs_size : 0);
     int s_hbs = add(has_db ? f->horizontal_bs : nullptr, has_db ? f->bs_size : 0);
@@ -517,8 +567,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.tu = (const OhTu *)(base + seg[s_tu].off);
     hd.coeffs = (const int16_t *)(base + seg[s_coef].off);
     hd.res = (int16_t *)(base + res_off);
-    hd.intra = (const OhIntra *)(base + seg[s_intra].off);
-    hd.ictu = (const OhIntraCtu *)(base + seg[s_ictu].off);
+    hd.intra = (const DevIntra *)(base + seg[s_intra].off);
+    hd.ictu = (const DevIntraCtu *)(base + seg[s_ictu].off);
     hd.sub_start = (const uint32_t *)(base + seg[s_sub].off);
     hd.vbs = (const uint8_t *)(base + seg[s_vbs].off);
     hd.hbs = (const uint8_t *)(base + seg[s_hbs].off);
@@ -527,6 +577,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.db = (const OhDeblockCtb *)(base + seg[s_db].off);
     hd.sao = has_sao ? (const OhSaoCtb *)(base + seg[s_sao].off) : nullptr;
     hd.n_pu = f->n_pu; hd.n_tiles = (uint32_t)tiles.size(); hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
+    hd.dbg = e->dbg;
     (void)s_hdr;
 
     /* stage everything in one host buffer -> one H2D copy */
@@ -550,8 +601,18 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     df->p = p;
     df->n_tiles = hd.n_tiles; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
     df->has_sao = has_sao;
-    if (f->n_intra)
+    if (f->n_intra) {
         df->level_start.assign(f->level_start, f->level_start + f->n_levels + 1);
+        df->level_staged.assign(f->n_levels, 1);
+        for (uint32_t l = 0; l < f->n_levels; l++)
+            for (uint32_t k = f->level_start[l]; k < f->level_start[l + 1]; k++) {
+                bool any_res = false;
+                for (uint32_t b = f->sub_start[dictu[k].sub_first]; b < f->sub_start[dictu[k].sub_first + dictu[k].n_sub] && !any_res; b++)
+                    any_res = dintra[b].res_off != OH_NO_COEFF;
+                if (any_res && !dictu[k].res_cnt)
+                    df->level_staged[l] = 0;
+            }
+    }
     cur->final_b = has_sao;
     *out = df;
     return OH_OK;
@@ -581,7 +642,7 @@ extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
     ohk_residual(df->d, &df->p, df->n_tu, st);
     MARK(OH_PASS_RESIDUAL);
     for (size_t l = 0; l + 1 < df->level_start.size(); l++)
-        ohk_intra_level(df->d, &df->p, df->level_start[l], df->level_start[l + 1] - df->level_start[l], st);
+        ohk_intra_level(df->d, &df->p, df->level_start[l], df->level_start[l + 1] - df->level_start[l], df->level_staged[l], st);
     MARK(OH_PASS_INTRA);
     if (df->p.deblock_enabled)
         ohk_deblock(df->d, &df->p, 0, st);

@@ -36,6 +36,27 @@ __constant__ int8_t  c_dst7[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 
 /* 32-point inverse DCT basis, filled by ohk_init() from the folded cosine table */
 __device__ int8_t g_dct[32][32];
 
+/* Pointers read out of DevFrame are generic to the compiler, which then emits flat_* accesses;
+ * those count on lgkmcnt as well as vmcnt, so every LDS wait would also wait for stores in flight.
+ * All of them point to HBM: say so. */
+#define GLOBAL __attribute__((address_space(1)))
+#define G_CONST(T, p) ((const GLOBAL T *)(p))
+#define G_MUT(T, p)   ((GLOBAL T *)(p))
+
+/* struct load from HBM (C++ cannot copy-construct from an address-space-qualified lvalue) */
+template <typename T>
+static __device__ __forceinline__ T gload(const T *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword-sized structs only");
+    T out;
+    const GLOBAL uint32_t *s = (const GLOBAL uint32_t *)p;
+    uint32_t *d = (uint32_t *)&out;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++)
+        d[i] = s[i];
+    return out;
+}
+
 static __device__ __forceinline__ int clip3(int v, int lo, int hi) { return min(max(v, lo), hi); }
 static __device__ __forceinline__ int clip_px(int v, int bd) { return min(max(v, 0), (1 << bd) - 1); }
 static __device__ __forceinline__ int clip16(int v) { return min(max(v, -32768), 32767); }
@@ -259,207 +280,334 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
  * pass 3: intra prediction as a CTU wavefront — hevcpred_template.c:30-538
  * (constrained_intra_pred_flag == 0), each block followed by its residual (transform_add).
  *
- * One workgroup reconstructs one CTU; its waves take the blocks of the current SUB-LEVEL (blocks
- * of one sub-level never read each other), a workgroup barrier separates sub-levels, so the
- * dependent chain inside a CTU costs barriers inside one CU instead of kernel launches.  CTUs of
- * one launch are mutually independent (same wavefront level, recorder.c).
- * L[] / T[] hold left[-1..2n-1] / top[-1..2n-1] at index i+1 (one set per wave).
+ * One workgroup reconstructs one CTU.  The CTU's samples (with the one-sample border above and
+ * to the left that intra_pred() gathers from, :164-183), the CTU's block list and the angle
+ * tables are staged in LDS once; the waves then take the blocks of the current SUB-LEVEL (blocks
+ * of one sub-level never read each other).  Per block a wave
+ *   - gathers left[]/top[] from the staged CTU, one element per lane, and substitutes missing
+ *     samples with wave-uniform lane reads (v_readlane) instead of the reference's serial fills,
+ *   - smooths with lane shuffles, publishes left[]/top[] in LDS once,
+ *   - predicts 4 consecutive samples per lane, adds the residual that was requested one
+ *     sub-level earlier, and writes LDS (for the next sub-level) and HBM (dword stores, async).
+ * Sub-levels are separated by an LDS-only workgroup barrier, so the dependent chain inside a CTU
+ * costs a handful of LDS round trips per block inside one CU — no kernel launch, no HBM round
+ * trip.  CTUs of one launch are mutually independent (same wavefront level, recorder.c).
  * ======================================================================================= */
 #define INTRA_WAVES 8
-struct IntraLds { int L[66], T[66], FL[66], FT[66], R[3 * 32 + 4]; };
+/* diagnostic build (-DOH_STAMPS, tools/intra_stamps.py): in-kernel cycle accounting of workgroup 0 */
+#ifdef OH_STAMPS
+#define STAMP(var) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; } while (0)
+#define ACC(slot, t0, t1) (acc[slot] += (t1) - (t0))
+#else
+#define STAMP(var) do { } while (0)
+#define ACC(slot, t0, t1) do { } while (0)
+#endif
+#define CTU_MAX 64
+#define CTU_RS (CTU_MAX + 4)                       /* LDS row stride: 3 pad + column -1 + 64 samples */
+#define MAX_CTU_BLOCKS 768                         /* 64x64 4:4:4 all 4x4 */
+#define RES_LDS_MAX (3 * CTU_MAX * CTU_MAX)        /* every sample of a 4:4:4 CTU coded */
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+struct IntraLds { int L[66], T[66]; };             /* left[-1..2n-1], top[-1..2n-1] at index i+1, per wave */
+struct __attribute__((aligned(16))) CtuLds {
+    uint16_t main[3][CTU_MAX * CTU_RS];            /* sample (x,y) of plane c at [y*rs + x + 4], rs = wc + 4 */
+    uint16_t top[3][2 * CTU_MAX + 8];              /* row -1: sample x at [x + 4]                             */
+    DevIntra items[MAX_CTU_BLOCKS];
+    uint32_t sub[MAX_CTU_BLOCKS + 2];
+    int      angle[33], inv_angle[15];
+    int16_t  res[RES_LDS_MAX];                     /* the CTU's residual blocks (engine.hip: DevIntraCtu.res_lo/res_cnt) */
+};
+struct IntraParams { int bd, chroma, log2_ctb, strong, no_smooth; };
 
-/* LDS hand-offs between lanes of ONE wave: DS operations of a wave execute in order, the fence
- * only stops the compiler from moving them */
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+/* workgroup barrier that waits for LDS traffic only (global stores of finished samples stay in flight) */
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <typename PX>
-static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const OhIntra it, IntraLds &s, const int lane)
+/* lane i <- lane i-1 (lane 0 keeps `fill`) / lane i <- lane i+1 (lane 63 keeps `fill`): GFX9 whole-wave DPP shifts */
+static __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+static __device__ __forceinline__ int wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+struct PlaneRegs { uint64_t base[3]; int stride[2], w[2], h[2]; };     /* wave-uniform (SGPRs): [0] luma, [1] chroma */
+
+template <typename PX, bool STAGED>
+static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const IntraParams pp, const PlaneRegs &pr,
+                                                   const uint32_t *__restrict__ item, IntraLds &s, CtuLds &ct, const int cx0, const int cy0,
+                                                   const uint32_t res_lo, const int lane, unsigned long long *acc)
 {
-    int *L = s.L, *T = s.T, *FL = s.FL, *FT = s.FT, *R = s.R;
-    const OhPicParams &pp = f->pp;
-    const int bd = pp.bit_depth, c = it.c_idx, log2 = it.log2_size, n = 1 << log2, mode = it.mode;
-    const int stride = f->cur.stride[c], pw = f->cur.w[c], ph = f->cur.h[c];
-    PX *__restrict__ src = (PX *)f->cur.p[c] + (size_t)it.y * stride + it.x;
-    bool a_bl = it.avail & OH_AV_BOTTOM_LEFT, a_l = it.avail & OH_AV_LEFT, a_ul = it.avail & OH_AV_UP_LEFT;
-    bool a_u = it.avail & OH_AV_UP, a_ur = it.avail & OH_AV_UP_RIGHT;
-    const int bl_size = max(min(it.y + 2 * n, ph) - (it.y + n), 0);     /* :111-114 */
-    const int tr_size = max(min(it.x + 2 * n, pw) - (it.x + n), 0);
+    unsigned long long ta = 0, tb = 0, tc = 0, td = 0; (void)ta; (void)tb; (void)tc; (void)td; (void)acc;
+    STAMP(ta);
+    /* the block descriptor is the same for every lane: keep it in scalar registers so that all the
+     * mode / availability decisions below are scalar branches */
+    const uint32_t w0 = __builtin_amdgcn_readfirstlane(item[0]), w1 = __builtin_amdgcn_readfirstlane(item[1]);
+    const uint32_t res_off = __builtin_amdgcn_readfirstlane(item[2]);
+    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, mode = (w1 >> 16) & 0xff, avail = w1 >> 24;
+    const int n = 1 << log2, bd = pp.bd;
+    const int stride = c ? pr.stride[1] : pr.stride[0], pw = c ? pr.w[1] : pr.w[0], ph = c ? pr.h[1] : pr.h[0];
+    const int hs = c && pp.chroma == 1;                     /* == vs: 4:2:2 is rejected by the engine */
+    const int rs = ((1 << pp.log2_ctb) >> hs) + 4;
+    const int lx = bx - (cx0 >> hs), ly = by - (cy0 >> hs);  /* position inside the CTU */
+    uint16_t *__restrict__ cm = ct.main[0] + c * (CTU_MAX * CTU_RS);
+    const uint16_t *__restrict__ trow = ly == 0 ? ct.top[0] + c * (2 * CTU_MAX + 8) + lx + 4 : cm + (ly - 1) * rs + lx + 4;   /* trow[i] = top[i] */
+    const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
+    const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
+    const int bl_size = max(min(by + 2 * n, ph) - (by + n), 0);         /* :111-114 */
+    const int tr_size = max(min(bx + 2 * n, pw) - (bx + n), 0);
     const int i = lane;                                                /* element this lane owns */
+    const int mid = 1 << (bd - 1);
+    const bool has_res = res_off != OH_NO_COEFF;
+    const int ngroups = (n * n) >> 2;
 
-    /* gather (:164-183) */
-    if (i < 2 * n) {
-        int tv = 0, lv = 0;
-        if (i < n) {
-            if (a_u) tv = src[-(ptrdiff_t)stride + i];
-            if (a_l) lv = src[(ptrdiff_t)i * stride - 1];
-        } else {
-            if (a_ur) tv = src[-(ptrdiff_t)stride + (i - n < tr_size ? i : n + tr_size - 1)];
-            if (a_bl) lv = src[(ptrdiff_t)(i - n < bl_size ? i : n + bl_size - 1) * stride - 1];
+    /* residual: requested now, consumed at the very end */
+    short4v rv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        rv[k] = short4v{ 0, 0, 0, 0 };
+        const int g = lane + 64 * k;
+        if (has_res && g < ngroups) {
+            if (STAGED) rv[k] = *(const short4v *)(ct.res + (res_off - res_lo) + 4 * g);
+            else        rv[k] = *((const GLOBAL short4v *)(f->res + res_off) + g);       /* slow path: dependent HBM load */
         }
-        T[i + 1] = tv; L[i + 1] = lv;
     }
-    if (lane == 0) { int cv = a_ul ? (int)src[-(ptrdiff_t)stride - 1] : 0; L[0] = cv; T[0] = cv; }
-    WSYNC();
 
-    /* substitution of unavailable samples (:251-286) */
-    if (!a_bl) {
-        if (a_l) {
-            int val = L[n];                              /* left[n-1] */
-            WSYNC();
-            if (i >= n && i < 2 * n) L[i + 1] = val;
-        } else if (a_ul) {
-            int val = L[0];
-            WSYNC();
-            if (i < 2 * n) L[i + 1] = val;
-            a_l = true;
-        } else if (a_u) {
-            int val = T[1];
-            WSYNC();
-            if (i < 2 * n) L[i + 1] = val;
-            if (lane == 0) L[0] = val;
-            a_ul = a_l = true;
-        } else if (a_ur) {
-            int val = T[n + 1];
-            WSYNC();
-            if (i < n) T[i + 1] = val;
-            if (i < 2 * n) L[i + 1] = val;
-            if (lane == 0) L[0] = val;
-            a_u = a_ul = a_l = true;
-        } else {
-            int val = 1 << (bd - 1);
-            if (i < 2 * n) { T[i + 1] = val; L[i + 1] = val; }
-            if (lane == 0) L[0] = val;
-        }
-        WSYNC();
+    /* gather (:164-183) from the staged CTU: lane i owns top[i] and left[i]; branch-free addresses */
+    int tv = 0, lv = 0, cv = 0;
+    {
+        const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
+        const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
+        const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
+        if (t_ok) tv = trow[ti];
+        if (l_ok) lv = cm[(ly + li) * rs + lx + 3];
+        if (a_ul) cv = trow[-1];
     }
-    if (!a_l) {
-        int val = L[n + 1];                              /* left[n] */
-        WSYNC();
-        if (i < n) L[i + 1] = val;
-        WSYNC();
+    /* substitution (:251-286) in closed form: the reference's cascaded fills only ever copy one of
+     * these wave-uniform values */
+    const int l_0 = __builtin_amdgcn_readlane(lv, 0), l_n1 = __builtin_amdgcn_readlane(lv, n - 1), l_n = __builtin_amdgcn_readlane(lv, n & 63);
+    const int t_0 = __builtin_amdgcn_readlane(tv, 0), t_n1 = __builtin_amdgcn_readlane(tv, n - 1), t_n = __builtin_amdgcn_readlane(tv, n & 63);
+    int corner, left_i, top_i;
+    if (a_bl || a_l) {
+        left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
+        corner = a_ul ? cv : (a_l ? l_0 : l_n);
+    } else {
+        corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : mid));
+        left_i = corner;
     }
-    if (!a_ul) {
-        if (lane == 0) L[0] = L[1];
-        WSYNC();
-    }
-    if (!a_u) {
-        int val = L[0];
-        WSYNC();
-        if (i < n) T[i + 1] = val;
-        WSYNC();
-    }
-    if (!a_ur) {
-        int val = T[n];                                  /* top[n-1] */
-        WSYNC();
-        if (i >= n && i < 2 * n) T[i + 1] = val;
-    }
-    if (lane == 0) T[0] = L[0];
-    WSYNC();
+    top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
 
-    /* smoothing (:288-326) */
-    const int *left = L + 1, *top = T + 1;
-    if (!pp.intra_smoothing_disabled && (c == 0 || pp.chroma_format_idc == 3) && mode != 1 && n != 4) {
-        int d26 = abs(mode - 26), d10 = abs(mode - 10);
-        int dist = min(d26, d10);
-        int thresh = log2 == 3 ? 7 : (log2 == 4 ? 1 : 0);
+    /* smoothing (:288-326) with whole-wave DPP shifts */
+    if (!pp.no_smooth && (c == 0 || pp.chroma == 3) && mode != 1 && n != 4) {
+        const int dist = min(abs(mode - 26), abs(mode - 10));
+        const int thresh = log2 == 3 ? 7 : (log2 == 4 ? 1 : 0);
         if (dist > thresh) {
             bool strong = false;
-            if (pp.strong_intra_smoothing && c == 0 && log2 == 5) {
-                int lim = 1 << (bd - 5);
-                strong = abs(top[-1] + top[63] - 2 * top[31]) < lim && abs(left[-1] + left[63] - 2 * left[31]) < lim;
+            int t63 = 0, l63 = 0;
+            if (pp.strong && c == 0 && log2 == 5) {
+                t63 = __builtin_amdgcn_readlane(top_i, 63); l63 = __builtin_amdgcn_readlane(left_i, 63);
+                const int t31 = __builtin_amdgcn_readlane(top_i, 31), l31 = __builtin_amdgcn_readlane(left_i, 31);
+                const int lim = 1 << (bd - 5);
+                strong = abs(corner + t63 - 2 * t31) < lim && abs(corner + l63 - 2 * l31) < lim;
             }
             if (strong) {
                 if (i < 63) {
-                    FT[i + 1] = ((63 - i) * top[-1] + (i + 1) * top[63] + 32) >> 6;
-                    FL[i + 1] = ((63 - i) * left[-1] + (i + 1) * left[63] + 32) >> 6;
-                } else {
-                    FT[64] = top[63]; FL[64] = left[63];
-                    FT[0] = top[-1]; FL[0] = left[-1];
+                    top_i  = ((63 - i) * corner + (i + 1) * t63 + 32) >> 6;
+                    left_i = ((63 - i) * corner + (i + 1) * l63 + 32) >> 6;
                 }
             } else {
+                const int lp = wave_shr1(left_i, corner), ln = wave_shl1(left_i, 0);
+                const int tp = wave_shr1(top_i, corner), tn = wave_shl1(top_i, 0);
+                const int l0v = __builtin_amdgcn_readlane(left_i, 0), t0v = __builtin_amdgcn_readlane(top_i, 0);
                 if (i < 2 * n - 1) {
-                    FL[i + 1] = (left[i + 1] + 2 * left[i] + left[i - 1] + 2) >> 2;
-                    FT[i + 1] = (top[i + 1] + 2 * top[i] + top[i - 1] + 2) >> 2;
-                } else if (i == 2 * n - 1) {
-                    FL[i + 1] = left[i]; FT[i + 1] = top[i];
+                    left_i = (ln + 2 * left_i + lp + 2) >> 2;
+                    top_i  = (tn + 2 * top_i + tp + 2) >> 2;
                 }
-                if (lane == 0) FT[0] = FL[0] = (left[0] + 2 * left[-1] + top[0] + 2) >> 2;
+                corner = (l0v + 2 * corner + t0v + 2) >> 2;
             }
-            left = FL + 1; top = FT + 1;
-            WSYNC();
         }
     }
+    /* publish the edges once: E[0..65] = left[-1..64), E[66..131] = top[-1..64) */
+    int *E = s.L;
+    if (i < 2 * n) { E[i + 1] = left_i; E[66 + i + 1] = top_i; }
+    if (lane == 0) { E[0] = corner; E[66] = corner; }
+    STAMP(tb);
+    WSYNC();
+    STAMP(tc);
 
-    /* prediction (:359-538): pixel idx = lane + 64*k -> (y = idx / n, x = idx % n) */
-    const int npx = n * n;
-    const int16_t *res = it.tu != OH_NO_COEFF ? f->res + f->tu[it.tu].coeff_off : nullptr;
+    /* prediction (:359-538): lane group g = lane + 64k owns samples 4g..4g+3 of the block (one row).
+     * All LDS reads of a group are issued before any of them is used. */
+    const int LB = 1, TB = 67;                            /* left[k] = E[LB + k], top[k] = E[TB + k] */
+    int dc = 0, angle = 0, inv_a = 0;
+    bool vertical = false;
     if (mode >= 2) {
-        const int angle = c_angle[mode - 2];
-        const bool vertical = mode >= 18;
-        const int *mainr = vertical ? top : left, *side = vertical ? left : top;
-        int *ref = R + 32;                                /* ref[k] == main[k-1] */
-        const int last = (n * angle) >> 5;
-        for (int k = lane; k <= 2 * n; k += 64) ref[k] = mainr[k - 1];
-        if (angle < 0 && last < -1) {
-            int inv = c_inv_angle[mode - 11];
-            int k = last + lane;
-            if (k <= -1) ref[k] = side[-1 + ((k * inv + 128) >> 8)];
-        }
-        WSYNC();
-        for (int idx = lane; idx < npx; idx += 64) {
-            int y = idx >> log2, x = idx & (n - 1);
-            int aa = vertical ? y : x, bb = vertical ? x : y;
-            int id = ((aa + 1) * angle) >> 5, fact = ((aa + 1) * angle) & 31;
-            int v = fact ? ((32 - fact) * ref[bb + id + 1] + fact * ref[bb + id + 2] + 16) >> 5 : ref[bb + id + 1];
-            if (c == 0 && n < 32) {                       /* :474-477, :501-508 */
-                if (mode == 26 && x == 0) v = clip_px(top[0] + ((left[y] - left[-1]) >> 1), bd);
-                if (mode == 10 && y == 0) v = clip_px(left[0] + ((top[x] - top[-1]) >> 1), bd);
-            }
-            if (res) v = clip_px(v + res[idx], bd);
-            src[(size_t)y * stride + x] = (PX)v;
-        }
-    } else if (mode == 0) {
-        for (int idx = lane; idx < npx; idx += 64) {
-            int y = idx >> log2, x = idx & (n - 1);
-            int v = ((n - 1 - x) * left[y] + (x + 1) * top[n] + (n - 1 - y) * top[x] + (y + 1) * left[n] + n) >> (log2 + 1);
-            if (res) v = clip_px(v + res[idx], bd);
-            src[(size_t)y * stride + x] = (PX)v;
-        }
-    } else {
-        int part = 0;
-        if (i < n) part = left[i] + top[i];
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
-        int dc = (__shfl(part, 0) + n) >> (log2 + 1);
-        for (int idx = lane; idx < npx; idx += 64) {
-            int y = idx >> log2, x = idx & (n - 1);
-            int v = dc;
-            if (c == 0 && n < 32) {                       /* :410-416 */
-                if (x == 0 && y == 0) v = (left[0] + 2 * dc + top[0] + 2) >> 2;
-                else if (y == 0)      v = (top[x] + 3 * dc + 2) >> 2;
-                else if (x == 0)      v = (left[y] + 3 * dc + 2) >> 2;
-            }
-            if (res) v = clip_px(v + res[idx], bd);
-            src[(size_t)y * stride + x] = (PX)v;
-        }
+        angle = ct.angle[mode - 2];
+        vertical = mode >= 18;
+        if (angle < 0 && ((n * angle) >> 5) < -1) inv_a = ct.inv_angle[mode - 11];
+    } else if (mode == 1) {
+        int part = i < n ? left_i + top_i : 0;
+        for (int m = 1; m < n; m <<= 1) part += __shfl_xor(part, m);
+        dc = (__builtin_amdgcn_readlane(part, 0) + n) >> (log2 + 1);
     }
-    WSYNC();                                              /* LDS is reused by this wave's next block */
+    const int MB = vertical ? TB : LB, SB = vertical ? LB : TB;       /* main / side reference arrays */
+    const bool edge_filter = c == 0 && n < 32;
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) + (size_t)by * stride + bx;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = lane + 64 * k;
+        if (g >= ngroups)
+            break;
+        const int y = (4 * g) >> log2, x0 = (4 * g) & (n - 1);
+        int v[4];
+        if (mode >= 2) {
+            int r0[4], r1[4], fact[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const int aa = vertical ? y : x, bb = vertical ? x : y;
+                const int id = ((aa + 1) * angle) >> 5;
+                fact[j] = ((aa + 1) * angle) & 31;
+                /* ref[k] == main[k-1] for k >= 0, the projected side sample for k < 0 (:447-453, :480-486) */
+                const int k0 = bb + id + 1, k1 = k0 + 1;
+                const int a0 = k0 >= 0 ? MB + k0 - 1 : SB - 1 + ((k0 * inv_a + 128) >> 8);
+                const int a1 = k1 >= 0 ? MB + k1 - 1 : SB - 1 + ((k1 * inv_a + 128) >> 8);
+                r0[j] = E[a0];
+                r1[j] = E[a1];
+            }
+            int e0 = 0, e1 = 0, e2 = 0;
+            int et[4] = { 0, 0, 0, 0 };
+            if (edge_filter && mode == 26) { e0 = E[TB]; e1 = E[LB + y]; e2 = E[LB - 1]; }
+            if (edge_filter && mode == 10) {
+                e0 = E[LB]; e2 = E[TB - 1];
+#pragma unroll
+                for (int j = 0; j < 4; j++) et[j] = E[TB + x0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int pv = fact[j] ? ((32 - fact[j]) * r0[j] + fact[j] * r1[j] + 16) >> 5 : r0[j];
+                if (edge_filter) {                        /* :474-477, :501-508 */
+                    if (mode == 26 && x0 + j == 0) pv = clip_px(e0 + ((e1 - e2) >> 1), bd);
+                    if (mode == 10 && y == 0)      pv = clip_px(e0 + ((et[j] - e2) >> 1), bd);
+                }
+                v[j] = pv;
+            }
+        } else {
+            const int ly_ = E[LB + y], tn_ = E[TB + n], ln_ = E[LB + n], l0_ = E[LB], t0_ = E[TB];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + x0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                int pv;
+                if (mode == 0) {
+                    pv = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - y) * tx[j] + (y + 1) * ln_ + n) >> (log2 + 1);
+                } else {
+                    pv = dc;
+                    if (edge_filter) {                    /* :410-416 */
+                        if (x == 0 && y == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
+                        else if (y == 0)      pv = (tx[j] + 3 * dc + 2) >> 2;
+                        else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
+                    }
+                }
+                v[j] = pv;
+            }
+        }
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[k][j], bd);
+        }
+        /* LDS copy for the next sub-level (8-byte aligned: lx, x0 are multiples of 4, data starts at +4) */
+        const uint2v pk16 = { (unsigned)(v[0] | (v[1] << 16)), (unsigned)(v[2] | (v[3] << 16)) };
+        *(uint2v *)(cm + (ly + y) * rs + lx + x0 + 4) = pk16;
+        if (sizeof(PX) == 1)
+            *(GLOBAL uint32_t *)(dst + (size_t)y * stride + x0) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        else
+            *(GLOBAL uint2v *)(dst + (size_t)y * stride + x0) = pk16;
+    }
+    WSYNC();                                              /* this wave's edge arrays are reused by its next block */
+    STAMP(td);
+    ACC(2, ta, tb); ACC(3, tb, tc); ACC(4, tc, td);
 }
 
-template <typename PX>
+template <typename PX, bool STAGED>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void intra_ctu_kernel(const DevFrame *__restrict__ f, uint32_t first_ctu)
 {
     __shared__ IntraLds lds[INTRA_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const OhIntraCtu ctu = f->ictu[first_ctu + blockIdx.x];
-    const uint32_t *__restrict__ ss = f->sub_start + ctu.sub_first;
-    for (int s = 0; s < ctu.n_sub; s++) {
-        const uint32_t b0 = ss[s], b1 = ss[s + 1];
-        for (uint32_t b = b0 + wave; b < b1; b += INTRA_WAVES)
-            intra_block<PX>(f, f->intra[b], lds[wave], lane);
-        /* workgroup barrier + workgroup-scope release/acquire of the global stores: the next
-         * sub-level reads the samples just written by other waves of this CU */
-        __syncthreads();
+    __shared__ CtuLds ct;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const DevIntraCtu ctu = gload(f->ictu + first_ctu + blockIdx.x);
+    const GLOBAL uint32_t *__restrict__ ss = G_CONST(uint32_t, f->sub_start) + ctu.sub_first;
+    const OhPicParams &pp = f->pp;
+    const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc;
+    const int cx0 = (ctu.ctu % ctbw) << lc, cy0 = (ctu.ctu / ctbw) << lc;      /* luma origin of the CTU */
+    const int n_sub = min((int)ctu.n_sub, MAX_CTU_BLOCKS);
+    const IntraParams ip = { pp.bit_depth, pp.chroma_format_idc, lc, pp.strong_intra_smoothing, pp.intra_smoothing_disabled };
+    PlaneRegs pr;
+    pr.base[0] = (uint64_t)f->cur.p[0]; pr.base[1] = (uint64_t)f->cur.p[1]; pr.base[2] = (uint64_t)f->cur.p[2];
+    pr.stride[0] = f->cur.stride[0]; pr.stride[1] = f->cur.stride[1];
+    pr.w[0] = f->cur.w[0]; pr.w[1] = f->cur.w[1]; pr.h[0] = f->cur.h[0]; pr.h[1] = f->cur.h[1];
+
+    /* stage: block list, sub-level table, angle tables */
+    const uint32_t item0 = ss[0], n_items = min(ss[n_sub] - item0, (uint32_t)MAX_CTU_BLOCKS);
+    {
+        const GLOBAL uint32_t *__restrict__ src = (const GLOBAL uint32_t *)(f->intra + item0);
+        uint32_t *dst = (uint32_t *)ct.items;
+        for (uint32_t e = tid; e < n_items * 3; e += 64 * INTRA_WAVES) dst[e] = src[e];
+        for (int e = tid; e <= n_sub; e += 64 * INTRA_WAVES) ct.sub[e] = ss[e] - item0;
+        if (tid < 33) ct.angle[tid] = c_angle[tid];
+        if (tid < 15) ct.inv_angle[tid] = c_inv_angle[tid];
+        /* the CTU's residual blocks: one coalesced sweep instead of a dependent load per block */
+        const GLOBAL short4v *__restrict__ rsrc = (const GLOBAL short4v *)(f->res + ctu.res_lo);
+        if (STAGED)
+            for (uint32_t e = tid; e < ctu.res_cnt / 4; e += 64 * INTRA_WAVES) ((short4v *)ct.res)[e] = rsrc[e];
     }
+    /* stage the CTU: samples already reconstructed by passes 1-2 (inter), the column left of it and
+     * the row above it (up to 2*wc samples: the up-right CTU) — all final by the wavefront order */
+    const int nplanes = pp.chroma_format_idc ? 3 : 1;
+    for (int c = 0; c < nplanes; c++) {
+        const int hs = hsh(pp, c), vs = vsh(pp, c);
+        const int wc = (1 << lc) >> hs, hc = (1 << lc) >> vs, rs = wc + 4, cols = wc + 1;
+        const int x0 = cx0 >> hs, y0 = cy0 >> vs, pw = f->cur.w[c], ph = f->cur.h[c], stride = f->cur.stride[c];
+        const GLOBAL PX *__restrict__ g = G_CONST(PX, f->cur.p[c]);
+        for (int e = tid; e < hc * cols; e += 64 * INTRA_WAVES) {
+            int yy = e / cols, xx = e - yy * cols - 1;
+            int gx = x0 + xx, gy = y0 + yy;
+            if (gx >= 0 && gx < pw && gy < ph)
+                ct.main[c][yy * rs + xx + 4] = g[(size_t)gy * stride + gx];
+        }
+        if (y0 > 0)
+            for (int e = tid; e < 2 * wc + 1; e += 64 * INTRA_WAVES) {
+                int gx = x0 + e - 1;
+                if (gx >= 0 && gx < pw)
+                    ct.top[c][e + 3] = g[(size_t)(y0 - 1) * stride + gx];
+            }
+    }
+    __syncthreads();
+    unsigned long long acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t0 = 0, t1 = 0, t2 = 0, tk = 0, rt1 = 0; (void)acc; (void)t0; (void)t1; (void)t2; (void)tk; (void)rt1;
+#ifdef OH_STAMPS
+    STAMP(tk);
+    rt1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    for (int s = 0; s < n_sub; s++) {
+        STAMP(t0);
+        const uint32_t b1 = ct.sub[s + 1];
+        for (uint32_t b = ct.sub[s] + wave; b < b1; b += INTRA_WAVES)
+            intra_block<PX, STAGED>(f, ip, pr, (const uint32_t *)&ct.items[b], lds[wave], ct, cx0, cy0, ctu.res_lo, lane, acc);
+        STAMP(t1);
+        LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
+        STAMP(t2);
+        ACC(0, t0, t1); ACC(1, t1, t2);
+    }
+#ifdef OH_STAMPS
+    if (f->dbg && blockIdx.x == 0 && wave == 0 && lane == 0) {
+        unsigned long long te; STAMP(te);
+        unsigned long long rt2 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long slot = atomicAdd((unsigned long long *)f->dbg, 1ull);
+        if (slot < 4000) {
+            unsigned long long *o = (unsigned long long *)f->dbg + 16 + slot * 16;
+            o[0] = n_sub; o[1] = te - tk; o[2] = rt2 - rt1; o[3] = acc[0]; o[4] = acc[1]; o[5] = acc[2]; o[6] = acc[3]; o[7] = acc[4];
+            o[8] = gridDim.x; o[9] = n_items; o[10] = tk; 
+        }
+    }
+#endif
 }
 
 /* =========================================================================================
@@ -740,10 +888,17 @@ extern "C" void ohk_residual(const DevFrame *df, const OhPicParams *p, uint32_t 
     LAUNCH_BY_DEPTH(p->bit_depth, residual_kernel, dim3(n_tu), dim3(64), st, df);
 }
 
-extern "C" void ohk_intra_level(const DevFrame *df, const OhPicParams *p, uint32_t first_ctu, uint32_t n_ctu, hipStream_t st)
+extern "C" void ohk_intra_level(const DevFrame *df, const OhPicParams *p, uint32_t first_ctu, uint32_t n_ctu, int staged, hipStream_t st)
 {
     if (!n_ctu) return;
-    LAUNCH_BY_DEPTH(p->bit_depth, intra_ctu_kernel, dim3(n_ctu), dim3(64 * INTRA_WAVES), st, df, first_ctu);
+    dim3 g(n_ctu), b(64 * INTRA_WAVES);
+    if (p->bit_depth == 8) {
+        if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, true>), g, b, 0, st, df, first_ctu);
+        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, false>), g, b, 0, st, df, first_ctu);
+    } else {
+        if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, true>), g, b, 0, st, df, first_ctu);
+        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, false>), g, b, 0, st, df, first_ctu);
+    }
 }
 
 extern "C" void ohk_deblock(const DevFrame *df, const OhPicParams *p, int horiz, hipStream_t st)

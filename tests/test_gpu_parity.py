@@ -193,3 +193,34 @@ def test_malformed_work_lists_fail_on_the_host(eng):
     for v in ids.values():
         eng.pic_free(v)
     rec.close()
+
+
+def test_unordered_coefficient_pool(eng):
+    """A work list whose coefficient blocks are NOT stored CTU by CTU (legal for the C ABI, never
+    produced by the recorder): the intra kernel cannot stage a CTU's residual span in LDS and takes
+    its slow path; results must not change."""
+    p = F.pic_params(416, 240)
+    rec = F.Recorder(p)
+    f = rec.synth(F.synth_params(0, 31, cbf_pct=80), 2, [0, 1])
+    n_tu = int(f.n_tu)
+    tus = [(f.tu[i].coeff_off, 1 << (2 * f.tu[i].log2_size)) for i in range(n_tu)]
+    src = np.ctypeslib.as_array(f.coeffs, shape=(int(f.n_coeff),)).copy()
+    perm = np.random.default_rng(4).permutation(n_tu)
+    dst = np.zeros_like(src)
+    new_tu = (F.OhTu * n_tu)()
+    C.memmove(new_tu, f.tu, C.sizeof(F.OhTu) * n_tu)
+    pos = 0
+    for i in perm:
+        off, n2 = tus[i]
+        dst[pos:pos + n2] = src[off:off + n2]
+        new_tu[i].coeff_off = pos
+        pos += n2
+    g = F.OhFrame()
+    C.memmove(C.byref(g), C.byref(f), C.sizeof(F.OhFrame))
+    g.tu = C.cast(new_tu, C.POINTER(F.OhTu))
+    g.coeffs = dst.ctypes.data_as(C.POINTER(C.c_int16))
+    rng = np.random.default_rng(0)
+    pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}
+    want, got = run_both(eng, p, g, pics)
+    assert_same(want, got, "unordered coefficient pool")
+    rec.close()

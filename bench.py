@@ -7,7 +7,9 @@
 One STEP is one wave-scheduled group of pictures per GPU (openhevc_amd/parallel.py): 1 I picture,
 3 reference B pictures and 12 non-reference B pictures of the workload's geometry, work lists
 already resident in HBM (uploaded before the timed region; the PCIe-inclusive rate is a separate
-figure in DESIGN.md).  With N GPUs every rank decodes its own 16 pictures per step and the four
+figure in DESIGN.md).  Steps are closed GOPs (they start with an I picture), so --chains of them are
+kept in flight per GPU, each on its own HIP stream: the GPU form of the reference's frame threads
+(pthread_frame.c).  With N GPUs every rank decodes its own 16 pictures per step and the four
 reference pictures of every rank are replicated with one RCCL all-gather per wave (weak scaling).
 Rank 0 prints ONE JSON line.
 """
@@ -21,11 +23,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: the configuration the metric is quoted on
-    "1080p_main8": dict(width=1920, height=1080, bit_depth=8, chroma_format_idc=1),
-    # configs[2] / configs[3] geometry (single GPU fits; used for profiling sweeps)
-    "2160p_main8": dict(width=3840, height=2160, bit_depth=8, chroma_format_idc=1),
+    # BASELINE.json `metric` is quoted on 4K Main10 (configs[3] geometry); it fits one GPU
     "2160p_main10": dict(width=3840, height=2160, bit_depth=10, chroma_format_idc=1),
+    # configs[1] / configs[2] geometries (parity-test and profiling cases)
+    "1080p_main8": dict(width=1920, height=1080, bit_depth=8, chroma_format_idc=1),
+    "2160p_main8": dict(width=3840, height=2160, bit_depth=8, chroma_format_idc=1),
     "480p_main8": dict(width=832, height=480, bit_depth=8, chroma_format_idc=1),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
@@ -59,12 +61,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="1080p_main8", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
+                    help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
+    ap.add_argument("--chains", type=int, default=16, help="closed GOPs (steps) in flight per GPU, one HIP stream each")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
     args = ap.parse_args()
+
+    # One HIP stream per chain only overlaps if the runtime maps them to distinct hardware queues
+    # (ROCm default: 4).  Must be set before the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.chains, 24))))
 
     import torch
     import torch.distributed as dist
@@ -88,9 +96,18 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     params = F.pic_params(**WORKLOADS[args.workload])
+    n_chains = max(1, args.chains)
+    chains = []                                            # (plan, backend, stream, process group)
+    for k in range(n_chains):
+        plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + k)
+        plan_k = P.make_step_plan(world, rank, **plan_kwargs)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):                    # the engine adopts the current stream
+            be_k = P.EngineBackend(torch, local_rank, params, plan_k)
+        group = dist.new_group() if world > 1 else None    # collectives of different chains must not share a communicator
+        chains.append((plan_k, be_k, stream, group))
+    plan, be = chains[0][0], chains[0][1]
     plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643)
-    plan = P.make_step_plan(world, rank, **plan_kwargs)
-    be = P.EngineBackend(torch, local_rank, params, plan)
     pics_per_step = P.pictures_per_step(plan)
 
     def barrier():
@@ -98,17 +115,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        P.run_step(plan, be, dist if world > 1 else None)
-    be.engine.pass_times(reset=True)
-    be.engine.profile(not args.no_profile)
+    def run(n_steps):
+        for i in range(n_steps):
+            plan_k, be_k, stream, group = chains[i % n_chains]
+            with torch.cuda.stream(stream):
+                P.run_step(plan_k, be_k, dist if world > 1 else None, group)
+
+    run(max(args.warmup, n_chains))
+    barrier()
+    for _, be_k, _, _ in chains:
+        be_k.engine.pass_times(reset=True)
+        be_k.engine.profile(not args.no_profile)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        P.run_step(plan, be, dist if world > 1 else None)
+    run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    be.engine.profile(False)
+    for _, be_k, _, _ in chains:
+        be_k.engine.profile(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -121,7 +145,11 @@ def main():
     out = None
     if rank == 0:
         b = 2 if params.bit_depth > 8 else 1
-        pass_ms, n_exec = be.engine.pass_times()
+        pass_ms, n_exec = None, 0
+        for _, be_k, _, _ in chains:                       # sum over the chains in flight
+            ms_k, n_k = be_k.engine.pass_times()
+            pass_ms = ms_k if pass_ms is None else {k: pass_ms[k] + ms_k[k] for k in ms_k}
+            n_exec += n_k
         roofline = None
         if n_exec:
             # algorithmic bytes of this rank's step, per pass (openhevc_amd/parallel.py)
@@ -158,12 +186,14 @@ def main():
             "dtype": "u8" if params.bit_depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "width": params.width, "height": params.height, "bit_depth": params.bit_depth,
                        "chroma_format_idc": params.chroma_format_idc, "pictures_per_step_per_gpu": pics_per_step,
-                       "step": f"1 I + {args.waves - 1} reference B + {args.tail} non-reference B pictures per GPU, one picture in flight per GPU",
+                       "step": f"1 I + {args.waves - 1} reference B + {args.tail} non-reference B pictures per GPU (a closed GOP)",
+                       "chains_in_flight_per_gpu": n_chains,
                        "exchange": "one RCCL all-gather of the finished reference pictures per wave" if world > 1 else "none (1 GPU)",
                        "generator": dict(knobs, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
             "roofline": roofline,
         }
-    be.close()
+    for _, be_k, _, _ in chains:
+        be_k.close()
     if rank == 0:
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:

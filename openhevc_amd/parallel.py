@@ -78,14 +78,15 @@ class Backend:
         raise NotImplementedError
 
 
-def run_step(plan: StepPlan, backend: Backend, dist=None):
-    """Enqueue one step.  dist: torch.distributed module (initialised) or None for world == 1."""
+def run_step(plan: StepPlan, backend: Backend, dist=None, group=None):
+    """Enqueue one step.  dist: torch.distributed module (initialised) or None for world == 1;
+    group: the process group this chain's collectives use (one group per chain in flight)."""
     for w, pic in enumerate(plan.waves):
         backend.execute(pic.name)
         if plan.world > 1:
             half = backend.final_half(pic.name)
             buf = backend.wave_tensor(w)[half]                    # [world][half_bytes], contiguous
-            dist.all_gather_into_tensor(buf.view(-1), buf[plan.rank])
+            dist.all_gather_into_tensor(buf.view(-1), buf[plan.rank], group=group)
             for r in range(plan.world):
                 if r != plan.rank:
                     backend.set_final_half(("ref", w, r), half)   # same SPS => same half on every rank

@@ -47,6 +47,11 @@ uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int ki
  * Computes the block's dependency level from the levels of the neighbours it reads. */
 int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu);
 
+/* two-step form for callers that learn the residual after the prediction (the table slots):
+ * record with tu = OH_NO_COEFF, then attach.  index = value of oh_rec_n_intra() before the record. */
+uint32_t oh_rec_n_intra(const OhRecorder *r);
+int oh_rec_intra_attach_tu(OhRecorder *r, uint32_t intra_index, uint32_t tu);
+
 /* side arrays the caller fills in place (sizes: oh_bs_size / oh_qp_tab_size / min_pu grid / CTBs) */
 uint8_t      *oh_rec_vertical_bs(OhRecorder *r);
 uint8_t      *oh_rec_horizontal_bs(OhRecorder *r);

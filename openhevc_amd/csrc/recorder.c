@@ -231,6 +231,17 @@ int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode
     return 0;
 }
 
+uint32_t oh_rec_n_intra(const OhRecorder *r) { return r->f.n_intra; }
+
+int oh_rec_intra_attach_tu(OhRecorder *r, uint32_t intra_index, uint32_t tu)
+{
+    if (intra_index >= r->f.n_intra || tu >= r->f.n_tu)
+        return -1;
+    r->intra[intra_index].tu = tu;
+    r->tu[tu].flags &= (uint8_t)~OH_TUF_ADD_NOW;
+    return 0;
+}
+
 uint8_t      *oh_rec_vertical_bs(OhRecorder *r)   { return r->vbs; }
 uint8_t      *oh_rec_horizontal_bs(OhRecorder *r) { return r->hbs; }
 int8_t       *oh_rec_qp_y_tab(OhRecorder *r)      { return r->qp; }

@@ -204,10 +204,21 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
     const int log2 = tu.log2_size, n = 1 << log2, n2 = n * n;
     const int16_t *__restrict__ cin = f->coeffs + tu.coeff_off;
 
-    for (int e = lane; e < n2; e += 64)
-        a[e] = cin[e];
-
+    /* load, and find the bounding box of the non-zero coefficients: dequantised blocks are sparse and
+     * concentrated in the low-frequency corner, and zero rows/columns contribute nothing (this is what
+     * the reference's col_limit argument exploits, hevc_cabac.c:1927-1934) */
+    __shared__ int bbox[2];
+    if (lane < 2) bbox[lane] = 0;
+    __syncthreads();
+    int my_r = 0, my_c = 0;
+    for (int e = lane; e < n2; e += 64) {
+        int16_t cv = cin[e];
+        a[e] = cv;
+        if (cv) { my_r = max(my_r, e >> log2); my_c = max(my_c, e & (n - 1)); }
+    }
     if (tu.kind == OH_TU_IDCT || tu.kind == OH_TU_DST4) {
+        if (my_r) atomicMax(&bbox[0], my_r);
+        if (my_c) atomicMax(&bbox[1], my_c);
         /* basis rows: every (32/n)-th row of the 32-point matrix, or the DST-VII matrix */
         const int step = 32 >> log2;
         for (int e = lane; e < n2; e += 64) {
@@ -215,11 +226,13 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
             m[e] = tu.kind == OH_TU_DST4 ? c_dst7[k][i] : g_dct[k * step][i];
         }
         __syncthreads();
+        const int nr = bbox[0] + 1, nc = bbox[1] + 1;   /* rows / columns that hold coefficients */
         for (int e = lane; e < n2; e += 64) {          /* pass 1: down the columns, shift 7 */
             int i = e >> log2, col = e & (n - 1);
             int acc = 0;
-            for (int k = 0; k < n; k++)
-                acc += m[k * n + i] * a[k * n + col];
+            if (col < nc)
+                for (int k = 0; k < nr; k++)
+                    acc += m[k * n + i] * a[k * n + col];
             b[i * n + col] = (int16_t)clip16((acc + 64) >> 7);
         }
         __syncthreads();
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
         for (int e = lane; e < n2; e += 64) {          /* pass 2: along the rows */
             int row = e >> log2, i = e & (n - 1);
             int acc = 0;
-            for (int k = 0; k < n; k++)
+            for (int k = 0; k < nc; k++)
                 acc += m[k * n + i] * b[row * n + k];
             a[e] = (int16_t)clip16((acc + add) >> shift);
         }
@@ -630,6 +643,29 @@ static __device__ __forceinline__ int get_pcm(const DevFrame *f, int x, int y)
     return f->is_pcm ? f->is_pcm[(y >> l) * mpw + (x >> l)] : 0;
 }
 
+/* four consecutive samples as one 4-byte (8 bit) or 8-byte (>8 bit) access */
+template <typename PX>
+static __device__ __forceinline__ void load4(const GLOBAL PX *p, int v[4])
+{
+    if (sizeof(PX) == 1) {
+        unsigned r = *(const GLOBAL unsigned *)p;
+        v[0] = r & 0xff; v[1] = (r >> 8) & 0xff; v[2] = (r >> 16) & 0xff; v[3] = r >> 24;
+    } else {
+        uint2v r = *(const GLOBAL uint2v *)p;
+        v[0] = r[0] & 0xffff; v[1] = r[0] >> 16; v[2] = r[1] & 0xffff; v[3] = r[1] >> 16;
+    }
+}
+template <typename PX>
+static __device__ __forceinline__ void store4(GLOBAL PX *p, int a, int b, int c, int d)
+{
+    if (sizeof(PX) == 1) {
+        *(GLOBAL unsigned *)p = (unsigned)(a | (b << 8) | (c << 16) | (d << 24));
+    } else {
+        uint2v r = { (unsigned)(a | (b << 16)), (unsigned)(c | (d << 16)) };
+        *(GLOBAL uint2v *)p = r;
+    }
+}
+
 template <typename PX, int HORIZ>       /* HORIZ = 1: horizontal edges (filter across y) */
 __global__ __launch_bounds__(256) void deblock_luma_kernel(const DevFrame *__restrict__ f)
 {
@@ -667,17 +703,34 @@ __global__ __launch_bounds__(256) void deblock_luma_kernel(const DevFrame *__res
         no_q = get_pcm(f, x, y);
     }
     const int stride = f->cur.stride[0];
-    PX *pix = (PX *)f->cur.p[0] + (size_t)y * stride + x;
-    const ptrdiff_t xs = HORIZ ? stride : 1, ys = HORIZ ? 1 : stride;
+    GLOBAL PX *pix = G_MUT(PX, f->cur.p[0]) + (size_t)y * stride + x;
 
-    int P[4][4], Q[4][4];                                  /* [line][distance from the edge] */
+    /* [line][distance from the edge]; vertical edges: a line is one row (8 contiguous samples),
+     * horizontal edges: a line is one column, the lane's 4 columns are contiguous in every row */
+    int P[4][4], Q[4][4];
+    if (!HORIZ) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            int t[4];
+            load4<PX>(pix + (size_t)d * stride - 4, t);
+            P[d][3] = t[0]; P[d][2] = t[1]; P[d][1] = t[2]; P[d][0] = t[3];
+            load4<PX>(pix + (size_t)d * stride, Q[d]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int t[4];
+            load4<PX>(pix - (size_t)(k + 1) * stride, t);
+            P[0][k] = t[0]; P[1][k] = t[1]; P[2][k] = t[2]; P[3][k] = t[3];
+            load4<PX>(pix + (size_t)k * stride, t);
+            Q[0][k] = t[0]; Q[1][k] = t[1]; Q[2][k] = t[2]; Q[3][k] = t[3];
+        }
+    }
+    int NP[4][3], NQ[4][3];                                /* filtered samples, distance 0..2 */
 #pragma unroll
     for (int d = 0; d < 4; d++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            P[d][k] = pix[d * ys - (k + 1) * xs];
-            Q[d][k] = pix[d * ys + k * xs];
-        }
+        for (int k = 0; k < 3; k++) { NP[d][k] = P[d][k]; NQ[d][k] = Q[d][k]; }
     const int dp0 = abs(P[0][2] - 2 * P[0][1] + P[0][0]), dq0 = abs(Q[0][2] - 2 * Q[0][1] + Q[0][0]);
     const int dp3 = abs(P[3][2] - 2 * P[3][1] + P[3][0]), dq3 = abs(Q[3][2] - 2 * Q[3][1] + Q[3][0]);
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
@@ -695,14 +748,14 @@ __global__ __launch_bounds__(256) void deblock_luma_kernel(const DevFrame *__res
             int p3 = P[d][3], p2 = P[d][2], p1 = P[d][1], p0 = P[d][0];
             int q0 = Q[d][0], q1 = Q[d][1], q2 = Q[d][2], q3 = Q[d][3];
             if (!no_p) {
-                pix[d * ys - 1 * xs] = (PX)(p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -tc2, tc2));
-                pix[d * ys - 2 * xs] = (PX)(p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -tc2, tc2));
-                pix[d * ys - 3 * xs] = (PX)(p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -tc2, tc2));
+                NP[d][0] = p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -tc2, tc2);
+                NP[d][1] = p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -tc2, tc2);
+                NP[d][2] = p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -tc2, tc2);
             }
             if (!no_q) {
-                pix[d * ys + 0 * xs] = (PX)(q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -tc2, tc2));
-                pix[d * ys + 1 * xs] = (PX)(q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -tc2, tc2));
-                pix[d * ys + 2 * xs] = (PX)(q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -tc2, tc2));
+                NQ[d][0] = q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -tc2, tc2);
+                NQ[d][1] = q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -tc2, tc2);
+                NQ[d][2] = q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -tc2, tc2);
             }
         }
     } else {
@@ -715,10 +768,25 @@ __global__ __launch_bounds__(256) void deblock_luma_kernel(const DevFrame *__res
             if (abs(delta) >= 10 * tc)
                 continue;
             delta = clip3(delta, -tc, tc);
-            if (!no_p) pix[d * ys - xs] = (PX)clip_px(p0 + delta, bd);
-            if (!no_q) pix[d * ys]      = (PX)clip_px(q0 - delta, bd);
-            if (!no_p && nd_p) pix[d * ys - 2 * xs] = (PX)clip_px(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2), bd);
-            if (!no_q && nd_q) pix[d * ys + xs]     = (PX)clip_px(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2), bd);
+            if (!no_p) NP[d][0] = clip_px(p0 + delta, bd);
+            if (!no_q) NQ[d][0] = clip_px(q0 - delta, bd);
+            if (!no_p && nd_p) NP[d][1] = clip_px(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2), bd);
+            if (!no_q && nd_q) NQ[d][1] = clip_px(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2), bd);
+        }
+    }
+    /* write back whole 4-sample groups; the untouched outer samples (distance 3) are rewritten with
+     * their own values, which no other segment of this pass modifies */
+    if (!HORIZ) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            store4<PX>(pix + (size_t)d * stride - 4, P[d][3], NP[d][2], NP[d][1], NP[d][0]);
+            store4<PX>(pix + (size_t)d * stride, NQ[d][0], NQ[d][1], NQ[d][2], Q[d][3]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            store4<PX>(pix - (size_t)(k + 1) * stride, NP[0][k], NP[1][k], NP[2][k], NP[3][k]);
+            store4<PX>(pix + (size_t)k * stride, NQ[0][k], NQ[1][k], NQ[2][k], NQ[3][k]);
         }
     }
 }
@@ -767,70 +835,169 @@ __global__ __launch_bounds__(256) void deblock_chroma_kernel(const DevFrame *__r
         no_q = get_pcm(f, x, y);
     }
     const int stride = f->cur.stride[c];
-    PX *pix = (PX *)f->cur.p[c] + (size_t)(y >> vs) * stride + (x >> hs);
-    const ptrdiff_t xs = HORIZ ? stride : 1, ys = HORIZ ? 1 : stride;
+    GLOBAL PX *pix = G_MUT(PX, f->cur.p[c]) + (size_t)(y >> vs) * stride + (x >> hs);
+    if (!HORIZ) {                                          /* a line is one row: p3..p0 | q0..q3 contiguous */
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        int p1 = pix[d * ys - 2 * xs], p0 = pix[d * ys - xs], q0 = pix[d * ys], q1 = pix[d * ys + xs];
-        int delta = clip3((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
-        if (!no_p) pix[d * ys - xs] = (PX)clip_px(p0 + delta, bd);
-        if (!no_q) pix[d * ys]      = (PX)clip_px(q0 - delta, bd);
+        for (int d = 0; d < 4; d++) {
+            int p[4], q[4];
+            load4<PX>(pix + (size_t)d * stride - 4, p);
+            load4<PX>(pix + (size_t)d * stride, q);
+            int delta = clip3((((q[0] - p[3]) * 4) + p[2] - q[1] + 4) >> 3, -tc, tc);
+            if (!no_p) p[3] = clip_px(p[3] + delta, bd);
+            if (!no_q) q[0] = clip_px(q[0] - delta, bd);
+            store4<PX>(pix + (size_t)d * stride - 4, p[0], p[1], p[2], p[3]);
+            store4<PX>(pix + (size_t)d * stride, q[0], q[1], q[2], q[3]);
+        }
+    } else {                                               /* the lane's 4 columns are contiguous in every row */
+        int p1[4], p0[4], q0[4], q1[4];
+        load4<PX>(pix - 2 * (size_t)stride, p1);
+        load4<PX>(pix - (size_t)stride, p0);
+        load4<PX>(pix, q0);
+        load4<PX>(pix + (size_t)stride, q1);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            int delta = clip3((((q0[d] - p0[d]) * 4) + p1[d] - q1[d] + 4) >> 3, -tc, tc);
+            if (!no_p) p0[d] = clip_px(p0[d] + delta, bd);
+            if (!no_q) q0[d] = clip_px(q0[d] - delta, bd);
+        }
+        store4<PX>(pix - (size_t)stride, p0[0], p0[1], p0[2], p0[3]);
+        store4<PX>(pix, q0[0], q0[1], q0[2], q0[3]);
     }
 }
 
 /* =========================================================================================
  * pass 5: SAO — hevcdsp_template.c:340-567 driven per CTB by sao_filter_CTB (hevc_filter.c:197-322),
  * here one whole-picture pass from the deblocked planes (cur) into the output planes (out).
+ * One lane owns 8 consecutive samples of a row (8- or 16-byte accesses); a group never straddles a
+ * CTB (CTB widths are multiples of 8 samples in every plane).  Rows are 256-byte aligned and padded,
+ * so whole-vector accesses past the picture width stay inside the row.
  * ======================================================================================= */
+template <typename PX> struct Vec8;
+template <> struct Vec8<uint8_t>  { typedef unsigned int  T __attribute__((ext_vector_type(2))); };
+template <> struct Vec8<uint16_t> { typedef unsigned int  T __attribute__((ext_vector_type(4))); };
+
+template <typename PX>
+static __device__ __forceinline__ void load8(const GLOBAL PX *p, int v[8])
+{
+    typename Vec8<PX>::T r = *(const GLOBAL typename Vec8<PX>::T *)p;
+    if (sizeof(PX) == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (r[j >> 2] >> (8 * (j & 3))) & 0xff;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (r[j >> 1] >> (16 * (j & 1))) & 0xffff;
+    }
+}
+template <typename PX>
+static __device__ __forceinline__ void store8(GLOBAL PX *p, const int v[8])
+{
+    typename Vec8<PX>::T r;
+    if (sizeof(PX) == 1) {
+        r[0] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        r[1] = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = v[2 * j] | (v[2 * j + 1] << 16);
+    }
+    *(GLOBAL typename Vec8<PX>::T *)p = r;
+}
+
+struct SaoEdgeCtx { int x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd; };
+
+/* first neighbour a = (x+DX, y+DY), second b = (x-DX, y-DY) (pos[][] of hevcdsp_template.c:379-384) */
+template <typename PX, int DX, int DY>
+static __device__ __forceinline__ void sao_edge8(const GLOBAL PX *__restrict__ src, const SaoEdgeCtx &e, const int off[5], const int v[8], int r[8])
+{
+    int a[10], b[10];                                       /* samples x-1..x+8 of rows y+DY and y-DY */
+    const int ya = min(max(e.y + DY, 0), e.ph - 1), yb = min(max(e.y - DY, 0), e.ph - 1);
+    load8<PX>(src + (size_t)ya * e.sstride + e.x, a + 1);
+    load8<PX>(src + (size_t)yb * e.sstride + e.x, b + 1);
+    a[0] = b[0] = a[9] = b[9] = 0;
+    if (DX != 0) {
+        if (e.x > 0)        { a[0] = src[(size_t)ya * e.sstride + e.x - 1]; b[0] = src[(size_t)yb * e.sstride + e.x - 1]; }
+        if (e.x + 8 < e.pw) { a[9] = src[(size_t)ya * e.sstride + e.x + 8]; b[9] = src[(size_t)yb * e.sstride + e.x + 8]; }
+    }
+    const int ly = e.y - e.y0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int lx = e.x + j - e.x0;
+        bool keep = e.x + j >= e.pw;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int nx = lx + (k ? -DX : DX), ny = ly + (k ? -DY : DY);
+            const int rx = nx < 0 ? -1 : (nx >= e.w ? 1 : 0), ry = ny < 0 ? -1 : (ny >= e.h ? 1 : 0);
+            if ((rx < 0 && e.cx == 0) || (rx > 0 && e.cx == e.ctbw - 1) || (ry < 0 && e.cy == 0) || (ry > 0 && e.cy == e.ctbh - 1))
+                keep = true;
+            else if (e.flags && (rx || ry)) {
+                int bit;
+                if (rx && ry) bit = 4 + (ry < 0 ? (rx < 0 ? 0 : 1) : (rx > 0 ? 2 : 3));
+                else if (rx)  bit = rx > 0 ? 1 : 0;
+                else          bit = ry > 0 ? 3 : 2;
+                keep = keep || ((e.flags >> bit) & 1);
+            }
+        }
+        if (!keep) {
+            const int na = a[1 + j + DX], nb = b[1 + j - DX];
+            const int sum = (v[j] > na) - (v[j] < na) + (v[j] > nb) - (v[j] < nb);
+            const int o = sum == 0 ? off[0] : (sum == -2 ? off[1] : (sum == -1 ? off[2] : (sum == 1 ? off[3] : off[4])));
+            r[j] = clip_px(v[j] + o, e.bd);
+        }
+    }
+}
+
+/* Lane -> sample mapping: a wave covers ONE CTB-wide strip (wc samples x 512/wc rows) so that the
+ * SAO type / class is the same for all its lanes (no divergent band/edge paths); a workgroup of
+ * 4 waves covers 4 such strips stacked vertically.  grid = (CTB columns, strips of rows, planes). */
 template <typename PX>
 __global__ __launch_bounds__(256) void sao_kernel(const DevFrame *__restrict__ f)
 {
     const OhPicParams &pp = f->pp;
     const int c = blockIdx.z;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     const int pw = f->cur.w[c], ph = f->cur.h[c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int log2_gx = pp.log2_ctb_size - hsh(pp, c) - 3;            /* 8-sample groups per CTB row: 1 << log2_gx */
+    const int rows_per_wave = 64 >> log2_gx;
+    const int x = (blockIdx.x << (log2_gx + 3)) + ((lane & ((1 << log2_gx) - 1)) << 3);
+    const int y = (blockIdx.y * 4 + wave) * rows_per_wave + (lane >> log2_gx);
     if (x >= pw || y >= ph)
         return;
     const int bd = pp.bit_depth, hs = hsh(pp, c), vs = vsh(pp, c), lc = pp.log2_ctb_size;
     const int ctbw = (pp.width + (1 << lc) - 1) >> lc, ctbh = (pp.height + (1 << lc) - 1) >> lc;
     const int sstride = f->cur.stride[c];
-    const PX *__restrict__ src = (const PX *)f->cur.p[c];
-    PX *__restrict__ dst = (PX *)f->out.p[c];
+    const GLOBAL PX *__restrict__ src = G_CONST(PX, f->cur.p[c]);
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, f->out.p[c]) + (size_t)y * f->out.stride[c] + x;
     const int cx = (x << hs) >> lc, cy = (y << vs) >> lc;
-    const OhSaoCtb *s = &f->sao[cy * ctbw + cx];
+    const GLOBAL OhSaoCtb *s = G_CONST(OhSaoCtb, f->sao) + cy * ctbw + cx;
     const int type = s->type_idx[c];
-    const int v = src[(size_t)y * sstride + x];
-    int r = v;
+    int v[8], r[8];
+    load8<PX>(src + (size_t)y * sstride + x, v);
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = v[j];
     if (type == 1) {                                        /* band, :340-365 */
-        int k = ((v >> (bd - 5)) - s->band_position[c]) & 31;
-        if (k < 4) r = clip_px(v + s->offset_val[c][k + 1], bd);
+        const int bp = s->band_position[c];
+        int off[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) off[k] = s->offset_val[c][k + 1];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int k = ((v[j] >> (bd - 5)) - bp) & 31;
+            int o = k == 0 ? off[0] : (k == 1 ? off[1] : (k == 2 ? off[2] : off[3]));
+            if (k < 4) r[j] = clip_px(v[j] + o, bd);
+        }
     } else if (type == 2) {                                 /* edge, :372-567 (per-sample form) */
         const int eo = s->eo_class[c];
         const int x0 = (cx << lc) >> hs, y0 = (cy << lc) >> vs;
         const int w = min((1 << lc) >> hs, pw - x0), h = min((1 << lc) >> vs, ph - y0);
-        const int lx = x - x0, ly = y - y0;
-        const int dx0 = eo == 1 ? 0 : (eo == 3 ? 1 : -1), dy0 = eo == 0 ? 0 : -1;
         const int flags = s->edge_flags;
-        bool keep = false;
+        int off[5];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            int nx = lx + (k ? -dx0 : dx0), ny = ly + (k ? -dy0 : dy0);
-            int rx = nx < 0 ? -1 : (nx >= w ? 1 : 0), ry = ny < 0 ? -1 : (ny >= h ? 1 : 0);
-            if ((rx < 0 && cx == 0) || (rx > 0 && cx == ctbw - 1) || (ry < 0 && cy == 0) || (ry > 0 && cy == ctbh - 1))
-                keep = true;
-            else if (flags && (rx || ry)) {
-                int bit;
-                if (rx && ry) bit = 4 + (ry < 0 ? (rx < 0 ? 0 : 1) : (rx > 0 ? 2 : 3));
-                else if (rx)  bit = rx > 0 ? 1 : 0;
-                else          bit = ry > 0 ? 3 : 2;
-                keep = keep || ((flags >> bit) & 1);
-            }
-        }
-        if (!keep) {
-            int a = src[(size_t)(y + dy0) * sstride + x + dx0], b = src[(size_t)(y - dy0) * sstride + x - dx0];
-            int sum = (v > a) - (v < a) + (v > b) - (v < b);
-            int cat = sum == 0 ? 0 : (sum == -2 ? 1 : (sum == -1 ? 2 : (sum == 1 ? 3 : 4)));
-            r = clip_px(v + s->offset_val[c][cat], bd);
+        for (int k = 0; k < 5; k++) off[k] = s->offset_val[c][k];
+        const SaoEdgeCtx ec = { x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd };
+        switch (eo) {                                       /* compile-time neighbour offsets: no indexed registers */
+        case 0:  sao_edge8<PX, -1, 0>(src, ec, off, v, r); break;
+        case 1:  sao_edge8<PX, 0, -1>(src, ec, off, v, r); break;
+        case 2:  sao_edge8<PX, -1, -1>(src, ec, off, v, r); break;
+        default: sao_edge8<PX, 1, -1>(src, ec, off, v, r); break;
         }
     }
     if (type && f->is_pcm && (pp.transquant_bypass_enable || pp.pcm_loop_filter_disable)) {
@@ -840,16 +1007,20 @@ __global__ __launch_bounds__(256) void sao_kernel(const DevFrame *__restrict__ f
         const int l = pp.log2_min_pu_size, mpw = pp.width >> l;
         const int X0 = cx << lc, Y0 = cy << lc;
         const int wc = min((1 << lc) >> hs, pw - (X0 >> hs)), hc = min((1 << lc) >> vs, ph - (Y0 >> vs));
-        const int px = (x << hs) >> l, py = (y << vs) >> l;
-        if (px >= (X0 >> l) && px < ((X0 + wc) >> l) && py >= (Y0 >> l) && py < ((Y0 + hc) >> l) &&
-            f->is_pcm[py * mpw + px]) {
-            int sx = (px << l) >> hs;
-            int len_samples = ((1 << l) >> hs) / (int)sizeof(PX);
-            if (x - sx < len_samples)
-                r = v;
+        const int py = (y << vs) >> l;
+        const GLOBAL uint8_t *pcm = G_CONST(uint8_t, f->is_pcm);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int px = ((x + j) << hs) >> l;
+            if (px >= (X0 >> l) && px < ((X0 + wc) >> l) && py >= (Y0 >> l) && py < ((Y0 + hc) >> l) && pcm[py * mpw + px]) {
+                int sx = (px << l) >> hs;
+                int len_samples = ((1 << l) >> hs) / (int)sizeof(PX);
+                if (x + j - sx < len_samples)
+                    r[j] = v[j];
+            }
         }
     }
-    dst[(size_t)y * f->out.stride[c] + x] = (PX)r;
+    store8<PX>(dst, r);
 }
 
 /* =========================================================================================
@@ -928,6 +1099,9 @@ extern "C" void ohk_deblock(const DevFrame *df, const OhPicParams *p, int horiz,
 
 extern "C" void ohk_sao(const DevFrame *df, const OhPicParams *p, hipStream_t st)
 {
-    dim3 grid((p->width + 255) / 256, p->height, p->chroma_format_idc ? 3 : 1);
+    /* luma geometry decides the grid; chroma planes (smaller) leave their surplus workgroups idle */
+    const int ctbw = (p->width + (1 << p->log2_ctb_size) - 1) >> p->log2_ctb_size;
+    const int rows_per_block = 4 * (64 >> (p->log2_ctb_size - 3));            /* luma: 4 waves x (512 / ctb) rows */
+    dim3 grid(ctbw, (p->height + rows_per_block - 1) / rows_per_block, p->chroma_format_idc ? 3 : 1);
     LAUNCH_BY_DEPTH(p->bit_depth, sao_kernel, grid, dim3(256), st, df);
 }

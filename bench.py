@@ -125,14 +125,26 @@ def main():
     barrier()
     for _, be_k, _, _ in chains:
         be_k.engine.pass_times(reset=True)
-        be_k.engine.profile(not args.no_profile)
+        be_k.engine.profile(0 if args.no_profile else 1)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     for _, be_k, _, _ in chains:
-        be_k.engine.profile(False)
+        be_k.engine.profile(0)
+    # roofline leg: with many streams overlapping, events around a launch measure queueing as much as
+    # the kernel, so the per-launch durations of the multi-launch intra pass are taken on ONE chain
+    # running alone right after the timed region (rocprofv3's per-dispatch average agrees with it)
+    if rank == 0 and not args.no_profile:
+        plan_k, be_k, stream, group = chains[0]
+        if world == 1:
+            with torch.cuda.stream(stream):
+                be_k.engine.profile(2)
+                for _ in range(2):
+                    P.run_step(plan_k, be_k, None, None)
+            torch.cuda.synchronize()
+            be_k.engine.profile(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -145,11 +157,14 @@ def main():
     out = None
     if rank == 0:
         b = 2 if params.bit_depth > 8 else 1
-        pass_ms, n_exec = None, 0
+        pass_ms, n_exec, intra_ms, intra_n = None, 0, 0.0, 0
         for _, be_k, _, _ in chains:                       # sum over the chains in flight
             ms_k, n_k = be_k.engine.pass_times()
             pass_ms = ms_k if pass_ms is None else {k: pass_ms[k] + ms_k[k] for k in ms_k}
             n_exec += n_k
+            im, inn = be_k.engine.intra_launch_times()
+            intra_ms += im
+            intra_n += inn
         roofline = None
         if n_exec:
             # algorithmic bytes of this rank's step, per pass (openhevc_amd/parallel.py)
@@ -170,10 +185,25 @@ def main():
             ms_per_step_pass = pass_ms[dom] / steps_timed
             n_launch = max(launches[dom], 1)
             avg_launch_us = ms_per_step_pass * 1e3 / n_launch
+            launch_source = "pass time / launches, timed region"
+            if dom == "intra" and intra_n:                 # every launch bracketed by its own events (roofline leg)
+                avg_launch_us = intra_ms * 1e3 / intra_n
+                launch_source = "HIP events around every launch, one chain alone after the timed region"
             achieved = (abytes[dom] / n_launch) / (avg_launch_us * 1e-6) / 1e9
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
+            # rocprofv3 --pmc passes of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes
+            # for gfx950); recorded under profiles/ because bench.py cannot run the profiler on itself
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    for kname, rec in json.load(fh).items():
+                        if kname.startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0]):
+                            traffic = rec["hbm_bytes_per_launch_corrected"]
+                            break
             roofline = dict(bound="hbm", kernel=PASS_KERNEL[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
-                            launches_per_step=n_launch, avg_launch_us=round(avg_launch_us, 3),
+                            frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
+                            launches_per_step=n_launch, avg_launch_us=round(avg_launch_us, 3), avg_launch_source=launch_source,
                             algorithmic_bytes_per_launch=round(abytes[dom] / n_launch, 1),
                             pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
                             pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms})

@@ -83,10 +83,14 @@ int oh_frame_free(OhEngine *e, OhDevFrame *df);
 int oh_frame_submit(OhEngine *e, const OhFrame *f);     /* upload + execute + deferred free */
 
 /* per-pass device time of the executes since the last reset, measured with HIP events on the
- * engine stream (enable costs two event records per pass).  ms[] and launches[] hold OH_N_PASSES
+ * engine stream (enable = 1 costs two event records per pass; enable = 2 additionally brackets every
+ * launch of the intra pass, see oh_engine_intra_launch_times).  ms[] and launches[] hold OH_N_PASSES
  * entries: accumulated milliseconds and number of timed executes. */
 int oh_engine_profile(OhEngine *e, int enable);
 int oh_engine_pass_times(OhEngine *e, double *ms, uint64_t *executes, int reset);
+/* the intra pass is one launch per CTU-wavefront level: summed per-launch device time and launch
+ * count (events bracket every launch in profile mode); read after oh_engine_pass_times() */
+int oh_engine_intra_launch_times(OhEngine *e, double *ms, uint64_t *launches, int reset);
 
 /* the stream everything is enqueued on (hipStream_t as void*), for callers that need to order
  * their own work (RCCL broadcasts of reference pictures) against the engine */

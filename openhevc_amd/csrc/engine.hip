@@ -47,8 +47,11 @@ struct OhEngine {
     bool        own_stream = true;
     std::vector<Pic> pics;
     std::string err;
-    bool        profile = false;
+    int         profile = 0;             /* 0 off, 1 events between passes, 2 also around every intra launch */
     std::vector<EventSet> ev_pool, ev_pending;
+    std::vector<hipEvent_t> lev_pool, lev_pending;   /* per-launch event pairs of the intra pass (profile mode) */
+    double      intra_launch_ms = 0;
+    uint64_t    intra_launches = 0;
     double      pass_ms[OH_N_PASSES] = {};
     uint64_t    executes = 0;
     std::vector<OhDevFrame *> deferred;
@@ -165,6 +168,8 @@ extern "C" void oh_engine_destroy(OhEngine *e)
             (void)hipFree(p.base);
     for (auto &s : e->ev_pool)
         for (auto &ev : s.ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->lev_pool) (void)hipEventDestroy(ev);
+    for (auto &ev : e->lev_pending) (void)hipEventDestroy(ev);
     for (auto &s : e->ev_pending)
         for (auto &ev : s.ev) (void)hipEventDestroy(ev);
     if (e->own_stream)
@@ -625,7 +630,7 @@ extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
     EventSet es;
-    bool prof = e->profile;
+    const bool prof = e->profile > 0, prof_launch = e->profile > 1;
     if (prof) {
         if (!e->ev_pool.empty()) {
             es = e->ev_pool.back();
@@ -641,8 +646,22 @@ extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
     MARK(OH_PASS_INTER);
     ohk_residual(df->d, &df->p, df->n_tu, st);
     MARK(OH_PASS_RESIDUAL);
-    for (size_t l = 0; l + 1 < df->level_start.size(); l++)
+    for (size_t l = 0; l + 1 < df->level_start.size(); l++) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (prof_launch) {                                /* bracket every launch: the pass is many dependent launches */
+            for (hipEvent_t *pe : { &a, &b }) {
+                if (!e->lev_pool.empty()) { *pe = e->lev_pool.back(); e->lev_pool.pop_back(); }
+                else HIPCHK(e, hipEventCreate(pe));
+            }
+            HIPCHK(e, hipEventRecord(a, st));
+        }
         ohk_intra_level(df->d, &df->p, df->level_start[l], df->level_start[l + 1] - df->level_start[l], df->level_staged[l], st);
+        if (prof_launch) {
+            HIPCHK(e, hipEventRecord(b, st));
+            e->lev_pending.push_back(a);
+            e->lev_pending.push_back(b);
+        }
+    }
     MARK(OH_PASS_INTRA);
     if (df->p.deblock_enabled)
         ohk_deblock(df->d, &df->p, 0, st);
@@ -686,7 +705,7 @@ extern "C" int oh_engine_profile(OhEngine *e, int enable)
 {
     if (!e)
         return OH_E_ARG;
-    e->profile = enable != 0;
+    e->profile = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return OH_OK;
 }
 
@@ -706,6 +725,15 @@ extern "C" int oh_engine_pass_times(OhEngine *e, double *ms, uint64_t *executes,
         e->ev_pool.push_back(s);
     }
     e->ev_pending.clear();
+    for (size_t i = 0; i + 1 < e->lev_pending.size(); i += 2) {
+        float t = 0;
+        HIPCHK(e, hipEventElapsedTime(&t, e->lev_pending[i], e->lev_pending[i + 1]));
+        e->intra_launch_ms += t;
+        e->intra_launches++;
+        e->lev_pool.push_back(e->lev_pending[i]);
+        e->lev_pool.push_back(e->lev_pending[i + 1]);
+    }
+    e->lev_pending.clear();
     if (ms)
         for (int k = 0; k < OH_N_PASSES; k++) ms[k] = e->pass_ms[k];
     if (executes)
@@ -714,5 +742,16 @@ extern "C" int oh_engine_pass_times(OhEngine *e, double *ms, uint64_t *executes,
         for (double &v : e->pass_ms) v = 0;
         e->executes = 0;
     }
+    return OH_OK;
+}
+
+/* per-LAUNCH device time of the intra pass (sum over launches, count); call after oh_engine_pass_times */
+extern "C" int oh_engine_intra_launch_times(OhEngine *e, double *ms, uint64_t *launches, int reset)
+{
+    if (!e)
+        return OH_E_ARG;
+    if (ms) *ms = e->intra_launch_ms;
+    if (launches) *launches = e->intra_launches;
+    if (reset) { e->intra_launch_ms = 0; e->intra_launches = 0; }
     return OH_OK;
 }

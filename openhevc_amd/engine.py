@@ -58,6 +58,7 @@ def lib():
         L.oh_frame_submit.argtypes = [V, C.POINTER(F.OhFrame)]
         L.oh_engine_profile.argtypes = [V, I]
         L.oh_engine_pass_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
+        L.oh_engine_intra_launch_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
         L.oh_engine_stream.argtypes = [V]
         L.oh_engine_stream.restype = V
         L.oh_pic_device_planes.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -167,6 +168,11 @@ class Engine:
         n = C.c_uint64()
         self._chk(self.L.oh_engine_pass_times(self.h, ms, C.byref(n), int(reset)), "oh_engine_pass_times")
         return dict(zip(PASS_NAMES, list(ms))), n.value
+
+    def intra_launch_times(self, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        self._chk(self.L.oh_engine_intra_launch_times(self.h, C.byref(ms), C.byref(n), int(reset)), "oh_engine_intra_launch_times")
+        return ms.value, n.value
 
     def stream(self):
         return self.L.oh_engine_stream(self.h)

@@ -184,8 +184,8 @@ static int check_params(OhEngine *e, const OhPicParams *p)
         FAIL(e, OH_E_ARG, "bad picture size");
     if (p->bit_depth != 8 && p->bit_depth != 10 && p->bit_depth != 12)
         FAIL(e, OH_E_UNSUPPORTED, "bit depth %d not supported (8/10/12)", p->bit_depth);
-    if (p->chroma_format_idc != 0 && p->chroma_format_idc != 1 && p->chroma_format_idc != 3)
-        FAIL(e, OH_E_UNSUPPORTED, "chroma_format_idc %d not supported yet (0, 1, 3)", p->chroma_format_idc);
+    if (p->chroma_format_idc < 0 || p->chroma_format_idc > 3)
+        FAIL(e, OH_E_ARG, "chroma_format_idc %d out of range", p->chroma_format_idc);
     if (p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_cb_size < 3 || p->log2_min_cb_size > p->log2_ctb_size ||
         p->log2_min_tb_size < 2 || p->log2_min_tb_size > 5 || p->log2_min_pu_size != p->log2_min_cb_size - 1)
         FAIL(e, OH_E_ARG, "bad block size parameters");

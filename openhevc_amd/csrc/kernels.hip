@@ -356,9 +356,9 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, mode = (w1 >> 16) & 0xff, avail = w1 >> 24;
     const int n = 1 << log2, bd = pp.bd;
     const int stride = c ? pr.stride[1] : pr.stride[0], pw = c ? pr.w[1] : pr.w[0], ph = c ? pr.h[1] : pr.h[0];
-    const int hs = c && pp.chroma == 1;                     /* == vs: 4:2:2 is rejected by the engine */
+    const int hs = c && (pp.chroma == 1 || pp.chroma == 2), vs = c && pp.chroma == 1;
     const int rs = ((1 << pp.log2_ctb) >> hs) + 4;
-    const int lx = bx - (cx0 >> hs), ly = by - (cy0 >> hs);  /* position inside the CTU */
+    const int lx = bx - (cx0 >> hs), ly = by - (cy0 >> vs);  /* position inside the CTU */
     uint16_t *__restrict__ cm = ct.main[0] + c * (CTU_MAX * CTU_RS);
     const uint16_t *__restrict__ trow = ly == 0 ? ct.top[0] + c * (2 * CTU_MAX + 8) + lx + 4 : cm + (ly - 1) * rs + lx + 4;   /* trow[i] = top[i] */
     const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;

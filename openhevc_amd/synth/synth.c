@@ -181,18 +181,25 @@ static void gen_tu(Gen *g, const CuInfo *cu, int x, int y, int log2, int blk_idx
     mark_edges(g, x, y, 1 << log2, 1 << log2, 1, 0);
     emit_tb(g, cu, 0, x, y, log2, cu->mode[pu], avail, cbf_y);
     if (cbf_y) set_cbf(g, x, y, 1 << log2);
+    /* the luma block is reconstructed before its chroma blocks: from here on it counts as decoded
+     * (the second chroma block of a 4:2:2 pair has the first one above it, hevc.c:1297-1345) */
+    if (cu->intra) oh_rec_mark_decoded(g->rec, x, y, 1 << log2, 1 << log2);
     if (nch == 3 || (nch && log2 > 2)) {
-        int lc = chroma_log2(g, log2);
+        int lc = chroma_log2(g, log2), nblk = nch == 2 ? 2 : 1;
         for (int c = 1; c < 3; c++)
-            emit_tb(g, cu, c, x, y, lc, cu->mode_c[pu], avail, pct(g, g->sp->cbf_pct / 2) || cu->bypass);
-        if (cu->intra) oh_rec_mark_decoded(g->rec, x, y, 1 << log2, 1 << log2);
-    } else {
-        if (cu->intra) oh_rec_mark_decoded(g->rec, x, y, 1 << log2, 1 << log2);
-        if (nch && blk_idx == 3) {                  /* 4:2:0 chroma of four 4x4 luma blocks, hevc.c:1395-1420 */
-            int av = cu->intra ? oh_rec_avail(g->rec, xb, yb, 8, 8) : 0;
-            for (int c = 1; c < 3; c++)
-                emit_tb(g, cu, c, xb, yb, 2, cu->mode_c[0], av, pct(g, g->sp->cbf_pct / 2) || cu->bypass);
-        }
+            for (int i = 0; i < nblk; i++) {
+                int yy = y + (i << lc);               /* 4:2:2: two square blocks stacked vertically */
+                int av = nch == 2 ? (cu->intra ? oh_rec_avail(g->rec, x, yy, 2 << lc, 1 << lc) : 0) : avail;
+                emit_tb(g, cu, c, x, yy, lc, cu->mode_c[pu], av, pct(g, g->sp->cbf_pct / 2) || cu->bypass);
+            }
+    } else if (nch && blk_idx == 3) {               /* chroma of four 4x4 luma blocks, hevc.c:1395-1420 */
+        int nblk = nch == 2 ? 2 : 1;
+        for (int c = 1; c < 3; c++)
+            for (int i = 0; i < nblk; i++) {
+                int yy = yb + 4 * i;
+                int av = cu->intra ? oh_rec_avail(g->rec, xb, yy, 8, nch == 2 ? 4 : 8) : 0;
+                emit_tb(g, cu, c, xb, yy, 2, cu->mode_c[0], av, pct(g, g->sp->cbf_pct / 2) || cu->bypass);
+            }
     }
 }
 
@@ -288,10 +295,12 @@ static void gen_cu(Gen *g, int x, int y, int log2)
         oh_rec_tu(g->rec, 0, x, y, log2, OH_TU_PCM, OH_TUF_ADD_NOW, g->blk);
         if (g->p.chroma_format_idc) {
             int lc = chroma_log2(g, log2);
-            for (int c = 1; c < 3; c++) {
-                gen_coeffs(g, lc, OH_TU_PCM);
-                oh_rec_tu(g->rec, c, x >> oh_hshift(&g->p, c), y >> oh_vshift(&g->p, c), lc, OH_TU_PCM, OH_TUF_ADD_NOW, g->blk);
-            }
+            for (int c = 1; c < 3; c++)
+                for (int i = 0; i < (g->p.chroma_format_idc == 2 ? 2 : 1); i++) {      /* 4:2:2: w/2 x h samples as two squares */
+                    gen_coeffs(g, lc, OH_TU_PCM);
+                    oh_rec_tu(g->rec, c, x >> oh_hshift(&g->p, c), (y >> oh_vshift(&g->p, c)) + (i << lc), lc, OH_TU_PCM,
+                              OH_TUF_ADD_NOW, g->blk);
+                }
         }
         oh_rec_mark_decoded(g->rec, x, y, n, n);
         return;

@@ -63,6 +63,9 @@ CASES = [
     ("i8_444", 136, 88, 8, 3, 6, 0, {}),
     ("b10_444", 136, 88, 10, 3, 5, 2, {}),
     ("i8_mono", 128, 64, 8, 0, 6, 0, {}),
+    ("i8_422", 136, 88, 8, 2, 6, 0, {}),
+    ("b10_422", 200, 136, 10, 2, 5, 2, {"weighted_pct": 25, "intra_pct": 25}),
+    ("b8_422_pcm_bypass", 200, 136, 8, 2, 6, 2, {"pcm_pct": 12, "bypass_pct": 12, "intra_pct": 30}),
     ("b8_tskip", 200, 136, 8, 1, 6, 2, {"tskip_pct": 40, "intra_pct": 30}),
     ("b8_pcm_bypass", 264, 200, 8, 1, 6, 2, {"pcm_pct": 12, "bypass_pct": 12, "intra_pct": 30, "vary_deblock_offsets": 1}),
     ("b10_pcm_bypass", 264, 200, 10, 1, 5, 2, {"pcm_pct": 12, "bypass_pct": 12, "intra_pct": 30}),

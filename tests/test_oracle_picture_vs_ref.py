@@ -27,6 +27,8 @@ CASES = [
     (136, 88, 10, 3, 4),
     (96, 64, 12, 1, 5),
     (64, 64, 8, 0, 6),
+    (136, 88, 8, 2, 6),          # 4:2:2
+    (200, 136, 10, 2, 5),
 ]
 
 
@@ -79,7 +81,7 @@ def decode_order(rec, f):
         cx, cy = x // ctb, y // ctb
         xi, yi = x % ctb, y % ctb
         # 4:2:0 chroma of four 4x4 luma blocks is coded after the 4th luma block (hevc.c:1395)
-        if it.c_idx and p.chroma_format_idc != 3 and it.log2_size == 2:
+        if it.c_idx and p.chroma_format_idc == 1 and it.log2_size == 2:
             xi += 4
             yi += 4
         m = 0

@@ -52,7 +52,8 @@ def visible(p, arrs, pad=96):
 
 CASES = [("p8", 8, 1, 1, {}), ("b8", 8, 1, 2, {"weighted_pct": 30}), ("b8_far", 8, 1, 2, {"mv_range": 1200}),
          ("b10", 10, 1, 2, {"tskip_pct": 30, "intra_pct": 30}), ("i8", 8, 1, 0, {}), ("b8_444", 8, 3, 2, {"weighted_pct": 30}),
-         ("b8_bypass", 8, 1, 2, {"bypass_pct": 20, "pcm_pct": 10, "intra_pct": 30})]
+         ("b8_bypass", 8, 1, 2, {"bypass_pct": 20, "pcm_pct": 10, "intra_pct": 30}),
+         ("b8_422", 8, 2, 2, {"weighted_pct": 30, "intra_pct": 25})]
 
 
 @pytest.mark.parametrize("name,bd,chroma,st,knobs", CASES, ids=[c[0] for c in CASES])

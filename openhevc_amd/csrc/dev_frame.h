@@ -20,11 +20,31 @@ struct DevTile {
     uint8_t  ox, oy, w, h;        /* offset inside the PU and size, luma samples             */
 };
 
-/* intra block as the kernel wants it: OhIntra with the TU index resolved to its residual offset */
+/* LDS geometry of the intra CTU kernel (kernels.hip: CtuLds); the host precomputes offsets into it */
+#define OH_CTU_MAX 64
+#define OH_CTU_RS (OH_CTU_MAX + 4)                 /* row stride: 3 pad + column -1 + 64 samples */
+#define OH_CTU_TOP (2 * OH_CTU_MAX + 8)            /* row -1 of a plane: 3 pad + corner + 2*64 samples */
+#define OH_MAX_CTU_BLOCKS 768                      /* 64x64 4:4:4 all 4x4 */
+#define OH_RES_LDS_MAX (3 * OH_CTU_MAX * OH_CTU_MAX)
+
+enum { OH_IF_FILTER = 1, OH_IF_STRONG_CAND = 2, OH_IF_EDGE = 4 };            /* DevIntra.flags bits 0..2 */
+enum { OH_IC_PLANAR = 0, OH_IC_DC, OH_IC_ANG_V, OH_IC_ANG_H, OH_IC_PURE_V, OH_IC_PURE_H };   /* flags >> 4 */
+
+/* intra block as the kernel wants it: OhIntra plus everything that only depends on the block's
+ * geometry and mode, resolved once on the host at upload (engine.hip) */
 struct DevIntra {
-    uint16_t x, y;
+    uint16_t x, y;                /* position in the plane (HBM store address)                  */
     uint8_t  c_idx, log2_size, mode, avail;
     uint32_t res_off;             /* int16 offset into DevFrame.res, OH_NO_COEFF when cbf == 0  */
+    uint16_t cm_off;              /* LDS: index of the block's sample (0,0), in uint16 from CtuLds::main */
+    uint16_t top_off;             /* LDS: index of top[0] (row above the block); top[-1] is at -1 */
+    uint16_t rs;                  /* LDS row stride of the plane                                */
+    uint8_t  tr_size, bl_size;    /* samples inside the picture above-right / below-left (:111-114) */
+    int8_t   angle;               /* intraPredAngle, 0 for planar / DC                          */
+    uint8_t  flags;               /* OH_IF_* | (OH_IC_* << 4)                                   */
+    int16_t  inv_angle;           /* invAngle when the side projection is needed, else 0        */
+    uint32_t res_lds;             /* offset of the residual inside the staged span (res_off - res_lo) */
+    uint32_t pad;
 };
 
 /* OhIntraCtu plus the span of the residual pool its blocks use (staged in LDS when it fits) */

@@ -508,12 +508,46 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_tiles = add(tiles.data(), tiles.size() * sizeof(DevTile));
     int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
     int s_tu = add(f->tu, (size_t)f->n_tu * sizeof(OhTu));
+    /* intra block descriptors: everything that depends only on geometry and mode is resolved here */
+    static const int8_t k_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                                        -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };      /* hevcpred_template.c:430-433 */
+    static const int16_t k_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
     std::vector<DevIntra> dintra(f->n_intra);
     for (uint32_t i = 0; i < f->n_intra; i++) {
         const OhIntra &it = f->intra[i];
         DevIntra &d = dintra[i];
+        memset(&d, 0, sizeof(d));
+        const int c = it.c_idx, hs = oh_hshift(&p, c), vs = oh_vshift(&p, c), log2 = it.log2_size, n = 1 << log2, mode = it.mode;
+        const int lc = p.log2_ctb_size, rs = ((1 << lc) >> hs) + 4;
+        const int lx = it.x - ((((it.x << hs) >> lc) << lc) >> hs), ly = it.y - ((((it.y << vs) >> lc) << lc) >> vs);
         d.x = it.x; d.y = it.y; d.c_idx = it.c_idx; d.log2_size = it.log2_size; d.mode = it.mode; d.avail = it.avail;
         d.res_off = it.tu == OH_NO_COEFF ? OH_NO_COEFF : f->tu[it.tu].coeff_off;
+        d.rs = (uint16_t)rs;
+        d.cm_off = (uint16_t)(c * OH_CTU_MAX * OH_CTU_RS + ly * rs + lx + 4);
+        d.top_off = (uint16_t)(ly == 0 ? 3 * OH_CTU_MAX * OH_CTU_RS + c * OH_CTU_TOP + lx + 4 : d.cm_off - rs);
+        int tr = (it.x + 2 * n < cur->w[c] ? it.x + 2 * n : cur->w[c]) - (it.x + n);
+        int bl = (it.y + 2 * n < cur->h[c] ? it.y + 2 * n : cur->h[c]) - (it.y + n);
+        d.tr_size = (uint8_t)(tr < 0 ? 0 : tr); d.bl_size = (uint8_t)(bl < 0 ? 0 : bl);
+        int flags = 0, cls;
+        if (!p.intra_smoothing_disabled && (c == 0 || p.chroma_format_idc == 3) && mode != 1 && n != 4) {   /* :288-294 */
+            static const int thresh[3] = { 7, 1, 0 };
+            int d26 = mode > 26 ? mode - 26 : 26 - mode, d10 = mode > 10 ? mode - 10 : 10 - mode;
+            if ((d26 < d10 ? d26 : d10) > thresh[log2 - 3]) {
+                flags |= OH_IF_FILTER;
+                if (p.strong_intra_smoothing && c == 0 && log2 == 5) flags |= OH_IF_STRONG_CAND;
+            }
+        }
+        if (c == 0 && n < 32) flags |= OH_IF_EDGE;
+        if (mode == 0) cls = OH_IC_PLANAR;
+        else if (mode == 1) cls = OH_IC_DC;
+        else if (mode == 26) cls = OH_IC_PURE_V;
+        else if (mode == 10) cls = OH_IC_PURE_H;
+        else cls = mode >= 18 ? OH_IC_ANG_V : OH_IC_ANG_H;
+        if (mode >= 2) {
+            d.angle = k_angle[mode - 2];
+            if (d.angle < 0 && ((n * d.angle) >> 5) < -1) d.inv_angle = k_inv_angle[mode - 11];
+        }
+        d.flags = (uint8_t)(flags | (cls << 4));
     }
     int s_intra = add(dintra.data(), dintra.size() * sizeof(DevIntra));
     /* per CTU: span of the residual pool used by its intra blocks (the recorder appends TUs CTU by
@@ -539,6 +573,10 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             if ((uint64_t)d.res_lo + d.res_cnt > f->n_coeff) d.res_cnt = (uint32_t)(hi - lo) & ~3u;
         }
     }
+    for (size_t k = 0; k < dictu.size(); k++)
+        for (uint32_t b = f->sub_start[dictu[k].sub_first]; b < f->sub_start[dictu[k].sub_first + dictu[k].n_sub]; b++)
+            if (dintra[b].res_off != OH_NO_COEFF && dictu[k].res_cnt)
+                dintra[b].res_lds = dintra[b].res_off - dictu[k].res_lo;
     int s_ictu = add(dictu.data(), dictu.size() * sizeof(DevIntraCtu));
     int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
     int s_vbs = add(has_db ? f->vertical_bs : nullptr, has_db ? f->bs_size : 0);

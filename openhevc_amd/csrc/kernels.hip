@@ -294,14 +294,16 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
  * (constrained_intra_pred_flag == 0), each block followed by its residual (transform_add).
  *
  * One workgroup reconstructs one CTU.  The CTU's samples (with the one-sample border above and
- * to the left that intra_pred() gathers from, :164-183), the CTU's block list and the angle
- * tables are staged in LDS once; the waves then take the blocks of the current SUB-LEVEL (blocks
+ * to the left that intra_pred() gathers from, :164-183), the CTU's block descriptors and residual
+ * blocks are staged in LDS once; the waves then take the blocks of the current SUB-LEVEL (blocks
  * of one sub-level never read each other).  Per block a wave
+ *   - reads its 32-byte descriptor (everything that depends only on the block's geometry and mode
+ *     was resolved on the host at upload: LDS offsets, edge sizes, filter / class flags, angles),
  *   - gathers left[]/top[] from the staged CTU, one element per lane, and substitutes missing
  *     samples with wave-uniform lane reads (v_readlane) instead of the reference's serial fills,
- *   - smooths with lane shuffles, publishes left[]/top[] in LDS once,
- *   - predicts 4 consecutive samples per lane, adds the residual that was requested one
- *     sub-level earlier, and writes LDS (for the next sub-level) and HBM (dword stores, async).
+ *   - smooths with whole-wave DPP shifts, publishes left[]/top[] in LDS once,
+ *   - predicts 4 consecutive samples per lane in a mode-class specific loop, adds the residual and
+ *     writes LDS (for the next sub-level) and HBM (dword stores, never waited for).
  * Sub-levels are separated by an LDS-only workgroup barrier, so the dependent chain inside a CTU
  * costs a handful of LDS round trips per block inside one CU — no kernel launch, no HBM round
  * trip.  CTUs of one launch are mutually independent (same wavefront level, recorder.c).
@@ -315,22 +317,17 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
 #define STAMP(var) do { } while (0)
 #define ACC(slot, t0, t1) do { } while (0)
 #endif
-#define CTU_MAX 64
-#define CTU_RS (CTU_MAX + 4)                       /* LDS row stride: 3 pad + column -1 + 64 samples */
-#define MAX_CTU_BLOCKS 768                         /* 64x64 4:4:4 all 4x4 */
-#define RES_LDS_MAX (3 * CTU_MAX * CTU_MAX)        /* every sample of a 4:4:4 CTU coded */
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
-struct IntraLds { int L[66], T[66]; };             /* left[-1..2n-1], top[-1..2n-1] at index i+1, per wave */
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+struct IntraLds { int E[132]; };                   /* E[0..65] = left[-1..64), E[66..131] = top[-1..64), per wave */
 struct __attribute__((aligned(16))) CtuLds {
-    uint16_t main[3][CTU_MAX * CTU_RS];            /* sample (x,y) of plane c at [y*rs + x + 4], rs = wc + 4 */
-    uint16_t top[3][2 * CTU_MAX + 8];              /* row -1: sample x at [x + 4]                             */
-    DevIntra items[MAX_CTU_BLOCKS];
-    uint32_t sub[MAX_CTU_BLOCKS + 2];
-    int      angle[33], inv_angle[15];
-    int16_t  res[RES_LDS_MAX];                     /* the CTU's residual blocks (engine.hip: DevIntraCtu.res_lo/res_cnt) */
+    uint16_t main[3][OH_CTU_MAX * OH_CTU_RS];      /* sample (x,y) of plane c at [y*rs + x + 4], rs = wc + 4 */
+    uint16_t top[3][OH_CTU_TOP];                   /* row -1: sample x at [x + 4]; directly behind main[]    */
+    DevIntra items[OH_MAX_CTU_BLOCKS];
+    uint32_t sub[OH_MAX_CTU_BLOCKS + 2];
+    int16_t  res[OH_RES_LDS_MAX];                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
 };
-struct IntraParams { int bd, chroma, log2_ctb, strong, no_smooth; };
 
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 /* workgroup barrier that waits for LDS traffic only (global stores of finished samples stay in flight) */
@@ -340,33 +337,38 @@ struct IntraParams { int bd, chroma, log2_ctb, strong, no_smooth; };
 static __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 static __device__ __forceinline__ int wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
 
-struct PlaneRegs { uint64_t base[3]; int stride[2], w[2], h[2]; };     /* wave-uniform (SGPRs): [0] luma, [1] chroma */
+struct PlaneRegs { uint64_t base[3]; int stride[2]; };               /* wave-uniform (SGPRs): [0] luma, [1] chroma */
+
+template <typename PX>
+static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, GLOBAL PX *__restrict__ g, int v0, int v1, int v2, int v3)
+{
+    const uint2v pk16 = { (unsigned)(v0 | (v1 << 16)), (unsigned)(v2 | (v3 << 16)) };
+    *(uint2v *)lds = pk16;                                           /* 8-byte aligned by construction */
+    if (sizeof(PX) == 1) *(GLOBAL uint32_t *)g = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+    else                 *(GLOBAL uint2v *)g = pk16;
+}
 
 template <typename PX, bool STAGED>
-static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const IntraParams pp, const PlaneRegs &pr,
-                                                   const uint32_t *__restrict__ item, IntraLds &s, CtuLds &ct, const int cx0, const int cy0,
-                                                   const uint32_t res_lo, const int lane, unsigned long long *acc)
+static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
+                                                   const uint4v *__restrict__ item, IntraLds &s, CtuLds &ct, const int lane,
+                                                   unsigned long long *acc)
 {
     unsigned long long ta = 0, tb = 0, tc = 0, td = 0; (void)ta; (void)tb; (void)tc; (void)td; (void)acc;
     STAMP(ta);
-    /* the block descriptor is the same for every lane: keep it in scalar registers so that all the
-     * mode / availability decisions below are scalar branches */
-    const uint32_t w0 = __builtin_amdgcn_readfirstlane(item[0]), w1 = __builtin_amdgcn_readfirstlane(item[1]);
-    const uint32_t res_off = __builtin_amdgcn_readfirstlane(item[2]);
-    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, mode = (w1 >> 16) & 0xff, avail = w1 >> 24;
-    const int n = 1 << log2, bd = pp.bd;
-    const int stride = c ? pr.stride[1] : pr.stride[0], pw = c ? pr.w[1] : pr.w[0], ph = c ? pr.h[1] : pr.h[0];
-    const int hs = c && (pp.chroma == 1 || pp.chroma == 2), vs = c && pp.chroma == 1;
-    const int rs = ((1 << pp.log2_ctb) >> hs) + 4;
-    const int lx = bx - (cx0 >> hs), ly = by - (cy0 >> vs);  /* position inside the CTU */
-    uint16_t *__restrict__ cm = ct.main[0] + c * (CTU_MAX * CTU_RS);
-    const uint16_t *__restrict__ trow = ly == 0 ? ct.top[0] + c * (2 * CTU_MAX + 8) + lx + 4 : cm + (ly - 1) * rs + lx + 4;   /* trow[i] = top[i] */
+    /* the descriptor is the same for every lane: keep it in scalar registers */
+    const uint4v q0 = item[0], q1 = item[1];
+    const uint32_t w0 = __builtin_amdgcn_readfirstlane(q0[0]), w1 = __builtin_amdgcn_readfirstlane(q0[1]);
+    const uint32_t res_off = __builtin_amdgcn_readfirstlane(q0[2]), w3 = __builtin_amdgcn_readfirstlane(q0[3]);
+    const uint32_t w4 = __builtin_amdgcn_readfirstlane(q1[0]), w5 = __builtin_amdgcn_readfirstlane(q1[1]);
+    const uint32_t res_lds = __builtin_amdgcn_readfirstlane(q1[2]);
+    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
+    const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
+    const int n = 1 << log2, cls = flags >> 4;
+    uint16_t *__restrict__ M = &ct.main[0][0];
     const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
     const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
-    const int bl_size = max(min(by + 2 * n, ph) - (by + n), 0);         /* :111-114 */
-    const int tr_size = max(min(bx + 2 * n, pw) - (bx + n), 0);
     const int i = lane;                                                /* element this lane owns */
-    const int mid = 1 << (bd - 1);
     const bool has_res = res_off != OH_NO_COEFF;
     const int ngroups = (n * n) >> 2;
 
@@ -377,7 +379,7 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
         rv[k] = short4v{ 0, 0, 0, 0 };
         const int g = lane + 64 * k;
         if (has_res && g < ngroups) {
-            if (STAGED) rv[k] = *(const short4v *)(ct.res + (res_off - res_lo) + 4 * g);
+            if (STAGED) rv[k] = *(const short4v *)(ct.res + res_lds + 4 * g);
             else        rv[k] = *((const GLOBAL short4v *)(f->res + res_off) + g);       /* slow path: dependent HBM load */
         }
     }
@@ -388,9 +390,9 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
         const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
         const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
         const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
-        if (t_ok) tv = trow[ti];
-        if (l_ok) lv = cm[(ly + li) * rs + lx + 3];
-        if (a_ul) cv = trow[-1];
+        if (t_ok) tv = M[top_off + ti];
+        if (l_ok) lv = M[cm_off - 1 + li * rs];
+        if (a_ul) cv = M[top_off - 1];
     }
     /* substitution (:251-286) in closed form: the reference's cascaded fills only ever copy one of
      * these wave-uniform values */
@@ -401,139 +403,148 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
         left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
         corner = a_ul ? cv : (a_l ? l_0 : l_n);
     } else {
-        corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : mid));
+        corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : (1 << (bd - 1))));
         left_i = corner;
     }
     top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
 
-    /* smoothing (:288-326) with whole-wave DPP shifts */
-    if (!pp.no_smooth && (c == 0 || pp.chroma == 3) && mode != 1 && n != 4) {
-        const int dist = min(abs(mode - 26), abs(mode - 10));
-        const int thresh = log2 == 3 ? 7 : (log2 == 4 ? 1 : 0);
-        if (dist > thresh) {
-            bool strong = false;
-            int t63 = 0, l63 = 0;
-            if (pp.strong && c == 0 && log2 == 5) {
-                t63 = __builtin_amdgcn_readlane(top_i, 63); l63 = __builtin_amdgcn_readlane(left_i, 63);
-                const int t31 = __builtin_amdgcn_readlane(top_i, 31), l31 = __builtin_amdgcn_readlane(left_i, 31);
-                const int lim = 1 << (bd - 5);
-                strong = abs(corner + t63 - 2 * t31) < lim && abs(corner + l63 - 2 * l31) < lim;
+    /* smoothing (:288-326) with whole-wave DPP shifts; the mode/size test was done on the host */
+    if (flags & OH_IF_FILTER) {
+        bool strong = false;
+        int t63 = 0, l63 = 0;
+        if (flags & OH_IF_STRONG_CAND) {
+            t63 = __builtin_amdgcn_readlane(top_i, 63); l63 = __builtin_amdgcn_readlane(left_i, 63);
+            const int t31 = __builtin_amdgcn_readlane(top_i, 31), l31 = __builtin_amdgcn_readlane(left_i, 31);
+            const int lim = 1 << (bd - 5);
+            strong = abs(corner + t63 - 2 * t31) < lim && abs(corner + l63 - 2 * l31) < lim;
+        }
+        if (strong) {
+            if (i < 63) {
+                top_i  = ((63 - i) * corner + (i + 1) * t63 + 32) >> 6;
+                left_i = ((63 - i) * corner + (i + 1) * l63 + 32) >> 6;
             }
-            if (strong) {
-                if (i < 63) {
-                    top_i  = ((63 - i) * corner + (i + 1) * t63 + 32) >> 6;
-                    left_i = ((63 - i) * corner + (i + 1) * l63 + 32) >> 6;
-                }
-            } else {
-                const int lp = wave_shr1(left_i, corner), ln = wave_shl1(left_i, 0);
-                const int tp = wave_shr1(top_i, corner), tn = wave_shl1(top_i, 0);
-                const int l0v = __builtin_amdgcn_readlane(left_i, 0), t0v = __builtin_amdgcn_readlane(top_i, 0);
-                if (i < 2 * n - 1) {
-                    left_i = (ln + 2 * left_i + lp + 2) >> 2;
-                    top_i  = (tn + 2 * top_i + tp + 2) >> 2;
-                }
-                corner = (l0v + 2 * corner + t0v + 2) >> 2;
+        } else {
+            const int lp = wave_shr1(left_i, corner), ln = wave_shl1(left_i, 0);
+            const int tp = wave_shr1(top_i, corner), tn = wave_shl1(top_i, 0);
+            const int l0v = __builtin_amdgcn_readlane(left_i, 0), t0v = __builtin_amdgcn_readlane(top_i, 0);
+            if (i < 2 * n - 1) {
+                left_i = (ln + 2 * left_i + lp + 2) >> 2;
+                top_i  = (tn + 2 * top_i + tp + 2) >> 2;
             }
+            corner = (l0v + 2 * corner + t0v + 2) >> 2;
         }
     }
-    /* publish the edges once: E[0..65] = left[-1..64), E[66..131] = top[-1..64) */
-    int *E = s.L;
-    if (i < 2 * n) { E[i + 1] = left_i; E[66 + i + 1] = top_i; }
+    /* publish the edges once */
+    int *E = s.E;
+    const int LB = 1, TB = 67;                            /* left[k] = E[LB + k], top[k] = E[TB + k] */
+    if (i < 2 * n) { E[LB + i] = left_i; E[TB + i] = top_i; }
     if (lane == 0) { E[0] = corner; E[66] = corner; }
     STAMP(tb);
     WSYNC();
     STAMP(tc);
 
     /* prediction (:359-538): lane group g = lane + 64k owns samples 4g..4g+3 of the block (one row).
-     * All LDS reads of a group are issued before any of them is used. */
-    const int LB = 1, TB = 67;                            /* left[k] = E[LB + k], top[k] = E[TB + k] */
-    int dc = 0, angle = 0, inv_a = 0;
-    bool vertical = false;
-    if (mode >= 2) {
-        angle = ct.angle[mode - 2];
-        vertical = mode >= 18;
-        if (angle < 0 && ((n * angle) >> 5) < -1) inv_a = ct.inv_angle[mode - 11];
-    } else if (mode == 1) {
-        int part = i < n ? left_i + top_i : 0;
-        for (int m = 1; m < n; m <<= 1) part += __shfl_xor(part, m);
-        dc = (__builtin_amdgcn_readlane(part, 0) + n) >> (log2 + 1);
-    }
-    const int MB = vertical ? TB : LB, SB = vertical ? LB : TB;       /* main / side reference arrays */
-    const bool edge_filter = c == 0 && n < 32;
-    GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) + (size_t)by * stride + bx;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int g = lane + 64 * k;
-        if (g >= ngroups)
-            break;
-        const int y = (4 * g) >> log2, x0 = (4 * g) & (n - 1);
+     * One straight-line loop per mode class; all LDS reads of a group are issued before use. */
+    const bool edge = flags & OH_IF_EDGE;
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) +
+                                  (size_t)by * (c ? pr.stride[1] : pr.stride[0]) + bx;
+    const int gstride = c ? pr.stride[1] : pr.stride[0];
+    uint16_t *__restrict__ cm = M + cm_off;
+#define GROUP_LOOP_BEGIN                                                                  \
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {                                       \
+        const int g = lane + 64 * k;                                                      \
+        if (g >= ngroups) break;                                                          \
+        const int y = (4 * g) >> log2, x0 = (4 * g) & (n - 1);                            \
         int v[4];
-        if (mode >= 2) {
-            int r0[4], r1[4], fact[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = x0 + j;
-                const int aa = vertical ? y : x, bb = vertical ? x : y;
-                const int id = ((aa + 1) * angle) >> 5;
-                fact[j] = ((aa + 1) * angle) & 31;
-                /* ref[k] == main[k-1] for k >= 0, the projected side sample for k < 0 (:447-453, :480-486) */
-                const int k0 = bb + id + 1, k1 = k0 + 1;
-                const int a0 = k0 >= 0 ? MB + k0 - 1 : SB - 1 + ((k0 * inv_a + 128) >> 8);
-                const int a1 = k1 >= 0 ? MB + k1 - 1 : SB - 1 + ((k1 * inv_a + 128) >> 8);
-                r0[j] = E[a0];
-                r1[j] = E[a1];
-            }
-            int e0 = 0, e1 = 0, e2 = 0;
-            int et[4] = { 0, 0, 0, 0 };
-            if (edge_filter && mode == 26) { e0 = E[TB]; e1 = E[LB + y]; e2 = E[LB - 1]; }
-            if (edge_filter && mode == 10) {
-                e0 = E[LB]; e2 = E[TB - 1];
-#pragma unroll
-                for (int j = 0; j < 4; j++) et[j] = E[TB + x0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int pv = fact[j] ? ((32 - fact[j]) * r0[j] + fact[j] * r1[j] + 16) >> 5 : r0[j];
-                if (edge_filter) {                        /* :474-477, :501-508 */
-                    if (mode == 26 && x0 + j == 0) pv = clip_px(e0 + ((e1 - e2) >> 1), bd);
-                    if (mode == 10 && y == 0)      pv = clip_px(e0 + ((et[j] - e2) >> 1), bd);
-                }
-                v[j] = pv;
-            }
-        } else {
-            const int ly_ = E[LB + y], tn_ = E[TB + n], ln_ = E[LB + n], l0_ = E[LB], t0_ = E[TB];
+#define GROUP_LOOP_END                                                                    \
+        if (has_res) { _Pragma("unroll") for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[k][j], bd); } \
+        put4<PX>(cm + y * rs + x0 + 4 - 4, dst + (size_t)y * gstride + x0, v[0], v[1], v[2], v[3]);         \
+    }
+    /* note: cm already points at the block's sample (0,0) which sits at column index +4 of its row */
+    if (cls == OH_IC_PLANAR) {
+        const int tn_ = E[TB + n], ln_ = E[LB + n];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
             int tx[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) tx[j] = E[TB + x0 + j];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int x = x0 + j;
-                int pv;
-                if (mode == 0) {
-                    pv = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - y) * tx[j] + (y + 1) * ln_ + n) >> (log2 + 1);
-                } else {
-                    pv = dc;
-                    if (edge_filter) {                    /* :410-416 */
-                        if (x == 0 && y == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
-                        else if (y == 0)      pv = (tx[j] + 3 * dc + 2) >> 2;
-                        else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
-                    }
+                v[j] = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - y) * tx[j] + (y + 1) * ln_ + n) >> (log2 + 1);
+            }
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_DC) {
+        int part = i < n ? left_i + top_i : 0;
+        for (int m = 1; m < n; m <<= 1) part += __shfl_xor(part, m);
+        const int dc = (__builtin_amdgcn_readlane(part, 0) + n) >> (log2 + 1);
+        const int l0_ = E[LB], t0_ = E[TB];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + x0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                int pv = dc;
+                if (edge) {                               /* :410-416 */
+                    if (x == 0 && y == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
+                    else if (y == 0)      pv = (tx[j] + 3 * dc + 2) >> 2;
+                    else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
                 }
                 v[j] = pv;
             }
-        }
-        if (has_res) {
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_PURE_V) {                     /* mode 26: copy of the row above, :474-477 */
+        const int t0_ = E[TB], lm1 = E[LB - 1];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[k][j], bd);
-        }
-        /* LDS copy for the next sub-level (8-byte aligned: lx, x0 are multiples of 4, data starts at +4) */
-        const uint2v pk16 = { (unsigned)(v[0] | (v[1] << 16)), (unsigned)(v[2] | (v[3] << 16)) };
-        *(uint2v *)(cm + (ly + y) * rs + lx + x0 + 4) = pk16;
-        if (sizeof(PX) == 1)
-            *(GLOBAL uint32_t *)(dst + (size_t)y * stride + x0) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-        else
-            *(GLOBAL uint2v *)(dst + (size_t)y * stride + x0) = pk16;
+            for (int j = 0; j < 4; j++) v[j] = E[TB + x0 + j];
+            if (edge && x0 == 0) v[0] = clip_px(t0_ + ((ly_ - lm1) >> 1), bd);
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_PURE_H) {                     /* mode 10: copy of the left column, :501-508 */
+        const int l0_ = E[LB], tm1 = E[TB - 1];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + x0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (edge && y == 0) ? clip_px(l0_ + ((tx[j] - tm1) >> 1), bd) : ly_;
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_ANG_V) {                      /* modes 18..34 except 26: one (idx, fact) per row */
+        GROUP_LOOP_BEGIN
+            const int id = ((y + 1) * angle) >> 5, fact = ((y + 1) * angle) & 31;
+            int r[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                /* ref[k] == top[k-1] for k >= 0, the projected left sample for k < 0 (:447-453) */
+                const int kk = x0 + j + id + 1;
+                r[j] = E[kk >= 0 ? TB + kk - 1 : LB - 1 + ((kk * inv_a + 128) >> 8)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = fact ? ((32 - fact) * r[j] + fact * r[j + 1] + 16) >> 5 : r[j];
+        GROUP_LOOP_END
+    } else {                                              /* modes 2..17 except 10: one (idx, fact) per column */
+        GROUP_LOOP_BEGIN
+            int r0[4], r1[4], fact[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const int id = ((x + 1) * angle) >> 5;
+                fact[j] = ((x + 1) * angle) & 31;
+                const int k0 = y + id + 1, k1 = k0 + 1;   /* ref[k] == left[k-1], projected top sample for k < 0 (:480-486) */
+                r0[j] = E[k0 >= 0 ? LB + k0 - 1 : TB - 1 + ((k0 * inv_a + 128) >> 8)];
+                r1[j] = E[k1 >= 0 ? LB + k1 - 1 : TB - 1 + ((k1 * inv_a + 128) >> 8)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = fact[j] ? ((32 - fact[j]) * r0[j] + fact[j] * r1[j] + 16) >> 5 : r0[j];
+        GROUP_LOOP_END
     }
+#undef GROUP_LOOP_BEGIN
+#undef GROUP_LOOP_END
     WSYNC();                                              /* this wave's edge arrays are reused by its next block */
     STAMP(td);
     ACC(2, ta, tb); ACC(3, tb, tc); ACC(4, tc, td);
@@ -550,22 +561,19 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void intra_ctu_kernel(const DevFr
     const OhPicParams &pp = f->pp;
     const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc;
     const int cx0 = (ctu.ctu % ctbw) << lc, cy0 = (ctu.ctu / ctbw) << lc;      /* luma origin of the CTU */
-    const int n_sub = min((int)ctu.n_sub, MAX_CTU_BLOCKS);
-    const IntraParams ip = { pp.bit_depth, pp.chroma_format_idc, lc, pp.strong_intra_smoothing, pp.intra_smoothing_disabled };
+    const int n_sub = min((int)ctu.n_sub, OH_MAX_CTU_BLOCKS);
+    const int bd = pp.bit_depth;
     PlaneRegs pr;
     pr.base[0] = (uint64_t)f->cur.p[0]; pr.base[1] = (uint64_t)f->cur.p[1]; pr.base[2] = (uint64_t)f->cur.p[2];
     pr.stride[0] = f->cur.stride[0]; pr.stride[1] = f->cur.stride[1];
-    pr.w[0] = f->cur.w[0]; pr.w[1] = f->cur.w[1]; pr.h[0] = f->cur.h[0]; pr.h[1] = f->cur.h[1];
 
-    /* stage: block list, sub-level table, angle tables */
-    const uint32_t item0 = ss[0], n_items = min(ss[n_sub] - item0, (uint32_t)MAX_CTU_BLOCKS);
+    /* stage: block descriptors, sub-level table, residual blocks */
+    const uint32_t item0 = ss[0], n_items = min(ss[n_sub] - item0, (uint32_t)OH_MAX_CTU_BLOCKS);
     {
-        const GLOBAL uint32_t *__restrict__ src = (const GLOBAL uint32_t *)(f->intra + item0);
-        uint32_t *dst = (uint32_t *)ct.items;
-        for (uint32_t e = tid; e < n_items * 3; e += 64 * INTRA_WAVES) dst[e] = src[e];
+        const GLOBAL uint4v *__restrict__ src = (const GLOBAL uint4v *)(f->intra + item0);
+        uint4v *dst = (uint4v *)ct.items;
+        for (uint32_t e = tid; e < n_items * 2; e += 64 * INTRA_WAVES) dst[e] = src[e];
         for (int e = tid; e <= n_sub; e += 64 * INTRA_WAVES) ct.sub[e] = ss[e] - item0;
-        if (tid < 33) ct.angle[tid] = c_angle[tid];
-        if (tid < 15) ct.inv_angle[tid] = c_inv_angle[tid];
         /* the CTU's residual blocks: one coalesced sweep instead of a dependent load per block */
         const GLOBAL short4v *__restrict__ rsrc = (const GLOBAL short4v *)(f->res + ctu.res_lo);
         if (STAGED)
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void intra_ctu_kernel(const DevFr
         STAMP(t0);
         const uint32_t b1 = ct.sub[s + 1];
         for (uint32_t b = ct.sub[s] + wave; b < b1; b += INTRA_WAVES)
-            intra_block<PX, STAGED>(f, ip, pr, (const uint32_t *)&ct.items[b], lds[wave], ct, cx0, cy0, ctu.res_lo, lane, acc);
+            intra_block<PX, STAGED>(f, bd, pr, (const uint4v *)&ct.items[b], lds[wave], ct, lane, acc);
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
         STAMP(t2);
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void intra_ctu_kernel(const DevFr
         if (slot < 4000) {
             unsigned long long *o = (unsigned long long *)f->dbg + 16 + slot * 16;
             o[0] = n_sub; o[1] = te - tk; o[2] = rt2 - rt1; o[3] = acc[0]; o[4] = acc[1]; o[5] = acc[2]; o[6] = acc[3]; o[7] = acc[4];
-            o[8] = gridDim.x; o[9] = n_items; o[10] = tk; 
+            o[8] = gridDim.x; o[9] = n_items; o[10] = tk;
         }
     }
 #endif

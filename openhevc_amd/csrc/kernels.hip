@@ -75,7 +75,15 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
     __shared__ int16_t  tmp[23 * 16];
     const int lane = threadIdx.x;
     const int c = blockIdx.y;
-    const DevTile t = f->tiles[blockIdx.x];
+    /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
+     * tiles are recorded in CTU / z-scan order (neighbours adjacent in the list).  Give every XCD one
+     * CONTIGUOUS eighth of the list so that the overlapping interpolation windows of neighbouring
+     * tiles hit the same L2 instead of being fetched from HBM once per XCD. */
+    const uint32_t nt = f->n_tiles, per = (nt + 7) >> 3;
+    const uint32_t tile_idx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile_idx >= nt)
+        return;
+    const DevTile t = f->tiles[tile_idx];
     const OhPu pu = f->pu[t.pu];
     const OhPicParams &pp = f->pp;
     const int bd = pp.bit_depth;
@@ -1057,7 +1065,7 @@ extern "C" int ohk_init(void)
 extern "C" void ohk_inter(const DevFrame *df, const OhPicParams *p, uint32_t n_tiles, hipStream_t st)
 {
     if (!n_tiles) return;
-    dim3 grid(n_tiles, p->chroma_format_idc ? 3 : 1);
+    dim3 grid(((n_tiles + 7) >> 3) * 8, p->chroma_format_idc ? 3 : 1);      /* 8 contiguous slices, one per XCD */
     LAUNCH_BY_DEPTH(p->bit_depth, mc_kernel, grid, dim3(64), st, df);
 }
 

@@ -66,15 +66,22 @@ static __device__ __forceinline__ int vsh(const OhPicParams &p, int c) { return 
 /* =========================================================================================
  * pass 1: inter prediction — hevcdsp_template.c:610-1609 through the drivers hevc.c:1641-1949;
  * picture-edge emulation (videodsp_template.c:26-101) is coordinate clamping while loading.
+ *
+ * One wave per <=16x16 tile of one plane (TAPS = 8 luma, 4 chroma).  Lane layout per stage:
+ *   load     8 rows x 8 column triples per step   (window <= 23x23, clamped coordinates)
+ *   h-pass   8 rows x 8 column pairs per step     (TAPS+1 LDS reads feed two outputs)
+ *   v-pass   16 columns x 4 row quads             (TAPS+3 LDS reads feed four outputs)
+ * so every index is a shift/mask of the lane id, and the epilogue stores 16 consecutive samples per
+ * row.  The h-pass result is kept as int16 in LDS exactly like the reference's tmp_array (:776).
  * ======================================================================================= */
 #define WIN_STRIDE 24
-template <typename PX>
+template <typename PX, int TAPS>
 __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
 {
-    __shared__ uint16_t win[23 * WIN_STRIDE];
-    __shared__ int16_t  tmp[23 * 16];
+    __shared__ uint16_t win[24 * WIN_STRIDE];
+    __shared__ int16_t  tmp[24 * 16];
     const int lane = threadIdx.x;
-    const int c = blockIdx.y;
+    const int c = TAPS == 8 ? 0 : 1 + blockIdx.y;
     /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
      * tiles are recorded in CTU / z-scan order (neighbours adjacent in the list).  Give every XCD one
      * CONTIGUOUS eighth of the list so that the overlapping interpolation windows of neighbouring
@@ -83,97 +90,122 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
     const uint32_t tile_idx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (tile_idx >= nt)
         return;
-    const DevTile t = f->tiles[tile_idx];
-    const OhPu pu = f->pu[t.pu];
+    const DevTile t = gload(f->tiles + tile_idx);
+    const OhPu pu = gload(f->pu + t.pu);
     const OhPicParams &pp = f->pp;
     const int bd = pp.bit_depth;
     const int hs = hsh(pp, c), vs = vsh(pp, c);
-    const int taps = c ? 4 : 8, before = taps / 2 - 1;
+    constexpr int before = TAPS / 2 - 1;
     const int bx = (pu.x + t.ox) >> hs, by = (pu.y + t.oy) >> vs;
     const int bw = t.w >> hs, bh = t.h >> vs;
-    const int npx = bw * bh;
+    const int ww = bw + TAPS - 1, wh = bh + TAPS - 1;
+    const int lr = lane >> 3, lg = lane & 7;               /* load / h-pass layout */
+    const int vx = lane & 15, vy = (lane >> 4) * 4;         /* v-pass layout: column vx, rows vy..vy+3 */
     int v[2][4];
 
     for (int l = 0; l < 2; l++) {
         if (pu.ref[l] == OH_NO_REF)
             continue;
         const DevPlanes &rp = f->refs[pu.ref[l]];
-        const PX *__restrict__ src = (const PX *)rp.p[c];
+        const GLOBAL PX *__restrict__ src = G_CONST(PX, rp.p[c]);
         const int sstride = rp.stride[c], pw = rp.w[c], ph = rp.h[c];
         const int mvx = pu.mv[l][0], mvy = pu.mv[l][1];
         int fx, fy, ix, iy;
-        if (c == 0) {
+        if (TAPS == 8) {
             fx = mvx & 3; fy = mvy & 3; ix = mvx >> 2; iy = mvy >> 2;
         } else {                                    /* hevc.c:1807-1813 */
             fx = (mvx & ((1 << (2 + hs)) - 1)) << (1 - hs);
             fy = (mvy & ((1 << (2 + vs)) - 1)) << (1 - vs);
             ix = mvx >> (2 + hs); iy = mvy >> (2 + vs);
         }
-        const int ww = bw + taps - 1, wh = bh + taps - 1;
         const int wx0 = bx + ix - before, wy0 = by + iy - before;
-        for (int e = lane; e < ww * wh; e += 64) {
-            int wy = e / ww, wx = e - wy * ww;
-            int sx = clip3(wx0 + wx, 0, pw - 1), sy = clip3(wy0 + wy, 0, ph - 1);
-            win[wy * WIN_STRIDE + wx] = src[(size_t)sy * sstride + sx];
-        }
-        __syncthreads();
-        const int8_t *cx = c ? c_epel[fx] : c_qpel[fx];
-        const int8_t *cy = c ? c_epel[fy] : c_qpel[fy];
-        for (int e = lane; e < wh * bw; e += 64) {
-            int r = e / bw, x = e - r * bw;
-            int val;
-            if (fx) {
-                int s = 0;
-                for (int k = 0; k < taps; k++)
-                    s += cx[k] * win[r * WIN_STRIDE + x + k];
-                val = s >> (bd - 8);
-            } else {
-                val = win[r * WIN_STRIDE + x + before];
-            }
-            tmp[r * 16 + x] = (int16_t)val;
-        }
-        __syncthreads();
+        /* window -> LDS */
 #pragma unroll
-        for (int k4 = 0; k4 < 4; k4++) {
-            int idx = lane + 64 * k4;
-            int val = 0;
-            if (idx < npx) {
-                int py = idx / bw, px = idx - py * bw;
-                if (fy) {
-                    int s = 0;
-                    for (int k = 0; k < taps; k++)
-                        s += cy[k] * tmp[(py + k) * 16 + px];
-                    val = fx ? (s >> 6) : (s >> (bd - 8));
-                } else {
-                    int tv = tmp[(py + before) * 16 + px];
-                    val = fx ? tv : (tv << (14 - bd));
+        for (int it = 0; it < 3; it++) {
+            const int r = lr + 8 * it;
+            if (r < wh) {
+                const GLOBAL PX *row = src + (size_t)clip3(wy0 + r, 0, ph - 1) * sstride;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int col = lg * 3 + j;
+                    if (col < ww)
+                        win[r * WIN_STRIDE + col] = row[clip3(wx0 + col, 0, pw - 1)];
                 }
             }
-            v[l][k4] = val;
+        }
+        __syncthreads();
+        /* horizontal pass (or copy) -> tmp[r][x], two outputs per lane and step */
+        const int8_t *cx = TAPS == 8 ? c_qpel[fx] : c_epel[fx];
+        int kx[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) kx[k] = cx[k];
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int r = lr + 8 * it, x = lg * 2;
+            if (r < wh && x < bw) {
+                int o0, o1;
+                if (fx) {
+                    int p[TAPS + 1];
+#pragma unroll
+                    for (int k = 0; k <= TAPS; k++) p[k] = win[r * WIN_STRIDE + x + k];
+                    int s0 = 0, s1 = 0;
+#pragma unroll
+                    for (int k = 0; k < TAPS; k++) { s0 += kx[k] * p[k]; s1 += kx[k] * p[k + 1]; }
+                    o0 = s0 >> (bd - 8); o1 = s1 >> (bd - 8);
+                } else {
+                    o0 = win[r * WIN_STRIDE + x + before]; o1 = win[r * WIN_STRIDE + x + 1 + before];
+                }
+                *(unsigned *)(tmp + r * 16 + x) = (unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16);
+            }
+        }
+        __syncthreads();
+        /* vertical pass (or copy): column vx, four rows */
+        const int8_t *cy = TAPS == 8 ? c_qpel[fy] : c_epel[fy];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[l][j] = 0;
+        if (vx < bw && vy < bh) {
+            if (fy) {
+                int p[TAPS + 3];
+#pragma unroll
+                for (int k = 0; k < TAPS + 3; k++) p[k] = tmp[(vy + k) * 16 + vx];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int s = 0;
+#pragma unroll
+                    for (int k = 0; k < TAPS; k++) s += cy[k] * p[j + k];
+                    v[l][j] = fx ? (s >> 6) : (s >> (bd - 8));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int tv = tmp[(vy + j + before) * 16 + vx];
+                    v[l][j] = fx ? tv : (tv << (14 - bd));
+                }
+            }
         }
         __syncthreads();
     }
 
-    PX *__restrict__ dst = (PX *)f->cur.p[c];
+    if (vx >= bw || vy >= bh)
+        return;
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, f->cur.p[c]) + (size_t)(by + vy) * f->cur.stride[c] + bx + vx;
     const int dstride = f->cur.stride[c];
     const bool u0 = pu.ref[0] != OH_NO_REF, u1 = pu.ref[1] != OH_NO_REF;
     const bool weighted = pu.wp != OH_NO_WP;
     int w0 = 0, w1 = 0, o0 = 0, o1 = 0, denom = 0;
     if (weighted) {
-        const OhWeights wp = f->wp[pu.wp];
+        const OhWeights wp = gload(f->wp + pu.wp);
         w0 = wp.w[0][c]; w1 = wp.w[1][c];
         o0 = wp.o[0][c] * (1 << (bd - 8)); o1 = wp.o[1][c] * (1 << (bd - 8));
         denom = wp.log2_denom[c ? 1 : 0];
     }
 #pragma unroll
-    for (int k4 = 0; k4 < 4; k4++) {
-        int idx = lane + 64 * k4;
-        if (idx >= npx)
-            continue;
-        int py = idx / bw, px = idx - py * bw;
+    for (int j = 0; j < 4; j++) {
+        if (vy + j >= bh)
+            break;
         int r;
         if (u0 && u1) {
-            int a = (int16_t)v[0][k4], b = v[1][k4];            /* list 0 went through an int16 tmp, hevc.c:1761 */
+            int a = (int16_t)v[0][j], b = v[1][j];              /* list 0 went through an int16 tmp, hevc.c:1761 */
             if (!weighted) {
                 int shift = 15 - bd;
                 r = (b + a + (1 << (shift - 1))) >> shift;
@@ -182,7 +214,7 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
                 r = (b * w1 + a * w0 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
             }
         } else {
-            int a = u0 ? v[0][k4] : v[1][k4];
+            int a = u0 ? v[0][j] : v[1][j];
             if (!weighted) {
                 int shift = 14 - bd;
                 r = (a + (1 << (shift - 1))) >> shift;
@@ -191,7 +223,7 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
                 r = ((a * (u0 ? w0 : w1) + (1 << (shift - 1))) >> shift) + (u0 ? o0 : o1);
             }
         }
-        dst[(size_t)(by + py) * dstride + bx + px] = (PX)clip_px(r, bd);
+        dst[(size_t)j * dstride] = (PX)clip_px(r, bd);
     }
 }
 
@@ -1065,8 +1097,14 @@ extern "C" int ohk_init(void)
 extern "C" void ohk_inter(const DevFrame *df, const OhPicParams *p, uint32_t n_tiles, hipStream_t st)
 {
     if (!n_tiles) return;
-    dim3 grid(((n_tiles + 7) >> 3) * 8, p->chroma_format_idc ? 3 : 1);      /* 8 contiguous slices, one per XCD */
-    LAUNCH_BY_DEPTH(p->bit_depth, mc_kernel, grid, dim3(64), st, df);
+    const unsigned gx = ((n_tiles + 7) >> 3) * 8;             /* 8 contiguous slices, one per XCD */
+    if (p->bit_depth == 8) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 8>), dim3(gx), dim3(64), 0, st, df);
+        if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 4>), dim3(gx, 2), dim3(64), 0, st, df);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 8>), dim3(gx), dim3(64), 0, st, df);
+        if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 4>), dim3(gx, 2), dim3(64), 0, st, df);
+    }
 }
 
 extern "C" void ohk_residual(const DevFrame *df, const OhPicParams *p, uint32_t n_tu, hipStream_t st)

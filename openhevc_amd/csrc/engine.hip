@@ -414,6 +414,8 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
             FAIL(e, OH_E_ARG, "TU %u: outside the plane", i);
         if ((uint64_t)t.coeff_off + (uint64_t)n * n > f->n_coeff)
             FAIL(e, OH_E_ARG, "TU %u: coefficients outside the pool", i);
+        if ((t.coeff_off & 3) || (t.x & 3) || (t.y & 3))        /* the kernels move 4 elements per access */
+            FAIL(e, OH_E_ARG, "TU %u: position / coefficient offset not a multiple of 4", i);
         if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
             FAIL(e, OH_E_ARG, "TU %u: rotation is 4x4 only", i);
     }

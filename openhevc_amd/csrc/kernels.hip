@@ -57,11 +57,39 @@ static __device__ __forceinline__ T gload(const T *p)
     return out;
 }
 
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
 static __device__ __forceinline__ int clip3(int v, int lo, int hi) { return min(max(v, lo), hi); }
 static __device__ __forceinline__ int clip_px(int v, int bd) { return min(max(v, 0), (1 << bd) - 1); }
 static __device__ __forceinline__ int clip16(int v) { return min(max(v, -32768), 32767); }
 static __device__ __forceinline__ int hsh(const OhPicParams &p, int c) { return c && (p.chroma_format_idc == 1 || p.chroma_format_idc == 2); }
 static __device__ __forceinline__ int vsh(const OhPicParams &p, int c) { return c && p.chroma_format_idc == 1; }
+
+/* four consecutive samples as one 4-byte (8 bit) or 8-byte (>8 bit) access */
+template <typename PX>
+static __device__ __forceinline__ void load4(const GLOBAL PX *p, int v[4])
+{
+    if (sizeof(PX) == 1) {
+        unsigned r = *(const GLOBAL unsigned *)p;
+        v[0] = r & 0xff; v[1] = (r >> 8) & 0xff; v[2] = (r >> 16) & 0xff; v[3] = r >> 24;
+    } else {
+        uint2v r = *(const GLOBAL uint2v *)p;
+        v[0] = r[0] & 0xffff; v[1] = r[0] >> 16; v[2] = r[1] & 0xffff; v[3] = r[1] >> 16;
+    }
+}
+template <typename PX>
+static __device__ __forceinline__ void store4(GLOBAL PX *p, int a, int b, int c, int d)
+{
+    if (sizeof(PX) == 1) {
+        *(GLOBAL unsigned *)p = (unsigned)(a | (b << 8) | (c << 16) | (d << 24));
+    } else {
+        uint2v r = { (unsigned)(a | (b << 16)), (unsigned)(c | (d << 16)) };
+        *(GLOBAL uint2v *)p = r;
+    }
+}
+
 
 /* =========================================================================================
  * pass 1: inter prediction — hevcdsp_template.c:610-1609 through the drivers hevc.c:1641-1949;
@@ -231,62 +259,109 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
  * pass 2: residual — hevcdsp_template.c:114-316 dispatched as hevc_cabac.c:1868-1949;
  * inter blocks are added to the prediction here (transform_add, :45-111), intra blocks leave
  * their residual in f->res for pass 3.
+ *
+ * One wave per transform block; a lane owns groups of 4 consecutive elements (g = lane + 64k), so
+ * coefficients, prediction samples and results move as 8-byte (4-byte for 8-bit samples) vectors.
+ * Every HBM load of the block (coefficients, basis, prediction) is issued before the first wait.
+ * The two 1-D passes go through LDS once (pass 1 output is read transposed by pass 2); pass 2 ends in
+ * registers in the layout the epilogue stores.
  * ======================================================================================= */
+__device__ int8_t g_basis[5][1024];                 /* [log2-2] n x n DCT basis rows, [4] DST-VII; filled by ohk_init() */
+
 template <typename PX>
 __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict__ f)
 {
-    __shared__ int16_t a[1024];
-    __shared__ int16_t b[1024];
-    __shared__ int8_t  m[32 * 32];
-    const int lane = threadIdx.x;
-    const OhTu tu = f->tu[blockIdx.x];
-    const int bd = f->pp.bit_depth;
-    const int log2 = tu.log2_size, n = 1 << log2, n2 = n * n;
-    const int16_t *__restrict__ cin = f->coeffs + tu.coeff_off;
-
-    /* load, and find the bounding box of the non-zero coefficients: dequantised blocks are sparse and
-     * concentrated in the low-frequency corner, and zero rows/columns contribute nothing (this is what
-     * the reference's col_limit argument exploits, hevc_cabac.c:1927-1934) */
+    __shared__ __attribute__((aligned(16))) int16_t a[1024];
+    __shared__ __attribute__((aligned(16))) int16_t b[1024];
+    __shared__ __attribute__((aligned(16))) int8_t  m[32 * 32];
     __shared__ int bbox[2];
+    const int lane = threadIdx.x;
+    const OhTu tu = gload(f->tu + blockIdx.x);
+    const int bd = f->pp.bit_depth;
+    const int log2 = tu.log2_size, n = 1 << log2, ng = (n * n) >> 2;     /* groups of 4 elements */
+    const bool is_tr = tu.kind == OH_TU_IDCT || tu.kind == OH_TU_DST4;
+    const bool to_pic = tu.kind == OH_TU_PCM || (tu.flags & OH_TUF_ADD_NOW);
+    const bool add = to_pic && tu.kind != OH_TU_PCM;
+    const GLOBAL short4v *__restrict__ cin = (const GLOBAL short4v *)(f->coeffs + tu.coeff_off);
+    const GLOBAL unsigned *__restrict__ basis = (const GLOBAL unsigned *)g_basis[tu.kind == OH_TU_DST4 ? 4 : log2 - 2];
+    const int ds = f->cur.stride[tu.c_idx];
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, f->cur.p[tu.c_idx]) + (size_t)tu.y * ds + tu.x;
+
+    /* issue every load of the block */
+    short4v cv[4];
+    unsigned mv[4];
+    int pv[4][4];
     if (lane < 2) bbox[lane] = 0;
-    __syncthreads();
-    int my_r = 0, my_c = 0;
-    for (int e = lane; e < n2; e += 64) {
-        int16_t cv = cin[e];
-        a[e] = cv;
-        if (cv) { my_r = max(my_r, e >> log2); my_c = max(my_c, e & (n - 1)); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = lane + 64 * k;
+        cv[k] = short4v{ 0, 0, 0, 0 };
+        mv[k] = 0;
+        if (g < ng) {
+            cv[k] = cin[g];
+            if (is_tr) mv[k] = basis[g];
+            if (add) load4<PX>(dst + (size_t)((4 * g) >> log2) * ds + ((4 * g) & (n - 1)), pv[k]);
+        }
     }
-    if (tu.kind == OH_TU_IDCT || tu.kind == OH_TU_DST4) {
+    /* LDS: coefficients, basis, bounding box of the non-zero coefficients (zero rows / columns contribute
+     * nothing: what the reference's col_limit exploits, hevc_cabac.c:1927-1934) */
+    int my_r = 0, my_c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = lane + 64 * k;
+        if (g < ng) {
+            *(short4v *)(a + 4 * g) = cv[k];
+            if (is_tr) *(unsigned *)(m + 4 * g) = mv[k];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (cv[k][j]) { my_r = max(my_r, (4 * g) >> log2); my_c = max(my_c, ((4 * g) & (n - 1)) + j); }
+        }
+    }
+    __syncthreads();
+    int res[4][4];
+    if (is_tr) {
         if (my_r) atomicMax(&bbox[0], my_r);
         if (my_c) atomicMax(&bbox[1], my_c);
-        /* basis rows: every (32/n)-th row of the 32-point matrix, or the DST-VII matrix */
-        const int step = 32 >> log2;
-        for (int e = lane; e < n2; e += 64) {
-            int k = e >> log2, i = e & (n - 1);
-            m[e] = tu.kind == OH_TU_DST4 ? c_dst7[k][i] : g_dct[k * step][i];
-        }
         __syncthreads();
         const int nr = bbox[0] + 1, nc = bbox[1] + 1;   /* rows / columns that hold coefficients */
-        for (int e = lane; e < n2; e += 64) {          /* pass 1: down the columns, shift 7 */
-            int i = e >> log2, col = e & (n - 1);
-            int acc = 0;
+        /* pass 1: down the columns, shift 7; group = output row i, four consecutive columns */
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int g = lane + 64 * k;
+            if (g >= ng) break;
+            const int i = (4 * g) >> log2, col = (4 * g) & (n - 1);
+            int acc[4] = { 0, 0, 0, 0 };
             if (col < nc)
-                for (int k = 0; k < nr; k++)
-                    acc += m[k * n + i] * a[k * n + col];
-            b[i * n + col] = (int16_t)clip16((acc + 64) >> 7);
+                for (int kk = 0; kk < nr; kk++) {
+                    const int mm = m[kk * n + i];
+                    const short4v av = *(const short4v *)(a + kk * n + col);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] += mm * av[j];
+                }
+            short4v o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (short)clip16((acc[j] + 64) >> 7);
+            *(short4v *)(b + 4 * g) = o;
         }
         __syncthreads();
-        const int shift = 20 - bd, add = 1 << (shift - 1);
-        for (int e = lane; e < n2; e += 64) {          /* pass 2: along the rows */
-            int row = e >> log2, i = e & (n - 1);
-            int acc = 0;
-            for (int k = 0; k < nc; k++)
-                acc += m[k * n + i] * b[row * n + k];
-            a[e] = (int16_t)clip16((acc + add) >> shift);
+        /* pass 2: along the rows; group = row, four consecutive outputs i */
+        const int shift = 20 - bd, addc = 1 << (shift - 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int g = lane + 64 * k;
+            if (g >= ng) break;
+            const int row = (4 * g) >> log2, i0 = (4 * g) & (n - 1);
+            int acc[4] = { 0, 0, 0, 0 };
+            for (int kk = 0; kk < nc; kk++) {
+                const unsigned mm = *(const unsigned *)(m + kk * n + i0);
+                const int bv = b[row * n + kk];
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(mm >> (8 * j)) * bv;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) res[k][j] = clip16((acc[j] + addc) >> shift);
         }
-        __syncthreads();
-    } else if (tu.kind == OH_TU_SKIP || tu.kind == OH_TU_BYPASS) {
-        __syncthreads();
+    } else {
         if (tu.kind == OH_TU_SKIP) {
             if (tu.flags & OH_TUF_ROTATE) {            /* hevc_cabac.c:1879-1882, 4x4 only */
                 int16_t t0 = lane < 16 ? a[15 - lane] : 0;
@@ -295,13 +370,13 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
                 __syncthreads();
             }
             const int shift = 15 - bd - log2;
-            for (int e = lane; e < n2; e += 64) {
-                int cv = a[e];
-                a[e] = shift > 0 ? (int16_t)((cv + (1 << (shift - 1))) >> shift) : (int16_t)(cv << -shift);
+            for (int e = lane; e < n * n; e += 64) {
+                int c0 = a[e];
+                a[e] = shift > 0 ? (int16_t)((c0 + (1 << (shift - 1))) >> shift) : (int16_t)(c0 << -shift);
             }
             __syncthreads();
         }
-        if (tu.flags & OH_TUF_RDPCM) {                 /* hevcdsp_template.c:114-136 */
+        if ((tu.kind == OH_TU_SKIP || tu.kind == OH_TU_BYPASS) && (tu.flags & OH_TUF_RDPCM)) {   /* hevcdsp_template.c:114-136 */
             if (lane < n) {
                 if (tu.flags & OH_TUF_RDPCM_VER)
                     for (int y = 1; y < n; y++) a[y * n + lane] = (int16_t)(a[y * n + lane] + a[(y - 1) * n + lane]);
@@ -310,22 +385,32 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
             }
             __syncthreads();
         }
-    } else {
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int g = lane + 64 * k;
+            if (g >= ng) break;
+            const short4v o = *(const short4v *)(a + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; j++) res[k][j] = o[j];
+        }
     }
 
-    if (tu.kind == OH_TU_PCM || (tu.flags & OH_TUF_ADD_NOW)) {
-        PX *__restrict__ dst = (PX *)f->cur.p[tu.c_idx] + (size_t)tu.y * f->cur.stride[tu.c_idx] + tu.x;
-        const int ds = f->cur.stride[tu.c_idx];
-        for (int e = lane; e < n2; e += 64) {
-            int y = e >> log2, x = e & (n - 1);
-            if (tu.kind == OH_TU_PCM) dst[(size_t)y * ds + x] = (PX)a[e];
-            else                      dst[(size_t)y * ds + x] = (PX)clip_px(dst[(size_t)y * ds + x] + a[e], bd);
+    /* epilogue */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int g = lane + 64 * k;
+        if (g >= ng) break;
+        if (to_pic) {
+            int o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = add ? clip_px(pv[k][j] + res[k][j], bd) : (res[k][j] & (sizeof(PX) == 1 ? 0xff : 0xffff));
+            store4<PX>(dst + (size_t)((4 * g) >> log2) * ds + ((4 * g) & (n - 1)), o[0], o[1], o[2], o[3]);
+        } else {
+            short4v o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (short)res[k][j];
+            *((GLOBAL short4v *)(f->res + tu.coeff_off) + g) = o;
         }
-    } else {
-        int16_t *__restrict__ r = f->res + tu.coeff_off;
-        for (int e = lane; e < n2; e += 64)
-            r[e] = a[e];
     }
 }
 
@@ -357,9 +442,6 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
 #define STAMP(var) do { } while (0)
 #define ACC(slot, t0, t1) do { } while (0)
 #endif
-typedef short short4v __attribute__((ext_vector_type(4)));
-typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
-typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 struct IntraLds { int E[132]; };                   /* E[0..65] = left[-1..64), E[66..131] = top[-1..64), per wave */
 struct __attribute__((aligned(16))) CtuLds {
     uint16_t main[3][OH_CTU_MAX * OH_CTU_RS];      /* sample (x,y) of plane c at [y*rs + x + 4], rs = wc + 4 */
@@ -689,29 +771,6 @@ static __device__ __forceinline__ int get_pcm(const DevFrame *f, int x, int y)
     if (x < 0 || y < 0 || (x >> l) >= mpw || (y >> l) >= mph)
         return 2;
     return f->is_pcm ? f->is_pcm[(y >> l) * mpw + (x >> l)] : 0;
-}
-
-/* four consecutive samples as one 4-byte (8 bit) or 8-byte (>8 bit) access */
-template <typename PX>
-static __device__ __forceinline__ void load4(const GLOBAL PX *p, int v[4])
-{
-    if (sizeof(PX) == 1) {
-        unsigned r = *(const GLOBAL unsigned *)p;
-        v[0] = r & 0xff; v[1] = (r >> 8) & 0xff; v[2] = (r >> 16) & 0xff; v[3] = r >> 24;
-    } else {
-        uint2v r = *(const GLOBAL uint2v *)p;
-        v[0] = r[0] & 0xffff; v[1] = r[0] >> 16; v[2] = r[1] & 0xffff; v[3] = r[1] >> 16;
-    }
-}
-template <typename PX>
-static __device__ __forceinline__ void store4(GLOBAL PX *p, int a, int b, int c, int d)
-{
-    if (sizeof(PX) == 1) {
-        *(GLOBAL unsigned *)p = (unsigned)(a | (b << 8) | (c << 16) | (d << 24));
-    } else {
-        uint2v r = { (unsigned)(a | (b << 16)), (unsigned)(c | (d << 16)) };
-        *(GLOBAL uint2v *)p = r;
-    }
 }
 
 template <typename PX, int HORIZ>       /* HORIZ = 1: horizontal edges (filter across y) */
@@ -1085,6 +1144,17 @@ extern "C" int ohk_init(void)
             if (a > 64) a = 128 - a;
             m[k][n] = (int8_t)(k == 0 ? 64 : (a == 32 ? 0 : (a < 32 ? c[a] : -c[64 - a])));
         }
+    static const int8_t dst7[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+    static int8_t basis[5][1024];
+    for (int l = 0; l < 4; l++) {                     /* n-point basis: every (32/n)-th row of the 32-point matrix */
+        int n = 4 << l, step = 32 / n;
+        for (int k = 0; k < n; k++)
+            for (int i = 0; i < n; i++) basis[l][k * n + i] = m[k * step][i];
+    }
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < 4; i++) basis[4][k * 4 + i] = dst7[k][i];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_basis), basis, sizeof(basis)) != hipSuccess)
+        return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dct), m, sizeof(m)) == hipSuccess ? 0 : -1;
 }
 

@@ -129,6 +129,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
+    dt_enqueue = time.perf_counter() - t0                  # host time to record nothing and enqueue everything
     barrier()
     dt = time.perf_counter() - t0
     for _, be_k, _, _ in chains:
@@ -212,6 +213,7 @@ def main():
             "metric": "decoded Mpixels/s (luma), synthetic stream, bit-exact vs reference-pinned oracle",
             "value": round(value, 2), "unit": "Mpixels/s", "fps": round(total_pics / dt, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if params.bit_depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "width": params.width, "height": params.height, "bit_depth": params.bit_depth,

@@ -14,11 +14,18 @@ struct DevPlanes {
     int32_t w[3], h[3];
 };
 
-/* one <=16x16 luma tile of a PU: the unit one wave interpolates */
-struct DevTile {
-    uint32_t pu;                  /* index into DevFrame.pu                                  */
-    uint8_t  ox, oy, w, h;        /* offset inside the PU and size, luma samples             */
-};
+/* one <=8x8 block of one plane of a PU: the unit a quarter wave (16 lanes) interpolates.  The lists
+ * are compacted: ref[0] / mv[0] is the first list the PU uses, ref[1] the second or OH_NO_REF. */
+struct DevMcJob {
+    uint16_t x, y;                /* position in the plane, samples (even)                      */
+    uint8_t  w, h;                /* size in the plane, 2..8 (even)                             */
+    uint8_t  ref[2];              /* slots in DevFrame.refs                                     */
+    int16_t  mv[2][2];            /* quarter-luma-sample units, same order as ref[]             */
+    uint16_t wp;                  /* index into DevFrame.wp, OH_NO_WP = default weighting       */
+    uint8_t  c_idx;
+    uint8_t  flags;               /* OH_MCF_*                                                   */
+};                                /* 20 bytes */
+enum { OH_MCF_FROM_L1 = 1 };      /* uni-prediction whose only list is list 1 (selects the weights) */
 
 /* LDS geometry of the intra CTU kernel (kernels.hip: CtuLds); the host precomputes offsets into it */
 #define OH_CTU_MAX 64
@@ -61,7 +68,7 @@ struct DevFrame {
     DevPlanes   refs[OH_MAX_REFS];/* final planes of the reference pictures                   */
 
     const OhPu      *pu;
-    const DevTile   *tiles;
+    const DevMcJob  *mc_luma, *mc_chroma;
     const OhWeights *wp;
     const OhTu      *tu;
     const int16_t   *coeffs;
@@ -74,7 +81,7 @@ struct DevFrame {
     const uint8_t   *is_pcm;          /* may be null                                          */
     const OhDeblockCtb *db;
     const OhSaoCtb  *sao;             /* may be null                                          */
-    uint32_t n_pu, n_tiles, n_tu, n_intra;
+    uint32_t n_pu, n_mc_luma, n_mc_chroma, n_tu, n_intra;
     uint64_t *dbg;                    /* diagnostic builds only (OH_STAMPS), null otherwise       */
 };
 

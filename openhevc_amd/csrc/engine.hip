@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -35,7 +36,7 @@ struct OhDevFrame {
     void      *arena = nullptr;
     DevFrame  *d = nullptr;
     OhPicParams p{};
-    uint32_t   n_tiles = 0, n_tu = 0, n_intra = 0;
+    uint32_t   n_mc_luma = 0, n_mc_chroma = 0, n_tu = 0, n_intra = 0;
     bool       has_sao = false;
     std::vector<uint32_t> level_start;
     std::vector<uint8_t>  level_staged;   /* 1: every CTU of the level has its residual span staged in LDS */
@@ -370,7 +371,41 @@ static bool same_geometry(const OhPicParams &a, const OhPicParams &b)
 
 /* every index a kernel will follow is checked here: a malformed work list must fail on the host,
  * never fault on the GPU */
-static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<DevTile> &tiles)
+/* cut one plane's rectangle of a PU into the <=8x8 blocks the MC kernel works on */
+static void add_mc_jobs(std::vector<DevMcJob> &jobs, const OhPu &pu, int c, int hs, int vs)
+{
+    DevMcJob j;
+    const int first = pu.ref[0] != OH_NO_REF ? 0 : 1;
+    j.ref[0] = pu.ref[first];
+    j.ref[1] = first == 0 ? pu.ref[1] : (uint8_t)OH_NO_REF;
+    for (int k = 0; k < 2; k++) {
+        j.mv[0][k] = pu.mv[first][k];
+        j.mv[1][k] = pu.mv[1][k];
+    }
+    j.wp = pu.wp;
+    j.c_idx = (uint8_t)c;
+    j.flags = first ? OH_MCF_FROM_L1 : 0;
+    const int x0 = pu.x >> hs, y0 = pu.y >> vs, w = pu.w >> hs, h = pu.h >> vs;
+    for (int oy = 0; oy < h; oy += 8)
+        for (int ox = 0; ox < w; ox += 8) {
+            j.x = (uint16_t)(x0 + ox); j.y = (uint16_t)(y0 + oy);
+            j.w = (uint8_t)(w - ox < 8 ? w - ox : 8);
+            j.h = (uint8_t)(h - oy < 8 ? h - oy : 8);
+            jobs.push_back(j);
+        }
+}
+
+/* a wave runs the second list when any of its four blocks has one: keep bi-predicted blocks together
+ * (stable inside groups of 64 so that neighbours in the picture stay neighbours in the list) */
+static void group_by_lists(std::vector<DevMcJob> &jobs)
+{
+    for (size_t i = 0; i < jobs.size(); i += 64) {
+        size_t n = jobs.size() - i < 64 ? jobs.size() - i : 64;
+        std::stable_partition(jobs.begin() + i, jobs.begin() + i + n, [](const DevMcJob &j) { return j.ref[1] != OH_NO_REF; });
+    }
+}
+
+static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<DevMcJob> &mc_luma, std::vector<DevMcJob> &mc_chroma)
 {
     const OhPicParams &p = f->p;
     const int nplanes = p.chroma_format_idc ? 3 : 1;
@@ -393,15 +428,12 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
                 FAIL(e, OH_E_ARG, "PU %u: reference slot %d is not a usable picture", i, pu.ref[l]);
         if (pu.wp != OH_NO_WP && pu.wp >= f->n_wp)
             FAIL(e, OH_E_ARG, "PU %u: weight index out of range", i);
-        for (int oy = 0; oy < pu.h; oy += 16)
-            for (int ox = 0; ox < pu.w; ox += 16) {
-                DevTile t;
-                t.pu = i; t.ox = (uint8_t)ox; t.oy = (uint8_t)oy;
-                t.w = (uint8_t)(pu.w - ox < 16 ? pu.w - ox : 16);
-                t.h = (uint8_t)(pu.h - oy < 16 ? pu.h - oy : 16);
-                tiles.push_back(t);
-            }
+        add_mc_jobs(mc_luma, pu, 0, 0, 0);
+        for (int c = 1; c < nplanes; c++)
+            add_mc_jobs(mc_chroma, pu, c, oh_hshift(&p, c), oh_vshift(&p, c));
     }
+    group_by_lists(mc_luma);
+    group_by_lists(mc_chroma);
     for (uint32_t i = 0; i < f->n_wp; i++)
         if (f->wp[i].log2_denom[0] > 7 || f->wp[i].log2_denom[1] > 7)
             FAIL(e, OH_E_ARG, "weights %u: log2 denominator out of range", i);
@@ -480,9 +512,10 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     Pic *cur = get_pic(e, f->cur_pic);
     if (!cur || !same_geometry(cur->p, f->p))
         FAIL(e, OH_E_ARG, "cur_pic %d is not an allocated picture of this geometry", f->cur_pic);
-    std::vector<DevTile> tiles;
-    tiles.reserve((size_t)f->n_pu * 2);
-    rc = validate(e, f, cur, tiles);
+    std::vector<DevMcJob> mc_luma, mc_chroma;
+    mc_luma.reserve((size_t)f->n_pu * 4);
+    mc_chroma.reserve((size_t)f->n_pu * 4);
+    rc = validate(e, f, cur, mc_luma, mc_chroma);
     if (rc)
         return rc;
     HIPCHK(e, hipSetDevice(e->device));
@@ -493,9 +526,9 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     const bool has_sao = p.sao_enabled && f->sao;
     const bool has_db = p.deblock_enabled != 0;
 
-    /* arena layout: [DevFrame][pu][tiles][wp][tu][intra][vbs][hbs][qp][is_pcm][db][sao][coeffs] | [res] */
+    /* arena layout: [DevFrame][pu][mc jobs][wp][tu][intra][vbs][hbs][qp][is_pcm][db][sao][coeffs] | [res] */
     struct Seg { const void *src; size_t bytes, off; };
-    Seg seg[16];
+    Seg seg[20];
     int ns = 0;
     size_t total = 0;
     auto add = [&](const void *src, size_t bytes) {
@@ -507,7 +540,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     memset(&hd, 0, sizeof(hd));
     int s_hdr = add(&hd, sizeof(DevFrame));
     int s_pu = add(f->pu, (size_t)f->n_pu * sizeof(OhPu));
-    int s_tiles = add(tiles.data(), tiles.size() * sizeof(DevTile));
+    int s_mcl = add(mc_luma.data(), mc_luma.size() * sizeof(DevMcJob));
+    int s_mcc = add(mc_chroma.data(), mc_chroma.size() * sizeof(DevMcJob));
     int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
     int s_tu = add(f->tu, (size_t)f->n_tu * sizeof(OhTu));
     /* intra block descriptors: everything that depends only on geometry and mode is resolved here */
@@ -607,7 +641,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             fill_planes(&hd.refs[i], r, r->final_b);
     }
     hd.pu = (const OhPu *)(base + seg[s_pu].off);
-    hd.tiles = (const DevTile *)(base + seg[s_tiles].off);
+    hd.mc_luma = (const DevMcJob *)(base + seg[s_mcl].off);
+    hd.mc_chroma = (const DevMcJob *)(base + seg[s_mcc].off);
     hd.wp = (const OhWeights *)(base + seg[s_wp].off);
     hd.tu = (const OhTu *)(base + seg[s_tu].off);
     hd.coeffs = (const int16_t *)(base + seg[s_coef].off);
@@ -621,7 +656,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.is_pcm = f->is_pcm ? (const uint8_t *)(base + seg[s_pcm].off) : nullptr;
     hd.db = (const OhDeblockCtb *)(base + seg[s_db].off);
     hd.sao = has_sao ? (const OhSaoCtb *)(base + seg[s_sao].off) : nullptr;
-    hd.n_pu = f->n_pu; hd.n_tiles = (uint32_t)tiles.size(); hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
+    hd.n_pu = f->n_pu; hd.n_mc_luma = (uint32_t)mc_luma.size(); hd.n_mc_chroma = (uint32_t)mc_chroma.size(); hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
     hd.dbg = e->dbg;
     (void)s_hdr;
 
@@ -644,7 +679,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     }
     df->d = (DevFrame *)base;
     df->p = p;
-    df->n_tiles = hd.n_tiles; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
+    df->n_mc_luma = hd.n_mc_luma; df->n_mc_chroma = hd.n_mc_chroma; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
     df->has_sao = has_sao;
     if (f->n_intra) {
         df->level_start.assign(f->level_start, f->level_start + f->n_levels + 1);
@@ -682,7 +717,7 @@ extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
         HIPCHK(e, hipEventRecord(es.ev[0], st));
     }
 #define MARK(k) do { if (prof) HIPCHK(e, hipEventRecord(es.ev[(k) + 1], st)); } while (0)
-    ohk_inter(df->d, &df->p, df->n_tiles, st);
+    ohk_inter(df->d, &df->p, df->n_mc_luma, df->n_mc_chroma, st);
     MARK(OH_PASS_INTER);
     ohk_residual(df->d, &df->p, df->n_tu, st);
     MARK(OH_PASS_RESIDUAL);

@@ -95,163 +95,245 @@ static __device__ __forceinline__ void store4(GLOBAL PX *p, int a, int b, int c,
  * pass 1: inter prediction — hevcdsp_template.c:610-1609 through the drivers hevc.c:1641-1949;
  * picture-edge emulation (videodsp_template.c:26-101) is coordinate clamping while loading.
  *
- * One wave per <=16x16 tile of one plane (TAPS = 8 luma, 4 chroma).  Lane layout per stage:
- *   load     8 rows x 8 column triples per step   (window <= 23x23, clamped coordinates)
- *   h-pass   8 rows x 8 column pairs per step     (TAPS+1 LDS reads feed two outputs)
- *   v-pass   16 columns x 4 row quads             (TAPS+3 LDS reads feed four outputs)
- * so every index is a shift/mask of the lane id, and the epilogue stores 16 consecutive samples per
- * row.  The h-pass result is kept as int16 in LDS exactly like the reference's tmp_array (:776).
+ * The pass is bound by VALU issue (a wave64 instruction occupies its SIMD for 4 cycles), so the kernel
+ * is built to spend few instructions per sample and to keep all 64 lanes busy whatever the PU size:
+ *   - the unit of work is a <=8x8 block of one plane (DevMcJob); a wave runs four of them, 16 lanes each;
+ *   - samples travel as 16-bit pairs in one dword and the taps are applied with v_dot2_i32_i16
+ *     (2 multiply-adds per instruction).  A filter output at an odd position uses the taps shifted by
+ *     one inside the pairs ((0,c0)(c1,c2)...(c7,0)), so no pair is ever re-aligned;
+ *   - the h-pass lane owns 2 rows x 4 columns and writes its result as VERTICAL pairs, which is the
+ *     operand layout the v-pass needs; the v-pass lane owns 2 x 2 outputs and stores them as pairs;
+ *   - full-sample positions run through the same code with a unit filter (shift 0), which gives exactly
+ *     the reference's copy / h-only / v-only variants (:610-700) without a divergent branch;
+ *   - the windows of both lists are fetched before the first wait.
+ * The h-pass result is kept as int16 exactly like the reference's tmp_array (:776).
  * ======================================================================================= */
-#define WIN_STRIDE 24
+template <int TAPS> struct McGeom {
+    static constexpr int WROWS = 8 + TAPS;                 /* window rows kept: bh + TAPS - 1 <= WROWS - 1 */
+    static constexpr int NSEG  = TAPS == 8 ? 4 : 3;        /* 4-sample segments per window row              */
+    static constexpr int WP    = TAPS == 8 ? 10 : 6;       /* window row pitch, dwords (sample pairs)       */
+    static constexpr int NIT   = WROWS / 4;                /* load steps: 4 rows x 4 segments per block     */
+    static constexpr int NPD   = TAPS / 2 + 2;             /* pairs an h-pass lane reads per row            */
+    static constexpr int NCO   = TAPS + 1;                 /* packed taps: TAPS/2 even-position + TAPS/2+1 odd-position pairs */
+    static constexpr int CS    = TAPS + 2;                 /* pitch of one fraction in the tap table        */
+    static constexpr int NFR   = TAPS == 8 ? 4 : 8;        /* fractions; entry NFR = unit << (14 - bit_depth) */
+};
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef uint2v uint2v_a2 __attribute__((aligned(2)));
+typedef unsigned unsigned_a1 __attribute__((aligned(1)));
+static __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
+}
+static __device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+
+/* four consecutive samples at any sample address -> two dwords of 16-bit pairs */
+static __device__ __forceinline__ uint2v load4_pairs(const GLOBAL uint8_t *p)
+{
+    const unsigned b = *(const GLOBAL unsigned_a1 *)p;
+    return uint2v{ __builtin_amdgcn_perm(0, b, 0x0c010c00), __builtin_amdgcn_perm(0, b, 0x0c030c02) };
+}
+static __device__ __forceinline__ uint2v load4_pairs(const GLOBAL uint16_t *p) { return *(const GLOBAL uint2v_a2 *)p; }
+
 template <typename PX, int TAPS>
 __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
 {
-    __shared__ uint16_t win[24 * WIN_STRIDE];
-    __shared__ int16_t  tmp[24 * 16];
-    const int lane = threadIdx.x;
-    const int c = TAPS == 8 ? 0 : 1 + blockIdx.y;
-    /* XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
-     * tiles are recorded in CTU / z-scan order (neighbours adjacent in the list).  Give every XCD one
-     * CONTIGUOUS eighth of the list so that the overlapping interpolation windows of neighbouring
-     * tiles hit the same L2 instead of being fetched from HBM once per XCD. */
-    const uint32_t nt = f->n_tiles, per = (nt + 7) >> 3;
-    const uint32_t tile_idx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile_idx >= nt)
-        return;
-    const DevTile t = gload(f->tiles + tile_idx);
-    const OhPu pu = gload(f->pu + t.pu);
+    typedef McGeom<TAPS> G;
+    constexpr bool LUMA = TAPS == 8;
+    constexpr int before = TAPS / 2 - 1, HT = TAPS / 2;
+    __shared__ __attribute__((aligned(16))) unsigned win[4][G::WROWS * G::WP + 8];   /* +8: the four blocks start on different banks */
+    __shared__ __attribute__((aligned(16))) unsigned tmp[4][G::WROWS / 2 * 8];
+    __shared__ __attribute__((aligned(8)))  unsigned ctab[(G::NFR + 1) * G::CS];
+    __shared__ const void *refp[OH_MAX_REFS][2];
+    const int lane = threadIdx.x, s = lane >> 4, sl = lane & 15;
     const OhPicParams &pp = f->pp;
     const int bd = pp.bit_depth;
-    const int hs = hsh(pp, c), vs = vsh(pp, c);
-    constexpr int before = TAPS / 2 - 1;
-    const int bx = (pu.x + t.ox) >> hs, by = (pu.y + t.oy) >> vs;
-    const int bw = t.w >> hs, bh = t.h >> vs;
-    const int ww = bw + TAPS - 1, wh = bh + TAPS - 1;
-    const int lr = lane >> 3, lg = lane & 7;               /* load / h-pass layout */
-    const int vx = lane & 15, vy = (lane >> 4) * 4;         /* v-pass layout: column vx, rows vy..vy+3 */
-    int v[2][4];
+    const int hs = LUMA ? 0 : hsh(pp, 1), vs = LUMA ? 0 : vsh(pp, 1);
 
-    for (int l = 0; l < 2; l++) {
-        if (pu.ref[l] == OH_NO_REF)
-            continue;
-        const DevPlanes &rp = f->refs[pu.ref[l]];
-        const GLOBAL PX *__restrict__ src = G_CONST(PX, rp.p[c]);
-        const int sstride = rp.stride[c], pw = rp.w[c], ph = rp.h[c];
-        const int mvx = pu.mv[l][0], mvy = pu.mv[l][1];
-        int fx, fy, ix, iy;
-        if (TAPS == 8) {
+    /* XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), blocks
+     * are listed in CTU / z-scan order.  Every XCD takes one CONTIGUOUS eighth of the list so that the
+     * overlapping windows of neighbouring blocks hit the same L2. */
+    const uint32_t nj = LUMA ? f->n_mc_luma : f->n_mc_chroma;
+    const uint32_t nw = (nj + 3) >> 2, per = (nw + 7) >> 3;
+    const uint32_t widx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (widx >= nw)
+        return;
+    const uint32_t jidx = widx * 4 + s;
+    const bool live = jidx < nj;                            /* a dead quarter repeats the last block and stores nothing */
+    const DevMcJob job = gload((LUMA ? f->mc_luma : f->mc_chroma) + (live ? jidx : nj - 1));
+
+    /* per-wave tables: reference plane pointers and the packed taps */
+    if (lane < OH_MAX_REFS * (LUMA ? 1 : 2)) {
+        const int r = LUMA ? lane : lane >> 1, pl = LUMA ? 0 : lane & 1;
+        refp[r][pl] = f->refs[r].p[LUMA ? 0 : 1 + pl];
+    }
+    if (lane < (G::NFR + 1) * G::NCO) {
+        const int fr = lane / G::NCO, q = lane - fr * G::NCO;
+        int k0, k1;                                         /* tap indices of the pair; -1 / TAPS = outside */
+        if (q < HT) { k0 = 2 * q; k1 = 2 * q + 1; } else { k0 = 2 * (q - HT) - 1; k1 = 2 * (q - HT); }
+        auto tap = [&](int k) -> int {
+            if (k < 0 || k >= TAPS) return 0;
+            if (fr == 0) return k == before;
+            if (fr == G::NFR) return k == before ? 1 << (14 - bd) : 0;
+            return LUMA ? c_qpel[fr][k] : c_epel[fr][k];
+        };
+        ctab[fr * G::CS + q] = pack2(tap(k0), tap(k1));
+    }
+    const int pw = f->cur.w[LUMA ? 0 : 1], ph = f->cur.h[LUMA ? 0 : 1], stride = f->cur.stride[LUMA ? 0 : 1];
+    const int bw = job.w, bh = job.h, wh = bh + TAPS - 1;
+    const bool two = job.ref[1] != OH_NO_REF;
+    const bool any_two = __builtin_amdgcn_ballot_w64(two) != 0;
+    __syncthreads();
+
+    /* window of one list -> registers: step `it` covers rows 4it..4it+3, lane = (row, 4-sample segment) */
+    const int lrow = sl >> 2, seg = sl & 3;
+    auto fetch = [&](const int l, const bool on, uint2v (&W)[G::NIT], int &fx, int &fy) {
+        const int mvx = job.mv[l][0], mvy = job.mv[l][1];
+        int ix, iy;
+        if (LUMA) {
             fx = mvx & 3; fy = mvy & 3; ix = mvx >> 2; iy = mvy >> 2;
-        } else {                                    /* hevc.c:1807-1813 */
+        } else {                                            /* hevc.c:1807-1813 */
             fx = (mvx & ((1 << (2 + hs)) - 1)) << (1 - hs);
             fy = (mvy & ((1 << (2 + vs)) - 1)) << (1 - vs);
             ix = mvx >> (2 + hs); iy = mvy >> (2 + vs);
         }
-        const int wx0 = bx + ix - before, wy0 = by + iy - before;
-        /* window -> LDS */
 #pragma unroll
-        for (int it = 0; it < 3; it++) {
-            const int r = lr + 8 * it;
-            if (r < wh) {
-                const GLOBAL PX *row = src + (size_t)clip3(wy0 + r, 0, ph - 1) * sstride;
+        for (int it = 0; it < G::NIT; it++) W[it] = uint2v{ 0, 0 };
+        if (!on || seg >= G::NSEG)
+            return;
+        const GLOBAL PX *__restrict__ src = (const GLOBAL PX *)refp[job.ref[l]][LUMA ? 0 : job.c_idx - 1];
+        const int gx = job.x + ix - before + 4 * seg, wy0 = job.y + iy - before;
+        const bool inside = gx >= 0 && gx + 3 < pw;
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const int col = lg * 3 + j;
-                    if (col < ww)
-                        win[r * WIN_STRIDE + col] = row[clip3(wx0 + col, 0, pw - 1)];
+        for (int it = 0; it < G::NIT; it++) {
+            const int row = 4 * it + lrow;
+            if (row >= wh)
+                continue;
+            const GLOBAL PX *rowp = src + (size_t)clip3(wy0 + row, 0, ph - 1) * stride;
+            if (inside)
+                W[it] = load4_pairs(rowp + gx);
+            else
+                W[it] = uint2v{ pack2(rowp[clip3(gx, 0, pw - 1)], rowp[clip3(gx + 1, 0, pw - 1)]),
+                                pack2(rowp[clip3(gx + 2, 0, pw - 1)], rowp[clip3(gx + 3, 0, pw - 1)]) };
+        }
+    };
+    /* one list: registers -> LDS window -> h-pass -> vertical pairs -> v-pass -> v[0..3] = (row 0: col 0, col 1; row 1: col 0, col 1) */
+    auto filter = [&](const uint2v (&W)[G::NIT], const int fx, const int fy, int (&v)[4]) {
+        if (seg < G::NSEG) {
+#pragma unroll
+            for (int it = 0; it < G::NIT; it++)
+                *(uint2v *)&win[s][(4 * it + lrow) * G::WP + 2 * seg] = W[it];
+        }
+        __syncthreads();
+        {
+            const int i = sl >> 1, g = sl & 1;              /* row pair i, columns 4g..4g+3 */
+            const int sh = fx ? bd - 8 : 0;
+            unsigned co[G::NCO];
+#pragma unroll
+            for (int q = 0; q < G::NCO; q++) co[q] = ctab[fx * G::CS + q];
+            if (i < G::WROWS / 2) {
+                int o[2][4];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    unsigned P[G::NPD];
+#pragma unroll
+                    for (int q = 0; q < G::NPD; q += 2) {
+                        const uint2v t = *(const uint2v *)&win[s][(2 * i + rr) * G::WP + 2 * g + q];
+                        P[q] = t.x; P[q + 1] = t.y;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        int acc = 0;
+                        if (j & 1) {
+#pragma unroll
+                            for (int q = 0; q <= HT; q++) acc = dot2(P[(j >> 1) + q], co[HT + q], acc);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < HT; q++) acc = dot2(P[(j >> 1) + q], co[q], acc);
+                        }
+                        o[rr][j] = acc >> sh;
+                    }
                 }
+                *(uint4v *)&tmp[s][i * 8 + 4 * g] = uint4v{ pack2(o[0][0], o[1][0]), pack2(o[0][1], o[1][1]), pack2(o[0][2], o[1][2]), pack2(o[0][3], o[1][3]) };
             }
         }
         __syncthreads();
-        /* horizontal pass (or copy) -> tmp[r][x], two outputs per lane and step */
-        const int8_t *cx = TAPS == 8 ? c_qpel[fx] : c_epel[fx];
-        int kx[TAPS];
+        {
+            const int cp = sl & 3, rp = sl >> 2;            /* columns 2cp, 2cp+1; rows 2rp, 2rp+1 */
+            const int fr = fy ? fy : (fx ? 0 : G::NFR);
+            const int sh = fy ? (fx ? 6 : bd - 8) : 0;
+            unsigned co[G::NCO];
 #pragma unroll
-        for (int k = 0; k < TAPS; k++) kx[k] = cx[k];
+            for (int q = 0; q < G::NCO; q++) co[q] = ctab[fr * G::CS + q];
+            uint2v T[HT + 1];
 #pragma unroll
-        for (int it = 0; it < 3; it++) {
-            const int r = lr + 8 * it, x = lg * 2;
-            if (r < wh && x < bw) {
-                int o0, o1;
-                if (fx) {
-                    int p[TAPS + 1];
+            for (int q = 0; q <= HT; q++) T[q] = *(const uint2v *)&tmp[s][(rp + q) * 8 + 2 * cp];
+            int e0 = 0, e1 = 0, o0 = 0, o1 = 0;
 #pragma unroll
-                    for (int k = 0; k <= TAPS; k++) p[k] = win[r * WIN_STRIDE + x + k];
-                    int s0 = 0, s1 = 0;
+            for (int q = 0; q < HT; q++) { e0 = dot2(T[q].x, co[q], e0); e1 = dot2(T[q].y, co[q], e1); }
 #pragma unroll
-                    for (int k = 0; k < TAPS; k++) { s0 += kx[k] * p[k]; s1 += kx[k] * p[k + 1]; }
-                    o0 = s0 >> (bd - 8); o1 = s1 >> (bd - 8);
-                } else {
-                    o0 = win[r * WIN_STRIDE + x + before]; o1 = win[r * WIN_STRIDE + x + 1 + before];
-                }
-                *(unsigned *)(tmp + r * 16 + x) = (unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16);
-            }
+            for (int q = 0; q <= HT; q++) { o0 = dot2(T[q].x, co[HT + q], o0); o1 = dot2(T[q].y, co[HT + q], o1); }
+            v[0] = e0 >> sh; v[1] = e1 >> sh; v[2] = o0 >> sh; v[3] = o1 >> sh;
         }
-        __syncthreads();
-        /* vertical pass (or copy): column vx, four rows */
-        const int8_t *cy = TAPS == 8 ? c_qpel[fy] : c_epel[fy];
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[l][j] = 0;
-        if (vx < bw && vy < bh) {
-            if (fy) {
-                int p[TAPS + 3];
-#pragma unroll
-                for (int k = 0; k < TAPS + 3; k++) p[k] = tmp[(vy + k) * 16 + vx];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int s = 0;
-#pragma unroll
-                    for (int k = 0; k < TAPS; k++) s += cy[k] * p[j + k];
-                    v[l][j] = fx ? (s >> 6) : (s >> (bd - 8));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int tv = tmp[(vy + j + before) * 16 + vx];
-                    v[l][j] = fx ? tv : (tv << (14 - bd));
-                }
-            }
-        }
-        __syncthreads();
+    };
+
+    uint2v WA[G::NIT], WB[G::NIT];
+    int fxa, fya, fxb = 0, fyb = 0, va[4], vb[4] = { 0, 0, 0, 0 };
+    fetch(0, true, WA, fxa, fya);
+    if (any_two)
+        fetch(1, two, WB, fxb, fyb);
+    filter(WA, fxa, fya, va);
+    if (any_two) {
+        __syncthreads();                                    /* the v-pass of list 0 has read tmp */
+        filter(WB, fxb, fyb, vb);
     }
 
-    if (vx >= bw || vy >= bh)
+    const int x = 2 * (sl & 3), y = 2 * (sl >> 2);
+    if (!live || x >= bw || y >= bh)
         return;
-    GLOBAL PX *__restrict__ dst = G_MUT(PX, f->cur.p[c]) + (size_t)(by + vy) * f->cur.stride[c] + bx + vx;
-    const int dstride = f->cur.stride[c];
-    const bool u0 = pu.ref[0] != OH_NO_REF, u1 = pu.ref[1] != OH_NO_REF;
-    const bool weighted = pu.wp != OH_NO_WP;
+    const int c = LUMA ? 0 : job.c_idx;
+    const bool weighted = job.wp != OH_NO_WP;
+    const bool from_l1 = job.flags & OH_MCF_FROM_L1;
     int w0 = 0, w1 = 0, o0 = 0, o1 = 0, denom = 0;
     if (weighted) {
-        const OhWeights wp = gload(f->wp + pu.wp);
+        const OhWeights wp = gload(f->wp + job.wp);
         w0 = wp.w[0][c]; w1 = wp.w[1][c];
         o0 = wp.o[0][c] * (1 << (bd - 8)); o1 = wp.o[1][c] * (1 << (bd - 8));
         denom = wp.log2_denom[c ? 1 : 0];
+        if (from_l1) { w0 = w1; o0 = o1; }
     }
+    int r[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (vy + j >= bh)
-            break;
-        int r;
-        if (u0 && u1) {
-            int a = (int16_t)v[0][j], b = v[1][j];              /* list 0 went through an int16 tmp, hevc.c:1761 */
+        if (two) {
+            const int a = (int16_t)va[j], b = vb[j];            /* list 0 went through an int16 tmp, hevc.c:1761 */
             if (!weighted) {
-                int shift = 15 - bd;
-                r = (b + a + (1 << (shift - 1))) >> shift;
+                const int shift = 15 - bd;
+                r[j] = (b + a + (1 << (shift - 1))) >> shift;
             } else {
-                int log2wd = denom + 14 - bd;
-                r = (b * w1 + a * w0 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
+                const int log2wd = denom + 14 - bd;
+                r[j] = (b * w1 + a * w0 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
             }
         } else {
-            int a = u0 ? v[0][j] : v[1][j];
+            const int a = va[j];
             if (!weighted) {
-                int shift = 14 - bd;
-                r = (a + (1 << (shift - 1))) >> shift;
+                const int shift = 14 - bd;
+                r[j] = (a + (1 << (shift - 1))) >> shift;
             } else {
-                int shift = denom + 14 - bd;
-                r = ((a * (u0 ? w0 : w1) + (1 << (shift - 1))) >> shift) + (u0 ? o0 : o1);
+                const int shift = denom + 14 - bd;
+                r[j] = ((a * w0 + (1 << (shift - 1))) >> shift) + o0;
             }
         }
-        dst[(size_t)j * dstride] = (PX)clip_px(r, bd);
+        r[j] = clip_px(r[j], bd);
+    }
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, f->cur.p[c]) + (size_t)(job.y + y) * stride + job.x + x;
+    if (sizeof(PX) == 1) {
+        *(GLOBAL uint16_t *)dst = (uint16_t)(r[0] | (r[1] << 8));
+        *(GLOBAL uint16_t *)(dst + stride) = (uint16_t)(r[2] | (r[3] << 8));
+    } else {
+        *(GLOBAL unsigned *)dst = pack2(r[0], r[1]);
+        *(GLOBAL unsigned *)(dst + stride) = pack2(r[2], r[3]);
     }
 }
 
@@ -1164,16 +1246,16 @@ extern "C" int ohk_init(void)
         else           hipLaunchKernelGGL(HIP_KERNEL_NAME(kern<uint16_t>), grid, block, 0, stream, __VA_ARGS__);  \
     } while (0)
 
-extern "C" void ohk_inter(const DevFrame *df, const OhPicParams *p, uint32_t n_tiles, hipStream_t st)
+extern "C" void ohk_inter(const DevFrame *df, const OhPicParams *p, uint32_t n_luma, uint32_t n_chroma, hipStream_t st)
 {
-    if (!n_tiles) return;
-    const unsigned gx = ((n_tiles + 7) >> 3) * 8;             /* 8 contiguous slices, one per XCD */
+    /* four blocks per wave; the grid is 8 contiguous slices of the block list, one per XCD */
+    const unsigned gl = ((((n_luma + 3) >> 2) + 7) >> 3) * 8, gc = ((((n_chroma + 3) >> 2) + 7) >> 3) * 8;
     if (p->bit_depth == 8) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 8>), dim3(gx), dim3(64), 0, st, df);
-        if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 4>), dim3(gx, 2), dim3(64), 0, st, df);
+        if (n_luma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 8>), dim3(gl), dim3(64), 0, st, df);
+        if (n_chroma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 4>), dim3(gc), dim3(64), 0, st, df);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 8>), dim3(gx), dim3(64), 0, st, df);
-        if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 4>), dim3(gx, 2), dim3(64), 0, st, df);
+        if (n_luma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 8>), dim3(gl), dim3(64), 0, st, df);
+        if (n_chroma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 4>), dim3(gc), dim3(64), 0, st, df);
     }
 }
 

@@ -27,12 +27,39 @@ struct DevMcJob {
 };                                /* 20 bytes */
 enum { OH_MCF_FROM_L1 = 1 };      /* uni-prediction whose only list is list 1 (selects the weights) */
 
-/* LDS geometry of the intra CTU kernel (kernels.hip: CtuLds); the host precomputes offsets into it */
+/* LDS layout of the intra CTU kernel.  The sample area (uint16 units) holds per plane `main`: hc rows of
+ * rs = wc + 4 entries, sample (x,y) at [y*rs + x + 4] (column -1 at +3), then per plane `top`: row -1,
+ * sample x at [x + 4], x in [-1, 2*wc).  The host resolves block offsets into it (DevIntra.cm_off/top_off);
+ * the per-launch arrays behind it (descriptors, sub-level table, residual, per-wave edges) are sized by
+ * the host from the level's CTUs (OhIntraLaunch). */
 #define OH_CTU_MAX 64
-#define OH_CTU_RS (OH_CTU_MAX + 4)                 /* row stride: 3 pad + column -1 + 64 samples */
-#define OH_CTU_TOP (2 * OH_CTU_MAX + 8)            /* row -1 of a plane: 3 pad + corner + 2*64 samples */
 #define OH_MAX_CTU_BLOCKS 768                      /* 64x64 4:4:4 all 4x4 */
-#define OH_RES_LDS_MAX (3 * OH_CTU_MAX * OH_CTU_MAX)
+#define OH_INTRA_WAVE_LDS 528                      /* per-wave edge arrays: 132 ints (kernels.hip: IntraLds) */
+struct OhCtuAreas { uint32_t main[3], top[3], total; };
+static __host__ __device__ inline OhCtuAreas oh_ctu_areas(int log2_ctb, int chroma_format_idc)
+{
+    OhCtuAreas a;
+    uint32_t off = 0;
+    const int np = chroma_format_idc ? 3 : 1, ctb = 1 << log2_ctb;
+    for (int c = 0; c < 3; c++) {
+        const int hs = c && (chroma_format_idc == 1 || chroma_format_idc == 2), vs = c && chroma_format_idc == 1;
+        a.main[c] = off;
+        if (c < np) off += (uint32_t)((ctb >> vs) * ((ctb >> hs) + 4));
+    }
+    for (int c = 0; c < 3; c++) {
+        const int hs = c && (chroma_format_idc == 1 || chroma_format_idc == 2);
+        a.top[c] = off;
+        if (c < np) off += (uint32_t)(2 * (ctb >> hs) + 8);
+    }
+    a.total = off;
+    return a;
+}
+struct OhIntraLaunch {                             /* one wavefront level = one launch */
+    uint32_t first_ctu, n_ctu;
+    uint32_t off_items, off_sub, off_res, off_wave, lds_bytes;   /* byte offsets into the dynamic LDS block */
+    uint16_t waves;                                /* waves per workgroup (CTU)                         */
+    uint16_t staged;                               /* 1: every CTU of the level has its residual span in LDS */
+};
 
 enum { OH_IF_FILTER = 1, OH_IF_STRONG_CAND = 2, OH_IF_EDGE = 4 };            /* DevIntra.flags bits 0..2 */
 enum { OH_IC_PLANAR = 0, OH_IC_DC, OH_IC_ANG_V, OH_IC_ANG_H, OH_IC_PURE_V, OH_IC_PURE_H };   /* flags >> 4 */
@@ -59,6 +86,8 @@ struct DevIntraCtu {
     uint32_t sub_first;
     uint16_t n_sub, ctu;
     uint32_t res_lo, res_cnt;     /* int16 elements; res_cnt == 0: blocks read their residual from HBM */
+    int16_t  bx0, bx1, by0, by1;  /* CTU-local luma rectangle [x0,x1) x [y0,y1) that covers every sample a block of the
+                                     CTU reads (its row above and column to the left, up to 2n): what gets staged */
 };
 
 struct DevFrame {

@@ -39,7 +39,7 @@ struct OhDevFrame {
     uint32_t   n_mc_luma = 0, n_mc_chroma = 0, n_tu = 0, n_intra = 0;
     bool       has_sao = false;
     std::vector<uint32_t> level_start;
-    std::vector<uint8_t>  level_staged;   /* 1: every CTU of the level has its residual span staged in LDS */
+    std::vector<OhIntraLaunch> launches;  /* one per wavefront level: CTU range, LDS carve-up, waves per CTU */
 };
 
 struct OhEngine {
@@ -548,6 +548,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     static const int8_t k_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
                                         -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };      /* hevcpred_template.c:430-433 */
     static const int16_t k_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+    const OhCtuAreas areas = oh_ctu_areas(p.log2_ctb_size, p.chroma_format_idc);
     std::vector<DevIntra> dintra(f->n_intra);
     for (uint32_t i = 0; i < f->n_intra; i++) {
         const OhIntra &it = f->intra[i];
@@ -559,8 +560,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         d.x = it.x; d.y = it.y; d.c_idx = it.c_idx; d.log2_size = it.log2_size; d.mode = it.mode; d.avail = it.avail;
         d.res_off = it.tu == OH_NO_COEFF ? OH_NO_COEFF : f->tu[it.tu].coeff_off;
         d.rs = (uint16_t)rs;
-        d.cm_off = (uint16_t)(c * OH_CTU_MAX * OH_CTU_RS + ly * rs + lx + 4);
-        d.top_off = (uint16_t)(ly == 0 ? 3 * OH_CTU_MAX * OH_CTU_RS + c * OH_CTU_TOP + lx + 4 : d.cm_off - rs);
+        d.cm_off = (uint16_t)(areas.main[c] + ly * rs + lx + 4);
+        d.top_off = (uint16_t)(ly == 0 ? areas.top[c] + lx + 4 : d.cm_off - rs);
         int tr = (it.x + 2 * n < cur->w[c] ? it.x + 2 * n : cur->w[c]) - (it.x + n);
         int bl = (it.y + 2 * n < cur->h[c] ? it.y + 2 * n : cur->h[c]) - (it.y + n);
         d.tr_size = (uint8_t)(tr < 0 ? 0 : tr); d.bl_size = (uint8_t)(bl < 0 ? 0 : bl);
@@ -594,8 +595,15 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         DevIntraCtu &d = dictu[k];
         d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu;
         uint64_t lo = UINT64_MAX, hi = 0;
+        int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
         for (uint32_t b = f->sub_start[c.sub_first]; b < f->sub_start[c.sub_first + c.n_sub]; b++) {
             const DevIntra &it = dintra[b];
+            {
+                const int hs = oh_hshift(&p, it.c_idx), vs = oh_vshift(&p, it.c_idx), lc = p.log2_ctb_size, n = 1 << it.log2_size;
+                const int lx = it.x - ((((it.x << hs) >> lc) << lc) >> hs), ly = it.y - ((((it.y << vs) >> lc) << lc) >> vs);
+                bx0 = std::min(bx0, (lx - 1) * (1 << hs)); bx1 = std::max(bx1, (lx + 2 * n) << hs);
+                by0 = std::min(by0, (ly - 1) * (1 << vs)); by1 = std::max(by1, (ly + 2 * n) << vs);
+            }
             if (it.res_off == OH_NO_COEFF)
                 continue;
             uint64_t e = (uint64_t)it.res_off + (1u << (2 * it.log2_size));
@@ -603,6 +611,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             if (e > hi) hi = e;
         }
         d.res_lo = 0; d.res_cnt = 0;
+        d.bx0 = (int16_t)bx0; d.bx1 = (int16_t)bx1; d.by0 = (int16_t)by0; d.by1 = (int16_t)by1;
         if (hi > lo && (lo & 3) == 0 && hi - lo <= 3u * 64 * 64) {
             d.res_lo = (uint32_t)lo;
             d.res_cnt = (uint32_t)((hi - lo + 3) & ~3ull);
@@ -683,15 +692,38 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     df->has_sao = has_sao;
     if (f->n_intra) {
         df->level_start.assign(f->level_start, f->level_start + f->n_levels + 1);
-        df->level_staged.assign(f->n_levels, 1);
-        for (uint32_t l = 0; l < f->n_levels; l++)
+        const char *wenv = getenv("OHEVC_INTRA_WAVES");                /* experiments: force the waves per CTU */
+        df->launches.resize(f->n_levels);
+        for (uint32_t l = 0; l < f->n_levels; l++) {
+            OhIntraLaunch &L = df->launches[l];
+            L.first_ctu = f->level_start[l];
+            L.n_ctu = f->level_start[l + 1] - f->level_start[l];
+            L.staged = 1;
+            uint32_t max_items = 1, max_sub = 1, max_res = 0;
+            uint64_t sum_items = 0, sum_sub = 0;
             for (uint32_t k = f->level_start[l]; k < f->level_start[l + 1]; k++) {
+                const uint32_t b0 = f->sub_start[dictu[k].sub_first], b1 = f->sub_start[dictu[k].sub_first + dictu[k].n_sub];
                 bool any_res = false;
-                for (uint32_t b = f->sub_start[dictu[k].sub_first]; b < f->sub_start[dictu[k].sub_first + dictu[k].n_sub] && !any_res; b++)
+                for (uint32_t b = b0; b < b1 && !any_res; b++)
                     any_res = dintra[b].res_off != OH_NO_COEFF;
                 if (any_res && !dictu[k].res_cnt)
-                    df->level_staged[l] = 0;
+                    L.staged = 0;
+                max_items = std::max(max_items, std::min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
+                max_sub = std::max(max_sub, std::min((uint32_t)dictu[k].n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
+                max_res = std::max(max_res, dictu[k].res_cnt);
+                sum_items += b1 - b0; sum_sub += dictu[k].n_sub;
             }
+            /* waves per CTU: as many as blocks run side by side in a sub-level (more only hold LDS and wave slots) */
+            const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;
+            L.waves = (uint16_t)(wenv ? atoi(wenv) : par > 2.5 ? 8 : par > 1.25 ? 4 : 2);
+            if (L.waves < 1 || L.waves > 8) L.waves = 8;
+            size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
+            L.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
+            L.off_sub = (uint32_t)off;   off = align_up(off + ((size_t)max_sub + 1) * sizeof(uint32_t), 16);
+            L.off_res = (uint32_t)off;   off = align_up(off + (L.staged ? (size_t)max_res * sizeof(int16_t) : 0), 16);
+            L.off_wave = (uint32_t)off;  off += (size_t)L.waves * OH_INTRA_WAVE_LDS;
+            L.lds_bytes = (uint32_t)off;
+        }
     }
     cur->final_b = has_sao;
     *out = df;
@@ -730,7 +762,7 @@ extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
             }
             HIPCHK(e, hipEventRecord(a, st));
         }
-        ohk_intra_level(df->d, &df->p, df->level_start[l], df->level_start[l + 1] - df->level_start[l], df->level_staged[l], st);
+        ohk_intra_level(df->d, &df->p, &df->launches[l], st);
         if (prof_launch) {
             HIPCHK(e, hipEventRecord(b, st));
             e->lev_pending.push_back(a);

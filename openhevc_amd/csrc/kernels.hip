@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
  * costs a handful of LDS round trips per block inside one CU — no kernel launch, no HBM round
  * trip.  CTUs of one launch are mutually independent (same wavefront level, recorder.c).
  * ======================================================================================= */
-#define INTRA_WAVES 8
+#define INTRA_MAX_WAVES 8
 /* diagnostic build (-DOH_STAMPS, tools/intra_stamps.py): in-kernel cycle accounting of workgroup 0 */
 #ifdef OH_STAMPS
 #define STAMP(var) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; } while (0)
@@ -524,15 +524,7 @@ __global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict
 #define STAMP(var) do { } while (0)
 #define ACC(slot, t0, t1) do { } while (0)
 #endif
-struct IntraLds { int E[132]; };                   /* E[0..65] = left[-1..64), E[66..131] = top[-1..64), per wave */
-struct __attribute__((aligned(16))) CtuLds {
-    uint16_t main[3][OH_CTU_MAX * OH_CTU_RS];      /* sample (x,y) of plane c at [y*rs + x + 4], rs = wc + 4 */
-    uint16_t top[3][OH_CTU_TOP];                   /* row -1: sample x at [x + 4]; directly behind main[]    */
-    DevIntra items[OH_MAX_CTU_BLOCKS];
-    uint32_t sub[OH_MAX_CTU_BLOCKS + 2];
-    int16_t  res[OH_RES_LDS_MAX];                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
-};
-
+struct IntraLds { int E[OH_INTRA_WAVE_LDS / 4]; };                   /* E[0..65] = left[-1..64), E[66..131] = top[-1..64), per wave */
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 /* workgroup barrier that waits for LDS traffic only (global stores of finished samples stay in flight) */
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -554,8 +546,8 @@ static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, GLOBAL P
 
 template <typename PX, bool STAGED>
 static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
-                                                   const uint4v *__restrict__ item, IntraLds &s, CtuLds &ct, const int lane,
-                                                   unsigned long long *acc)
+                                                   const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
+                                                   const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
 {
     unsigned long long ta = 0, tb = 0, tc = 0, td = 0; (void)ta; (void)tb; (void)tc; (void)td; (void)acc;
     STAMP(ta);
@@ -569,7 +561,6 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
     const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
     const int n = 1 << log2, cls = flags >> 4;
-    uint16_t *__restrict__ M = &ct.main[0][0];
     const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
     const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
     const int i = lane;                                                /* element this lane owns */
@@ -583,7 +574,7 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
         rv[k] = short4v{ 0, 0, 0, 0 };
         const int g = lane + 64 * k;
         if (has_res && g < ngroups) {
-            if (STAGED) rv[k] = *(const short4v *)(ct.res + res_lds + 4 * g);
+            if (STAGED) rv[k] = *(const short4v *)(res_lds_base + res_lds + 4 * g);
             else        rv[k] = *((const GLOBAL short4v *)(f->res + res_off) + g);       /* slow path: dependent HBM load */
         }
     }
@@ -755,18 +746,23 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
 }
 
 template <typename PX, bool STAGED>
-__global__ __launch_bounds__(64 * INTRA_WAVES) void intra_ctu_kernel(const DevFrame *__restrict__ f, uint32_t first_ctu)
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const DevFrame *__restrict__ f, const OhIntraLaunch L)
 {
-    __shared__ IntraLds lds[INTRA_WAVES];
-    __shared__ CtuLds ct;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const DevIntraCtu ctu = gload(f->ictu + first_ctu + blockIdx.x);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *__restrict__ M = (uint16_t *)smem;                                  /* sample area, oh_ctu_areas() */
+    DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
+    uint32_t *__restrict__ sub = (uint32_t *)(smem + L.off_sub);
+    int16_t *__restrict__ res_l = (int16_t *)(smem + L.off_res);                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
+    IntraLds &edges = *(IntraLds *)(smem + L.off_wave + wave * OH_INTRA_WAVE_LDS);
+    const DevIntraCtu ctu = gload(f->ictu + L.first_ctu + blockIdx.x);
     const GLOBAL uint32_t *__restrict__ ss = G_CONST(uint32_t, f->sub_start) + ctu.sub_first;
     const OhPicParams &pp = f->pp;
     const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc;
     const int cx0 = (ctu.ctu % ctbw) << lc, cy0 = (ctu.ctu / ctbw) << lc;      /* luma origin of the CTU */
     const int n_sub = min((int)ctu.n_sub, OH_MAX_CTU_BLOCKS);
     const int bd = pp.bit_depth;
+    const OhCtuAreas ar = oh_ctu_areas(lc, pp.chroma_format_idc);
     PlaneRegs pr;
     pr.base[0] = (uint64_t)f->cur.p[0]; pr.base[1] = (uint64_t)f->cur.p[1]; pr.base[2] = (uint64_t)f->cur.p[2];
     pr.stride[0] = f->cur.stride[0]; pr.stride[1] = f->cur.stride[1];
@@ -775,34 +771,39 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void intra_ctu_kernel(const DevFr
     const uint32_t item0 = ss[0], n_items = min(ss[n_sub] - item0, (uint32_t)OH_MAX_CTU_BLOCKS);
     {
         const GLOBAL uint4v *__restrict__ src = (const GLOBAL uint4v *)(f->intra + item0);
-        uint4v *dst = (uint4v *)ct.items;
-        for (uint32_t e = tid; e < n_items * 2; e += 64 * INTRA_WAVES) dst[e] = src[e];
-        for (int e = tid; e <= n_sub; e += 64 * INTRA_WAVES) ct.sub[e] = ss[e] - item0;
+        uint4v *dst = (uint4v *)items;
+        for (uint32_t e = tid; e < n_items * 2; e += nthr) dst[e] = src[e];
+        for (int e = tid; e <= n_sub; e += nthr) sub[e] = ss[e] - item0;
         /* the CTU's residual blocks: one coalesced sweep instead of a dependent load per block */
         const GLOBAL short4v *__restrict__ rsrc = (const GLOBAL short4v *)(f->res + ctu.res_lo);
         if (STAGED)
-            for (uint32_t e = tid; e < ctu.res_cnt / 4; e += 64 * INTRA_WAVES) ((short4v *)ct.res)[e] = rsrc[e];
+            for (uint32_t e = tid; e < ctu.res_cnt / 4; e += nthr) ((short4v *)res_l)[e] = rsrc[e];
     }
-    /* stage the CTU: samples already reconstructed by passes 1-2 (inter), the column left of it and
-     * the row above it (up to 2*wc samples: the up-right CTU) — all final by the wavefront order */
+    /* stage the part of the CTU its blocks read (DevIntraCtu.bx0..by1): samples reconstructed by passes
+     * 1-2 (inter), the column left of the CTU and the row above it (up to 2*wc samples: the up-right CTU) —
+     * all final by the wavefront order.  Rows go as 4-sample vectors, 16 per row and step. */
     const int nplanes = pp.chroma_format_idc ? 3 : 1;
     for (int c = 0; c < nplanes; c++) {
         const int hs = hsh(pp, c), vs = vsh(pp, c);
-        const int wc = (1 << lc) >> hs, hc = (1 << lc) >> vs, rs = wc + 4, cols = wc + 1;
+        const int wc = (1 << lc) >> hs, hc = (1 << lc) >> vs, rs = wc + 4;
         const int x0 = cx0 >> hs, y0 = cy0 >> vs, pw = f->cur.w[c], ph = f->cur.h[c], stride = f->cur.stride[c];
+        const int px0 = ctu.bx0 >> hs, px1 = (ctu.bx1 + (1 << hs) - 1) >> hs, py0 = ctu.by0 >> vs, py1 = (ctu.by1 + (1 << vs) - 1) >> vs;
         const GLOBAL PX *__restrict__ g = G_CONST(PX, f->cur.p[c]);
-        for (int e = tid; e < hc * cols; e += 64 * INTRA_WAVES) {
-            int yy = e / cols, xx = e - yy * cols - 1;
-            int gx = x0 + xx, gy = y0 + yy;
-            if (gx >= 0 && gx < pw && gy < ph)
-                ct.main[c][yy * rs + xx + 4] = g[(size_t)gy * stride + gx];
+        uint16_t *__restrict__ Mm = M + ar.main[c], *__restrict__ Mt = M + ar.top[c];
+        const int r0 = max(py0, 0), r1 = min(min(py1, hc), ph - y0);
+        const int cs = max(px0, 0) & ~3, ce = min(min((px1 + 3) & ~3, wc), pw - x0);
+        const int seg = tid & 15;
+        if (cs + 4 * seg < ce)
+            for (int row = r0 + (tid >> 4); row < r1; row += nthr >> 4)
+                *(uint2v *)&Mm[row * rs + cs + 4 * seg + 4] = load4_pairs(g + (size_t)(y0 + row) * stride + x0 + cs + 4 * seg);
+        if (px0 < 0 && x0 > 0)
+            for (int row = r0 + tid; row < r1; row += nthr)
+                Mm[row * rs + 3] = g[(size_t)(y0 + row) * stride + x0 - 1];
+        if (py0 < 0 && y0 > 0) {
+            const int t0 = max(px0, x0 > 0 ? -1 : 0), t1 = min(min(px1, 2 * wc), pw - x0);
+            for (int xx = t0 + tid; xx < t1; xx += nthr)
+                Mt[xx + 4] = g[(size_t)(y0 - 1) * stride + x0 + xx];
         }
-        if (y0 > 0)
-            for (int e = tid; e < 2 * wc + 1; e += 64 * INTRA_WAVES) {
-                int gx = x0 + e - 1;
-                if (gx >= 0 && gx < pw)
-                    ct.top[c][e + 3] = g[(size_t)(y0 - 1) * stride + gx];
-            }
     }
     __syncthreads();
     unsigned long long acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t0 = 0, t1 = 0, t2 = 0, tk = 0, rt1 = 0; (void)acc; (void)t0; (void)t1; (void)t2; (void)tk; (void)rt1;
@@ -813,9 +814,9 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void intra_ctu_kernel(const DevFr
 
     for (int s = 0; s < n_sub; s++) {
         STAMP(t0);
-        const uint32_t b1 = ct.sub[s + 1];
-        for (uint32_t b = ct.sub[s] + wave; b < b1; b += INTRA_WAVES)
-            intra_block<PX, STAGED>(f, bd, pr, (const uint4v *)&ct.items[b], lds[wave], ct, lane, acc);
+        const uint32_t b1 = sub[s + 1];
+        for (uint32_t b = sub[s] + wave; b < b1; b += nwaves)
+            intra_block<PX, STAGED>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, lane, acc);
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
         STAMP(t2);
@@ -1237,6 +1238,13 @@ extern "C" int ohk_init(void)
         for (int i = 0; i < 4; i++) basis[4][k * 4 + i] = dst7[k][i];
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_basis), basis, sizeof(basis)) != hipSuccess)
         return -1;
+    /* the intra kernel's LDS block is sized per launch and exceeds 64 KiB for 4:4:4 CTUs full of 4x4 blocks */
+    const int max_lds = 128 * 1024;
+    if (hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+        return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dct), m, sizeof(m)) == hipSuccess ? 0 : -1;
 }
 
@@ -1265,16 +1273,16 @@ extern "C" void ohk_residual(const DevFrame *df, const OhPicParams *p, uint32_t 
     LAUNCH_BY_DEPTH(p->bit_depth, residual_kernel, dim3(n_tu), dim3(64), st, df);
 }
 
-extern "C" void ohk_intra_level(const DevFrame *df, const OhPicParams *p, uint32_t first_ctu, uint32_t n_ctu, int staged, hipStream_t st)
+extern "C" void ohk_intra_level(const DevFrame *df, const OhPicParams *p, const OhIntraLaunch *l, hipStream_t st)
 {
-    if (!n_ctu) return;
-    dim3 g(n_ctu), b(64 * INTRA_WAVES);
+    if (!l->n_ctu) return;
+    dim3 g(l->n_ctu), b(64 * l->waves);
     if (p->bit_depth == 8) {
-        if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, true>), g, b, 0, st, df, first_ctu);
-        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, false>), g, b, 0, st, df, first_ctu);
+        if (l->staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, true>), g, b, l->lds_bytes, st, df, *l);
+        else           hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, false>), g, b, l->lds_bytes, st, df, *l);
     } else {
-        if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, true>), g, b, 0, st, df, first_ctu);
-        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, false>), g, b, 0, st, df, first_ctu);
+        if (l->staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, true>), g, b, l->lds_bytes, st, df, *l);
+        else           hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, false>), g, b, l->lds_bytes, st, df, *l);
     }
 }
 

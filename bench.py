@@ -8,8 +8,10 @@ One STEP is one wave-scheduled group of pictures per GPU (openhevc_amd/parallel.
 3 reference B pictures and 12 non-reference B pictures of the workload's geometry, work lists
 already resident in HBM (uploaded before the timed region; the PCIe-inclusive rate is a separate
 figure in DESIGN.md).  Steps are closed GOPs (they start with an I picture), so --chains of them are
-kept in flight per GPU, each on its own HIP stream: the GPU form of the reference's frame threads
-(pthread_frame.c).  With N GPUs every rank decodes its own 16 pictures per step and the four
+kept in flight per GPU: the GPU form of the reference's frame threads (pthread_frame.c).  The chains
+are split over --streams HIP streams; the chains of one stream advance in LOCKSTEP, i.e. picture k of
+all of them is one batch of independent pictures and every pass is one launch over the batch
+(oh_frames_execute), which fills the GPU where a single picture's dependency chain cannot.  With N GPUs every rank decodes its own 16 pictures per step and the four
 reference pictures of every rank are replicated with one RCCL all-gather per wave (weak scaling).
 Rank 0 prints ONE JSON line.
 """
@@ -63,7 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
-    ap.add_argument("--chains", type=int, default=16, help="closed GOPs (steps) in flight per GPU, one HIP stream each")
+    ap.add_argument("--chains", type=int, default=32, help="closed GOPs (steps) in flight per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,13 +75,14 @@ def main():
 
     # One HIP stream per chain only overlaps if the runtime maps them to distinct hardware queues
     # (ROCm default: 4).  Must be set before the HIP runtime starts.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.chains, 24))))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.streams + 2, 24))))
 
     import torch
     import torch.distributed as dist
 
     from openhevc_amd import frame as F
     from openhevc_amd import parallel as P
+    from openhevc_amd.engine import Engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,15 +101,23 @@ def main():
 
     params = F.pic_params(**WORKLOADS[args.workload])
     n_chains = max(1, args.chains)
-    chains = []                                            # (plan, backend, stream, process group)
+    n_streams = max(1, min(args.streams, n_chains))
+    groups = [[] for _ in range(n_streams)]                # per stream: [(plan, backend, process group)], one engine
+    chains = []
     for k in range(n_chains):
         plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + k)
         plan_k = P.make_step_plan(world, rank, **plan_kwargs)
-        stream = torch.cuda.Stream()
-        with torch.cuda.stream(stream):                    # the engine adopts the current stream
-            be_k = P.EngineBackend(torch, local_rank, params, plan_k)
+        g = groups[k % n_streams]
+        if not g:                                          # [0] = (stream, engine) of the group
+            stream = torch.cuda.Stream()
+            g.append((stream, Engine(local_rank, stream=stream.cuda_stream)))
+        stream, engine = g[0]
+        with torch.cuda.stream(stream):
+            be_k = P.EngineBackend(torch, local_rank, params, plan_k, engine=engine)
         group = dist.new_group() if world > 1 else None    # collectives of different chains must not share a communicator
+        g.append((plan_k, be_k, group))
         chains.append((plan_k, be_k, stream, group))
+    engines = [g[0][1] for g in groups]
     plan, be = chains[0][0], chains[0][1]
     plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643)
     pics_per_step = P.pictures_per_step(plan)
@@ -116,24 +128,29 @@ def main():
         torch.cuda.synchronize()
 
     def run(n_steps):
-        for i in range(n_steps):
-            plan_k, be_k, stream, group = chains[i % n_chains]
-            with torch.cuda.stream(stream):
-                P.run_step(plan_k, be_k, dist if world > 1 else None, group)
+        """n_steps GOPs: the streams take turns, each turn advances every chain of the stream by one step"""
+        done, turn = 0, 0
+        while done < n_steps:
+            g = groups[turn % n_streams]
+            m = min(len(g) - 1, n_steps - done)
+            with torch.cuda.stream(g[0][0]):
+                P.run_steps_batched(g[1:1 + m], dist if world > 1 else None)
+            done += m
+            turn += 1
 
     run(max(args.warmup, n_chains))
     barrier()
-    for _, be_k, _, _ in chains:
-        be_k.engine.pass_times(reset=True)
-        be_k.engine.profile(0 if args.no_profile else 1)
+    for eng in engines:
+        eng.pass_times(reset=True)
+        eng.profile(0 if args.no_profile else 1)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     dt_enqueue = time.perf_counter() - t0                  # host time to record nothing and enqueue everything
     barrier()
     dt = time.perf_counter() - t0
-    for _, be_k, _, _ in chains:
-        be_k.engine.profile(0)
+    for eng in engines:
+        eng.profile(0)
     # roofline leg: with many streams overlapping, events around a launch measure queueing as much as
     # the kernel, so the per-launch durations of the multi-launch intra pass are taken on ONE chain
     # running alone right after the timed region (rocprofv3's per-dispatch average agrees with it)
@@ -159,11 +176,11 @@ def main():
     if rank == 0:
         b = 2 if params.bit_depth > 8 else 1
         pass_ms, n_exec, intra_ms, intra_n = None, 0, 0.0, 0
-        for _, be_k, _, _ in chains:                       # sum over the chains in flight
-            ms_k, n_k = be_k.engine.pass_times()
+        for eng in engines:                                # sum over the streams
+            ms_k, n_k = eng.pass_times()
             pass_ms = ms_k if pass_ms is None else {k: pass_ms[k] + ms_k[k] for k in ms_k}
             n_exec += n_k
-            im, inn = be_k.engine.intra_launch_times()
+            im, inn = eng.intra_launch_times()
             intra_ms += im
             intra_n += inn
         roofline = None
@@ -219,13 +236,16 @@ def main():
             "config": {"workload": args.workload, "width": params.width, "height": params.height, "bit_depth": params.bit_depth,
                        "chroma_format_idc": params.chroma_format_idc, "pictures_per_step_per_gpu": pics_per_step,
                        "step": f"1 I + {args.waves - 1} reference B + {args.tail} non-reference B pictures per GPU (a closed GOP)",
-                       "chains_in_flight_per_gpu": n_chains,
+                       "chains_in_flight_per_gpu": n_chains, "streams_per_gpu": n_streams,
+                       "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
                        "exchange": "one RCCL all-gather of the finished reference pictures per wave" if world > 1 else "none (1 GPU)",
                        "generator": dict(knobs, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
             "roofline": roofline,
         }
     for _, be_k, _, _ in chains:
         be_k.close()
+    for eng in engines:
+        eng.close()
     if rank == 0:
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:

@@ -79,6 +79,10 @@ int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3], const ptr
  * device frame (the coefficient pool is never modified). */
 int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out);
 int oh_frame_execute(OhEngine *e, OhDevFrame *df);
+/* n mutually independent pictures (none is a reference of another one; same OhPicParams): every pass
+ * is ONE launch over all of them, which is how pictures of independent sequences / GOPs (the reference's
+ * frame threads, pthread_frame.c) fill the GPU while each picture's own dependency chain is short of it */
+int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n);
 int oh_frame_free(OhEngine *e, OhDevFrame *df);
 int oh_frame_submit(OhEngine *e, const OhFrame *f);     /* upload + execute + deferred free */
 

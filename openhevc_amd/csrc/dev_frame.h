@@ -54,11 +54,10 @@ static __host__ __device__ inline OhCtuAreas oh_ctu_areas(int log2_ctb, int chro
     a.total = off;
     return a;
 }
-struct OhIntraLaunch {                             /* one wavefront level = one launch */
-    uint32_t first_ctu, n_ctu;
+struct OhIntraLaunch {                             /* one wavefront level of a batch of pictures = one launch */
+    uint32_t level;                                /* index into DevFrame.lvl_start / lvl_staged              */
     uint32_t off_items, off_sub, off_res, off_wave, lds_bytes;   /* byte offsets into the dynamic LDS block */
-    uint16_t waves;                                /* waves per workgroup (CTU)                         */
-    uint16_t staged;                               /* 1: every CTU of the level has its residual span in LDS */
+    uint32_t waves;                                /* waves per workgroup (CTU)                               */
 };
 
 enum { OH_IF_FILTER = 1, OH_IF_STRONG_CAND = 2, OH_IF_EDGE = 4 };            /* DevIntra.flags bits 0..2 */
@@ -105,6 +104,8 @@ struct DevFrame {
     const DevIntra  *intra;
     const DevIntraCtu *ictu;          /* CTUs with intra blocks in wavefront order             */
     const uint32_t  *sub_start;       /* sub-level ranges into intra[]                         */
+    const uint32_t  *lvl_start;       /* wavefront level ranges into ictu[]                    */
+    const uint8_t   *lvl_staged;      /* per level: 1 = every CTU has its residual span contiguous (staged in LDS) */
     const uint8_t   *vbs, *hbs;
     const int8_t    *qp;
     const uint8_t   *is_pcm;          /* may be null                                          */
@@ -113,5 +114,10 @@ struct DevFrame {
     uint32_t n_pu, n_mc_luma, n_mc_chroma, n_tu, n_intra;
     uint64_t *dbg;                    /* diagnostic builds only (OH_STAMPS), null otherwise       */
 };
+
+/* a batch of mutually independent pictures of one geometry: every pass is ONE launch over all of them
+ * (kernel argument; the picture is picked by a grid dimension) */
+#define OH_MAX_BATCH 32
+struct OhBatch { const DevFrame *f[OH_MAX_BATCH]; };
 
 #endif

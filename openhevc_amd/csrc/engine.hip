@@ -28,7 +28,7 @@ struct Pic {
     bool        final_b = false;         /* which buffer holds the finished picture */
 };
 
-struct EventSet { hipEvent_t ev[OH_N_PASSES + 1]; };
+struct EventSet { hipEvent_t ev[OH_N_PASSES + 1]; int n_frames = 1; };
 
 } // namespace
 
@@ -38,8 +38,11 @@ struct OhDevFrame {
     OhPicParams p{};
     uint32_t   n_mc_luma = 0, n_mc_chroma = 0, n_tu = 0, n_intra = 0;
     bool       has_sao = false;
-    std::vector<uint32_t> level_start;
-    std::vector<OhIntraLaunch> launches;  /* one per wavefront level: CTU range, LDS carve-up, waves per CTU */
+    struct Level {                        /* one wavefront level: what sizes the launch that runs it */
+        uint32_t n_ctu, max_items, max_sub, max_res;
+        uint64_t sum_items, sum_sub;
+    };
+    std::vector<Level> levels;
 };
 
 struct OhEngine {
@@ -622,7 +625,28 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         for (uint32_t b = f->sub_start[dictu[k].sub_first]; b < f->sub_start[dictu[k].sub_first + dictu[k].n_sub]; b++)
             if (dintra[b].res_off != OH_NO_COEFF && dictu[k].res_cnt)
                 dintra[b].res_lds = dintra[b].res_off - dictu[k].res_lo;
+    std::vector<OhDevFrame::Level> levels(f->n_intra ? f->n_levels : 0);
+    std::vector<uint8_t> lvl_staged(levels.size(), 1);
+    for (size_t l = 0; l < levels.size(); l++) {
+        OhDevFrame::Level &L = levels[l];
+        L.n_ctu = f->level_start[l + 1] - f->level_start[l];
+        L.max_items = 1; L.max_sub = 1; L.max_res = 0; L.sum_items = 0; L.sum_sub = 0;
+        for (uint32_t k = f->level_start[l]; k < f->level_start[l + 1]; k++) {
+            const uint32_t b0 = f->sub_start[dictu[k].sub_first], b1 = f->sub_start[dictu[k].sub_first + dictu[k].n_sub];
+            bool any_res = false;
+            for (uint32_t b = b0; b < b1 && !any_res; b++)
+                any_res = dintra[b].res_off != OH_NO_COEFF;
+            if (any_res && !dictu[k].res_cnt)
+                lvl_staged[l] = 0;
+            L.max_items = std::max(L.max_items, std::min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
+            L.max_sub = std::max(L.max_sub, std::min((uint32_t)dictu[k].n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
+            L.max_res = std::max(L.max_res, dictu[k].res_cnt);
+            L.sum_items += b1 - b0; L.sum_sub += dictu[k].n_sub;
+        }
+    }
     int s_ictu = add(dictu.data(), dictu.size() * sizeof(DevIntraCtu));
+    int s_lvl = add(levels.empty() ? nullptr : f->level_start, levels.empty() ? 0 : (levels.size() + 1) * sizeof(uint32_t));
+    int s_lst = add(lvl_staged.data(), lvl_staged.size());
     int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
     int s_vbs = add(has_db ? f->vertical_bs : nullptr, has_db ? f->bs_size : 0);
     int s_hbs = add(has_db ? f->horizontal_bs : nullptr, has_db ? f->bs_size : 0);
@@ -659,6 +683,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.intra = (const DevIntra *)(base + seg[s_intra].off);
     hd.ictu = (const DevIntraCtu *)(base + seg[s_ictu].off);
     hd.sub_start = (const uint32_t *)(base + seg[s_sub].off);
+    hd.lvl_start = (const uint32_t *)(base + seg[s_lvl].off);
+    hd.lvl_staged = (const uint8_t *)(base + seg[s_lst].off);
     hd.vbs = (const uint8_t *)(base + seg[s_vbs].off);
     hd.hbs = (const uint8_t *)(base + seg[s_hbs].off);
     hd.qp = (const int8_t *)(base + seg[s_qp].off);
@@ -691,99 +717,135 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     df->n_mc_luma = hd.n_mc_luma; df->n_mc_chroma = hd.n_mc_chroma; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
     df->has_sao = has_sao;
     if (f->n_intra) {
-        df->level_start.assign(f->level_start, f->level_start + f->n_levels + 1);
-        const char *wenv = getenv("OHEVC_INTRA_WAVES");                /* experiments: force the waves per CTU */
-        df->launches.resize(f->n_levels);
-        for (uint32_t l = 0; l < f->n_levels; l++) {
-            OhIntraLaunch &L = df->launches[l];
-            L.first_ctu = f->level_start[l];
-            L.n_ctu = f->level_start[l + 1] - f->level_start[l];
-            L.staged = 1;
-            uint32_t max_items = 1, max_sub = 1, max_res = 0;
-            uint64_t sum_items = 0, sum_sub = 0;
-            for (uint32_t k = f->level_start[l]; k < f->level_start[l + 1]; k++) {
-                const uint32_t b0 = f->sub_start[dictu[k].sub_first], b1 = f->sub_start[dictu[k].sub_first + dictu[k].n_sub];
-                bool any_res = false;
-                for (uint32_t b = b0; b < b1 && !any_res; b++)
-                    any_res = dintra[b].res_off != OH_NO_COEFF;
-                if (any_res && !dictu[k].res_cnt)
-                    L.staged = 0;
-                max_items = std::max(max_items, std::min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
-                max_sub = std::max(max_sub, std::min((uint32_t)dictu[k].n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
-                max_res = std::max(max_res, dictu[k].res_cnt);
-                sum_items += b1 - b0; sum_sub += dictu[k].n_sub;
-            }
-            /* waves per CTU: as many as blocks run side by side in a sub-level (more only hold LDS and wave slots) */
-            const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;
-            L.waves = (uint16_t)(wenv ? atoi(wenv) : par > 2.5 ? 8 : par > 1.25 ? 4 : 2);
-            if (L.waves < 1 || L.waves > 8) L.waves = 8;
-            size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
-            L.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
-            L.off_sub = (uint32_t)off;   off = align_up(off + ((size_t)max_sub + 1) * sizeof(uint32_t), 16);
-            L.off_res = (uint32_t)off;   off = align_up(off + (L.staged ? (size_t)max_res * sizeof(int16_t) : 0), 16);
-            L.off_wave = (uint32_t)off;  off += (size_t)L.waves * OH_INTRA_WAVE_LDS;
-            L.lds_bytes = (uint32_t)off;
-        }
+        df->levels = levels;
     }
     cur->final_b = has_sao;
     *out = df;
     return OH_OK;
 }
 
-extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
+/* Execute n mutually independent pictures: every pass is one launch over all of them (chunks of
+ * OH_MAX_BATCH).  Nothing orders the pictures of a batch against each other, so none of them may be a
+ * reference of another one. */
+extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
 {
-    if (!e || !df)
+    if (!e || !dfs || n < 1)
         return OH_E_ARG;
+    for (int i = 0; i < n; i++) {
+        if (!dfs[i])
+            return OH_E_ARG;
+        const OhPicParams &a = dfs[0]->p, &b = dfs[i]->p;
+        if (memcmp(&a, &b, sizeof(a)) != 0)
+            FAIL(e, OH_E_ARG, "batch: picture %d has other parameters than picture 0", i);
+    }
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
-    EventSet es;
     const bool prof = e->profile > 0, prof_launch = e->profile > 1;
-    if (prof) {
-        if (!e->ev_pool.empty()) {
-            es = e->ev_pool.back();
-            e->ev_pool.pop_back();
-        } else {
-            for (auto &ev : es.ev)
-                HIPCHK(e, hipEventCreate(&ev));
-        }
-        HIPCHK(e, hipEventRecord(es.ev[0], st));
-    }
-#define MARK(k) do { if (prof) HIPCHK(e, hipEventRecord(es.ev[(k) + 1], st)); } while (0)
-    ohk_inter(df->d, &df->p, df->n_mc_luma, df->n_mc_chroma, st);
-    MARK(OH_PASS_INTER);
-    ohk_residual(df->d, &df->p, df->n_tu, st);
-    MARK(OH_PASS_RESIDUAL);
-    for (size_t l = 0; l + 1 < df->level_start.size(); l++) {
-        hipEvent_t a = nullptr, b = nullptr;
-        if (prof_launch) {                                /* bracket every launch: the pass is many dependent launches */
-            for (hipEvent_t *pe : { &a, &b }) {
-                if (!e->lev_pool.empty()) { *pe = e->lev_pool.back(); e->lev_pool.pop_back(); }
-                else HIPCHK(e, hipEventCreate(pe));
+    static const char *wenv = getenv("OHEVC_INTRA_WAVES");            /* experiments: force the waves per CTU */
+    for (int c0 = 0; c0 < n; c0 += OH_MAX_BATCH) {
+        const int nb = n - c0 < OH_MAX_BATCH ? n - c0 : OH_MAX_BATCH;
+        OhDevFrame *const *fr = dfs + c0;
+        const OhPicParams *p = &fr[0]->p;
+        EventSet es;
+        if (prof) {
+            if (!e->ev_pool.empty()) {
+                es = e->ev_pool.back();
+                e->ev_pool.pop_back();
+            } else {
+                for (auto &ev : es.ev)
+                    HIPCHK(e, hipEventCreate(&ev));
             }
-            HIPCHK(e, hipEventRecord(a, st));
+            es.n_frames = nb;
+            HIPCHK(e, hipEventRecord(es.ev[0], st));
         }
-        ohk_intra_level(df->d, &df->p, &df->launches[l], st);
-        if (prof_launch) {
-            HIPCHK(e, hipEventRecord(b, st));
-            e->lev_pending.push_back(a);
-            e->lev_pending.push_back(b);
+#define MARK(k) do { if (prof) HIPCHK(e, hipEventRecord(es.ev[(k) + 1], st)); } while (0)
+        OhBatch all;
+        memset(&all, 0, sizeof(all));
+        uint32_t max_luma = 0, max_chroma = 0, max_tu = 0;
+        size_t max_levels = 0;
+        for (int i = 0; i < nb; i++) {
+            all.f[i] = fr[i]->d;
+            max_luma = std::max(max_luma, fr[i]->n_mc_luma); max_chroma = std::max(max_chroma, fr[i]->n_mc_chroma);
+            max_tu = std::max(max_tu, fr[i]->n_tu);
+            max_levels = std::max(max_levels, fr[i]->levels.size());
         }
-    }
-    MARK(OH_PASS_INTRA);
-    if (df->p.deblock_enabled)
-        ohk_deblock(df->d, &df->p, 0, st);
-    MARK(OH_PASS_DEBLOCK_V);
-    if (df->p.deblock_enabled)
-        ohk_deblock(df->d, &df->p, 1, st);
-    MARK(OH_PASS_DEBLOCK_H);
-    if (df->has_sao)
-        ohk_sao(df->d, &df->p, st);
-    MARK(OH_PASS_SAO);
+        ohk_inter(&all, nb, p, max_luma, max_chroma, st);
+        MARK(OH_PASS_INTER);
+        ohk_residual(&all, nb, p, max_tu, st);
+        MARK(OH_PASS_RESIDUAL);
+        const OhCtuAreas areas = oh_ctu_areas(p->log2_ctb_size, p->chroma_format_idc);
+        for (size_t l = 0; l < max_levels; l++) {
+            /* the pictures that have this level, and the LDS carve-up that fits all of them */
+            OhBatch sub;
+            memset(&sub, 0, sizeof(sub));
+            int ns = 0;
+            uint32_t max_ctu = 0, max_items = 1, max_sub = 1, max_res = 0;
+            uint64_t sum_items = 0, sum_sub = 0;
+            for (int i = 0; i < nb; i++) {
+                if (l >= fr[i]->levels.size())
+                    continue;
+                const OhDevFrame::Level &L = fr[i]->levels[l];
+                sub.f[ns++] = fr[i]->d;
+                max_ctu = std::max(max_ctu, L.n_ctu); max_items = std::max(max_items, L.max_items);
+                max_sub = std::max(max_sub, L.max_sub); max_res = std::max(max_res, L.max_res);
+                sum_items += L.sum_items; sum_sub += L.sum_sub;
+            }
+            OhIntraLaunch IL;
+            IL.level = (uint32_t)l;
+            /* waves per CTU: as many as blocks run side by side in a sub-level (more only hold LDS and wave slots) */
+            const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;
+            IL.waves = wenv ? (uint32_t)atoi(wenv) : par > 2.5 ? 8 : par > 1.25 ? 4 : 2;
+            if (IL.waves < 1 || IL.waves > 8) IL.waves = 8;
+            size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
+            IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
+            IL.off_sub = (uint32_t)off;   off = align_up(off + ((size_t)max_sub + 1) * sizeof(uint32_t), 16);
+            IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)max_res * sizeof(int16_t), 16);
+            IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
+            IL.lds_bytes = (uint32_t)off;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (prof_launch) {                            /* bracket every launch: the pass is many dependent launches */
+                for (hipEvent_t *pe : { &a, &b }) {
+                    if (!e->lev_pool.empty()) { *pe = e->lev_pool.back(); e->lev_pool.pop_back(); }
+                    else HIPCHK(e, hipEventCreate(pe));
+                }
+                HIPCHK(e, hipEventRecord(a, st));
+            }
+            ohk_intra_level(&sub, ns, p, &IL, max_ctu, st);
+            if (prof_launch) {
+                HIPCHK(e, hipEventRecord(b, st));
+                e->lev_pending.push_back(a);
+                e->lev_pending.push_back(b);
+            }
+        }
+        MARK(OH_PASS_INTRA);
+        if (p->deblock_enabled)
+            ohk_deblock(&all, nb, p, 0, st);
+        MARK(OH_PASS_DEBLOCK_V);
+        if (p->deblock_enabled)
+            ohk_deblock(&all, nb, p, 1, st);
+        MARK(OH_PASS_DEBLOCK_H);
+        {
+            OhBatch sub;
+            memset(&sub, 0, sizeof(sub));
+            int ns = 0;
+            for (int i = 0; i < nb; i++)
+                if (fr[i]->has_sao)
+                    sub.f[ns++] = fr[i]->d;
+            if (ns)
+                ohk_sao(&sub, ns, p, st);
+        }
+        MARK(OH_PASS_SAO);
 #undef MARK
-    HIPCHK(e, hipGetLastError());
-    if (prof)
-        e->ev_pending.push_back(es);
+        HIPCHK(e, hipGetLastError());
+        if (prof)
+            e->ev_pending.push_back(es);
+    }
     return OH_OK;
+}
+
+extern "C" int oh_frame_execute(OhEngine *e, OhDevFrame *df)
+{
+    return oh_frames_execute(e, &df, 1);
 }
 
 extern "C" int oh_frame_free(OhEngine *e, OhDevFrame *df)
@@ -828,7 +890,7 @@ extern "C" int oh_engine_pass_times(OhEngine *e, double *ms, uint64_t *executes,
             HIPCHK(e, hipEventElapsedTime(&t, s.ev[k], s.ev[k + 1]));
             e->pass_ms[k] += t;
         }
-        e->executes++;
+        e->executes += (uint64_t)s.n_frames;
         e->ev_pool.push_back(s);
     }
     e->ev_pending.clear();

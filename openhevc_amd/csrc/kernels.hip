@@ -137,9 +137,10 @@ static __device__ __forceinline__ uint2v load4_pairs(const GLOBAL uint8_t *p)
 static __device__ __forceinline__ uint2v load4_pairs(const GLOBAL uint16_t *p) { return *(const GLOBAL uint2v_a2 *)p; }
 
 template <typename PX, int TAPS>
-__global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
+__global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
 {
     typedef McGeom<TAPS> G;
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
     constexpr bool LUMA = TAPS == 8;
     constexpr int before = TAPS / 2 - 1, HT = TAPS / 2;
     __shared__ __attribute__((aligned(16))) unsigned win[4][G::WROWS * G::WP + 8];   /* +8: the four blocks start on different banks */
@@ -351,8 +352,11 @@ __global__ __launch_bounds__(64) void mc_kernel(const DevFrame *__restrict__ f)
 __device__ int8_t g_basis[5][1024];                 /* [log2-2] n x n DCT basis rows, [4] DST-VII; filled by ohk_init() */
 
 template <typename PX>
-__global__ __launch_bounds__(64) void residual_kernel(const DevFrame *__restrict__ f)
+__global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
 {
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    if (blockIdx.x >= f->n_tu)
+        return;
     __shared__ __attribute__((aligned(16))) int16_t a[1024];
     __shared__ __attribute__((aligned(16))) int16_t b[1024];
     __shared__ __attribute__((aligned(16))) int8_t  m[32 * 32];
@@ -544,10 +548,10 @@ static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, GLOBAL P
     else                 *(GLOBAL uint2v *)g = pk16;
 }
 
-template <typename PX, bool STAGED>
+template <typename PX>
 static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
                                                    const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
-                                                   const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
+                                                   const int16_t *__restrict__ res_lds_base, const bool STAGED, const int lane, unsigned long long *acc)
 {
     unsigned long long ta = 0, tb = 0, tc = 0, td = 0; (void)ta; (void)tb; (void)tc; (void)td; (void)acc;
     STAMP(ta);
@@ -745,9 +749,14 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     ACC(2, ta, tb); ACC(3, tb, tc); ACC(4, tc, td);
 }
 
-template <typename PX, bool STAGED>
-__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const DevFrame *__restrict__ f, const OhIntraLaunch L)
+template <typename PX>
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
 {
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t first_ctu = f->lvl_start[L.level];
+    if (blockIdx.x >= f->lvl_start[L.level + 1] - first_ctu)
+        return;
+    const bool STAGED = f->lvl_staged[L.level];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *__restrict__ M = (uint16_t *)smem;                                  /* sample area, oh_ctu_areas() */
     DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const D
     int16_t *__restrict__ res_l = (int16_t *)(smem + L.off_res);                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     IntraLds &edges = *(IntraLds *)(smem + L.off_wave + wave * OH_INTRA_WAVE_LDS);
-    const DevIntraCtu ctu = gload(f->ictu + L.first_ctu + blockIdx.x);
+    const DevIntraCtu ctu = gload(f->ictu + first_ctu + blockIdx.x);
     const GLOBAL uint32_t *__restrict__ ss = G_CONST(uint32_t, f->sub_start) + ctu.sub_first;
     const OhPicParams &pp = f->pp;
     const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc;
@@ -816,14 +825,14 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const D
         STAMP(t0);
         const uint32_t b1 = sub[s + 1];
         for (uint32_t b = sub[s] + wave; b < b1; b += nwaves)
-            intra_block<PX, STAGED>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, lane, acc);
+            intra_block<PX>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, STAGED, lane, acc);
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
         STAMP(t2);
         ACC(0, t0, t1); ACC(1, t1, t2);
     }
 #ifdef OH_STAMPS
-    if (f->dbg && blockIdx.x == 0 && wave == 0 && lane == 0) {
+    if (f->dbg && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0) {
         unsigned long long te; STAMP(te);
         unsigned long long rt2 = __builtin_amdgcn_s_memrealtime();
         unsigned long long slot = atomicAdd((unsigned long long *)f->dbg, 1ull);
@@ -857,8 +866,9 @@ static __device__ __forceinline__ int get_pcm(const DevFrame *f, int x, int y)
 }
 
 template <typename PX, int HORIZ>       /* HORIZ = 1: horizontal edges (filter across y) */
-__global__ __launch_bounds__(256) void deblock_luma_kernel(const DevFrame *__restrict__ f)
+__global__ __launch_bounds__(256) void deblock_luma_kernel(const OhBatch B)
 {
+    const DevFrame *__restrict__ f = B.f[blockIdx.z];
     const OhPicParams &pp = f->pp;
     const int W = pp.width, H = pp.height, bd = pp.bit_depth;
     /* x index runs fastest in both directions so that a wave touches neighbouring addresses */
@@ -991,12 +1001,13 @@ static __device__ __forceinline__ int chroma_tc(const DevFrame *f, int qp_y, int
 }
 
 template <typename PX, int HORIZ>
-__global__ __launch_bounds__(256) void deblock_chroma_kernel(const DevFrame *__restrict__ f)
+__global__ __launch_bounds__(256) void deblock_chroma_kernel(const OhBatch B)
 {
+    const DevFrame *__restrict__ f = B.f[blockIdx.z >> 1];
     const OhPicParams &pp = f->pp;
     const int W = pp.width, H = pp.height, bd = pp.bit_depth;
     const int hs = hsh(pp, 1), vs = vsh(pp, 1), hh = 1 << hs, vv = 1 << vs;
-    const int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y, c = 1 + blockIdx.z;
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y, c = 1 + (blockIdx.z & 1);
     int x, y;                                               /* luma coordinates of the segment */
     if (!HORIZ) { x = 8 * hh * (gx + 1); y = 4 * vv * gy; } else { x = 4 * hh * gx; y = 8 * vv * (gy + 1); }
     if (x >= W || y >= H)
@@ -1139,10 +1150,11 @@ static __device__ __forceinline__ void sao_edge8(const GLOBAL PX *__restrict__ s
  * SAO type / class is the same for all its lanes (no divergent band/edge paths); a workgroup of
  * 4 waves covers 4 such strips stacked vertically.  grid = (CTB columns, strips of rows, planes). */
 template <typename PX>
-__global__ __launch_bounds__(256) void sao_kernel(const DevFrame *__restrict__ f)
+__global__ __launch_bounds__(256) void sao_kernel(const OhBatch B, const int nplanes_)
 {
+    const DevFrame *__restrict__ f = B.f[blockIdx.z / nplanes_];
     const OhPicParams &pp = f->pp;
-    const int c = blockIdx.z;
+    const int c = blockIdx.z % nplanes_;
     const int pw = f->cur.w[c], ph = f->cur.h[c];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int log2_gx = pp.log2_ctb_size - hsh(pp, c) - 3;            /* 8-sample groups per CTB row: 1 << log2_gx */
@@ -1240,82 +1252,73 @@ extern "C" int ohk_init(void)
         return -1;
     /* the intra kernel's LDS block is sized per launch and exceeds 64 KiB for 4:4:4 CTUs full of 4x4 blocks */
     const int max_lds = 128 * 1024;
-    if (hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
         return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dct), m, sizeof(m)) == hipSuccess ? 0 : -1;
 }
 
-#define LAUNCH_BY_DEPTH(bd, kern, grid, block, stream, ...)                                   \
-    do {                                                                                      \
-        if ((bd) == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern<uint8_t>), grid, block, 0, stream, __VA_ARGS__);   \
-        else           hipLaunchKernelGGL(HIP_KERNEL_NAME(kern<uint16_t>), grid, block, 0, stream, __VA_ARGS__);  \
-    } while (0)
-
-extern "C" void ohk_inter(const DevFrame *df, const OhPicParams *p, uint32_t n_luma, uint32_t n_chroma, hipStream_t st)
+/* launchers: one launch per pass over a batch of n pictures of the geometry *p */
+extern "C" void ohk_inter(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_luma, uint32_t max_chroma, hipStream_t st)
 {
     /* four blocks per wave; the grid is 8 contiguous slices of the block list, one per XCD */
-    const unsigned gl = ((((n_luma + 3) >> 2) + 7) >> 3) * 8, gc = ((((n_chroma + 3) >> 2) + 7) >> 3) * 8;
+    const unsigned gl = ((((max_luma + 3) >> 2) + 7) >> 3) * 8, gc = ((((max_chroma + 3) >> 2) + 7) >> 3) * 8;
     if (p->bit_depth == 8) {
-        if (n_luma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 8>), dim3(gl), dim3(64), 0, st, df);
-        if (n_chroma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 4>), dim3(gc), dim3(64), 0, st, df);
+        if (max_luma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 8>), dim3(gl, n), dim3(64), 0, st, *B);
+        if (max_chroma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint8_t, 4>), dim3(gc, n), dim3(64), 0, st, *B);
     } else {
-        if (n_luma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 8>), dim3(gl), dim3(64), 0, st, df);
-        if (n_chroma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 4>), dim3(gc), dim3(64), 0, st, df);
+        if (max_luma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 8>), dim3(gl, n), dim3(64), 0, st, *B);
+        if (max_chroma) hipLaunchKernelGGL(HIP_KERNEL_NAME(mc_kernel<uint16_t, 4>), dim3(gc, n), dim3(64), 0, st, *B);
     }
 }
 
-extern "C" void ohk_residual(const DevFrame *df, const OhPicParams *p, uint32_t n_tu, hipStream_t st)
+extern "C" void ohk_residual(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_tu, hipStream_t st)
 {
-    if (!n_tu) return;
-    LAUNCH_BY_DEPTH(p->bit_depth, residual_kernel, dim3(n_tu), dim3(64), st, df);
+    if (!max_tu) return;
+    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<uint8_t>), dim3(max_tu, n), dim3(64), 0, st, *B);
+    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<uint16_t>), dim3(max_tu, n), dim3(64), 0, st, *B);
 }
 
-extern "C" void ohk_intra_level(const DevFrame *df, const OhPicParams *p, const OhIntraLaunch *l, hipStream_t st)
+extern "C" void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st)
 {
-    if (!l->n_ctu) return;
-    dim3 g(l->n_ctu), b(64 * l->waves);
-    if (p->bit_depth == 8) {
-        if (l->staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, true>), g, b, l->lds_bytes, st, df, *l);
-        else           hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, false>), g, b, l->lds_bytes, st, df, *l);
-    } else {
-        if (l->staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, true>), g, b, l->lds_bytes, st, df, *l);
-        else           hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, false>), g, b, l->lds_bytes, st, df, *l);
-    }
+    if (!max_ctu) return;
+    dim3 g(max_ctu, n), b(64 * l->waves);
+    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t>), g, b, l->lds_bytes, st, *B, *l);
+    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t>), g, b, l->lds_bytes, st, *B, *l);
 }
 
-extern "C" void ohk_deblock(const DevFrame *df, const OhPicParams *p, int horiz, hipStream_t st)
+extern "C" void ohk_deblock(const OhBatch *B, int n, const OhPicParams *p, int horiz, hipStream_t st)
 {
     const int W = p->width, H = p->height;
     const int hs = p->chroma_format_idc == 1 || p->chroma_format_idc == 2, vs = p->chroma_format_idc == 1;
     if (!horiz) {
-        dim3 g(W / 8 / 256 + 1, H / 4), gc(W / (8 << hs) / 256 + 1, (H + (4 << vs) - 1) / (4 << vs), 2);
+        dim3 g(W / 8 / 256 + 1, H / 4, n), gc(W / (8 << hs) / 256 + 1, (H + (4 << vs) - 1) / (4 << vs), 2 * n);
         if (p->bit_depth == 8) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint8_t, 0>), g, dim3(256), 0, st, df);
-            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint8_t, 0>), gc, dim3(256), 0, st, df);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint8_t, 0>), g, dim3(256), 0, st, *B);
+            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint8_t, 0>), gc, dim3(256), 0, st, *B);
         } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint16_t, 0>), g, dim3(256), 0, st, df);
-            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint16_t, 0>), gc, dim3(256), 0, st, df);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint16_t, 0>), g, dim3(256), 0, st, *B);
+            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint16_t, 0>), gc, dim3(256), 0, st, *B);
         }
     } else {
-        dim3 g(W / 4 / 256 + 1, H / 8), gc(W / (4 << hs) / 256 + 1, (H + (8 << vs) - 1) / (8 << vs), 2);
+        dim3 g(W / 4 / 256 + 1, H / 8, n), gc(W / (4 << hs) / 256 + 1, (H + (8 << vs) - 1) / (8 << vs), 2 * n);
         if (p->bit_depth == 8) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint8_t, 1>), g, dim3(256), 0, st, df);
-            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint8_t, 1>), gc, dim3(256), 0, st, df);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint8_t, 1>), g, dim3(256), 0, st, *B);
+            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint8_t, 1>), gc, dim3(256), 0, st, *B);
         } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint16_t, 1>), g, dim3(256), 0, st, df);
-            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint16_t, 1>), gc, dim3(256), 0, st, df);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_luma_kernel<uint16_t, 1>), g, dim3(256), 0, st, *B);
+            if (p->chroma_format_idc) hipLaunchKernelGGL(HIP_KERNEL_NAME(deblock_chroma_kernel<uint16_t, 1>), gc, dim3(256), 0, st, *B);
         }
     }
 }
 
-extern "C" void ohk_sao(const DevFrame *df, const OhPicParams *p, hipStream_t st)
+extern "C" void ohk_sao(const OhBatch *B, int n, const OhPicParams *p, hipStream_t st)
 {
     /* luma geometry decides the grid; chroma planes (smaller) leave their surplus workgroups idle */
     const int ctbw = (p->width + (1 << p->log2_ctb_size) - 1) >> p->log2_ctb_size;
     const int rows_per_block = 4 * (64 >> (p->log2_ctb_size - 3));            /* luma: 4 waves x (512 / ctb) rows */
-    dim3 grid(ctbw, (p->height + rows_per_block - 1) / rows_per_block, p->chroma_format_idc ? 3 : 1);
-    LAUNCH_BY_DEPTH(p->bit_depth, sao_kernel, grid, dim3(256), st, df);
+    const int np = p->chroma_format_idc ? 3 : 1;
+    dim3 grid(ctbw, (p->height + rows_per_block - 1) / rows_per_block, np * n);
+    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(sao_kernel<uint8_t>), grid, dim3(256), 0, st, *B, np);
+    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(sao_kernel<uint16_t>), grid, dim3(256), 0, st, *B, np);
 }

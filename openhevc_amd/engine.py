@@ -54,6 +54,7 @@ def lib():
         L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
         L.oh_frame_execute.argtypes = [V, V]
+        L.oh_frames_execute.argtypes = [V, C.POINTER(C.c_void_p), C.c_int]
         L.oh_frame_free.argtypes = [V, V]
         L.oh_frame_submit.argtypes = [V, C.POINTER(F.OhFrame)]
         L.oh_engine_profile.argtypes = [V, I]
@@ -152,6 +153,11 @@ class Engine:
 
     def frame_execute(self, df):
         self._chk(self.L.oh_frame_execute(self.h, df), "oh_frame_execute")
+
+    def frames_execute(self, dfs):
+        """one launch per pass over all the (mutually independent) pictures in dfs"""
+        arr = (C.c_void_p * len(dfs))(*[d.value if isinstance(d, C.c_void_p) else d for d in dfs])
+        self._chk(self.L.oh_frames_execute(self.h, arr, len(dfs)), "oh_frames_execute")
 
     def frame_free(self, df):
         self._chk(self.L.oh_frame_free(self.h, df), "oh_frame_free")

@@ -71,6 +71,10 @@ class Backend:
     def execute(self, name):              # enqueue the picture's work list
         raise NotImplementedError
 
+    def execute_batch(self, items):       # items: [(backend, name)], mutually independent pictures
+        for be, name in items:
+            be.execute(name)
+
     def final_half(self, name):
         raise NotImplementedError
 
@@ -92,6 +96,27 @@ def run_step(plan: StepPlan, backend: Backend, dist=None, group=None):
                     backend.set_final_half(("ref", w, r), half)   # same SPS => same half on every rank
     for pic in plan.tail:
         backend.execute(pic.name)
+
+
+def run_steps_batched(chains, dist=None):
+    """Enqueue one step of EVERY chain in lockstep.  chains: list of (plan, backend, process group); the
+    chains are independent GOPs with the same schedule, so wave w of all of them is one batch of
+    mutually independent pictures (Backend.execute_batch: one launch per pass over the whole batch), and
+    so is the union of their tails.  The exchange after a wave stays one all-gather per chain."""
+    plan0, be0 = chains[0][0], chains[0][1]
+    for w in range(len(plan0.waves)):
+        be0.execute_batch([(be, pl.waves[w].name) for pl, be, _ in chains])
+        if plan0.world > 1:
+            for pl, be, group in chains:
+                half = be.final_half(pl.waves[w].name)
+                buf = be.wave_tensor(w)[half]
+                dist.all_gather_into_tensor(buf.view(-1), buf[pl.rank], group=group)
+                for r in range(pl.world):
+                    if r != pl.rank:
+                        be.set_final_half(("ref", w, r), half)
+    tail = [(be, pic.name) for pl, be, _ in chains for pic in pl.tail]
+    if tail:
+        be0.execute_batch(tail)
 
 
 def pictures_per_step(plan: StepPlan):
@@ -132,13 +157,16 @@ class PictureStore:
 
 
 class EngineBackend(Backend):
-    def __init__(self, torch, device_index, params, plan, knobs=None):
+    def __init__(self, torch, device_index, params, plan, knobs=None, engine=None):
+        """engine: share another backend's engine (its stream, picture ids and batches); None = own engine
+        on the current torch stream"""
         from . import frame as F
         from .engine import Engine
         self.torch, self.params, self.plan = torch, params, plan
         dev = torch.device("cuda", device_index)
         torch.cuda.set_device(dev)
-        self.engine = Engine(device_index, stream=torch.cuda.current_stream().cuda_stream)
+        self.own_engine = engine is None
+        self.engine = engine if engine is not None else Engine(device_index, stream=torch.cuda.current_stream().cuda_stream)
         self.store = PictureStore(torch, dev, params, plan, len(plan.waves), len(plan.tail))
         self.ids: Dict[Tuple, int] = {}
         for name in self.store.names():
@@ -161,6 +189,10 @@ class EngineBackend(Backend):
     def execute(self, name):
         self.engine.frame_execute(self.frames[name])
 
+    def execute_batch(self, items):
+        assert all(be.engine is self.engine for be, _ in items), "a batch runs on one engine"
+        self.engine.frames_execute([be.frames[name] for be, name in items])
+
     def final_half(self, name):
         return self.engine.pic_final_half(self.ids[name])
 
@@ -171,7 +203,8 @@ class EngineBackend(Backend):
         self.engine.sync()
         for df in self.frames.values():
             self.engine.frame_free(df)
-        self.engine.close()
+        if self.own_engine:
+            self.engine.close()
 
 
 def frame_stats(f):

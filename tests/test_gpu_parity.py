@@ -227,3 +227,39 @@ def test_unordered_coefficient_pool(eng):
     want, got = run_both(eng, p, g, pics)
     assert_same(want, got, "unordered coefficient pool")
     rec.close()
+
+
+@pytest.mark.parametrize("n,w,h,bd", [(5, 416, 240, 8), (35, 136, 88, 10)])
+def test_batched_pictures(eng, n, w, h, bd):
+    """oh_frames_execute: n independent pictures (I and B mixed, different numbers of wavefront levels,
+    shared references) run as one launch per pass — each must equal the oracle's picture.  35 > the
+    kernels' batch size: the engine splits the call."""
+    from openhevc_amd.engine import remap_frame
+    p = F.pic_params(w, h, bit_depth=bd)
+    rec = F.Recorder(p)
+    rng = np.random.default_rng(11)
+    refs = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng)}
+    ids = {k: eng.pic_alloc(p) for k in refs}
+    for k, hp in refs.items():
+        eng.pic_upload(ids[k], hp)
+    dfs, want, cur_ids = [], [], []
+    for i in range(n):
+        st = 0 if i % 4 == 1 else 2
+        f = rec.synth(F.synth_params(st, 9100 + i, intra_pct=10 + 5 * (i % 7)), 2, [0, 1])
+        cur = F.HostPic(p, rng=rng)
+        pics = {0: refs[0].copy(), 1: refs[1].copy(), 2: cur.copy()}
+        assert oracle().oh_or_frame(C.byref(f), host_pic_array(pics)) == 0
+        want.append(pics[2])
+        cid = eng.pic_alloc(p)
+        eng.pic_upload(cid, cur)
+        cur_ids.append(cid)
+        dfs.append(eng.frame_upload(remap_frame(f, {0: ids[0], 1: ids[1], 2: cid})))
+    eng.frames_execute(dfs)
+    eng.sync()
+    for i in range(n):
+        assert_same(want[i], eng.pic_download(cur_ids[i], p), f"batched picture {i}")
+    for df in dfs:
+        eng.frame_free(df)
+    for v in list(ids.values()) + cur_ids:
+        eng.pic_free(v)
+    rec.close()

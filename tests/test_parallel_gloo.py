@@ -30,7 +30,7 @@ def _digest(planes):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, w, h, out_path):
+def _worker(rank, world, port, w, h, out_path, batched=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     from openhevc_amd import frame as F
@@ -42,8 +42,15 @@ def _worker(rank, world, port, w, h, out_path):
     p = F.pic_params(w, h)
     plan = P.make_step_plan(world, rank, n_waves=3, n_tail=2, seed=5)
     be = OracleBackend(p, plan)
+    if batched:                                        # a second, different chain runs in lockstep with the first
+        plan2 = P.make_step_plan(world, rank, n_waves=3, n_tail=2, seed=6)
+        be2 = OracleBackend(p, plan2)
+        chains = [(plan, be, None), (plan2, be2, dist.new_group())]
     for _ in range(2):                                 # two steps: buffers are reused across steps
-        P.run_step(plan, be, dist)
+        if batched:
+            P.run_steps_batched(chains, dist)
+        else:
+            P.run_step(plan, be, dist)
     res = {str(n): _digest(be.picture(n)) for n in be.store.names()}
     torch.save(res, f"{out_path}.{rank}")
     dist.barrier()
@@ -76,10 +83,11 @@ def _single_process_expectation(world, w, h):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_gloo_match_single_process(tmp_path):
+@pytest.mark.parametrize("batched", [False, True], ids=["chain_per_stream", "lockstep_batches"])
+def test_two_ranks_gloo_match_single_process(tmp_path, batched):
     world, w, h = 2, 128, 72
     out = str(tmp_path / "res")
-    mp.spawn(_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out, batched), nprocs=world, join=True)
     want = _single_process_expectation(world, w, h)
     for r in range(world):
         got = torch.load(f"{out}.{r}")

@@ -98,7 +98,8 @@ struct DevFrame {
     const OhPu      *pu;
     const DevMcJob  *mc_luma, *mc_chroma;
     const OhWeights *wp;
-    const OhTu      *tu;
+    const OhTu      *tu;              /* sorted by size: blocks of log2 size 2+k are tu[tu_first[k] .. +tu_cnt[k]) */
+    uint32_t        tu_first[4], tu_cnt[4];
     const int16_t   *coeffs;
     int16_t         *res;             /* residual pool (deferred adds of intra blocks)        */
     const DevIntra  *intra;

@@ -37,6 +37,7 @@ struct OhDevFrame {
     DevFrame  *d = nullptr;
     OhPicParams p{};
     uint32_t   n_mc_luma = 0, n_mc_chroma = 0, n_tu = 0, n_intra = 0;
+    uint32_t   tu_cnt[4] = { 0, 0, 0, 0 };
     bool       has_sao = false;
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
@@ -546,7 +547,16 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_mcl = add(mc_luma.data(), mc_luma.size() * sizeof(DevMcJob));
     int s_mcc = add(mc_chroma.data(), mc_chroma.size() * sizeof(DevMcJob));
     int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
-    int s_tu = add(f->tu, (size_t)f->n_tu * sizeof(OhTu));
+    /* transform blocks sorted by size (stable): the residual pass runs one launch per size */
+    std::vector<OhTu> tu_sorted(f->n_tu);
+    uint32_t tu_first[4] = { 0, 0, 0, 0 }, tu_cnt[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < f->n_tu; i++) tu_cnt[f->tu[i].log2_size - 2]++;
+    for (int k = 1; k < 4; k++) tu_first[k] = tu_first[k - 1] + tu_cnt[k - 1];
+    {
+        uint32_t cur_[4] = { tu_first[0], tu_first[1], tu_first[2], tu_first[3] };
+        for (uint32_t i = 0; i < f->n_tu; i++) tu_sorted[cur_[f->tu[i].log2_size - 2]++] = f->tu[i];
+    }
+    int s_tu = add(tu_sorted.data(), tu_sorted.size() * sizeof(OhTu));
     /* intra block descriptors: everything that depends only on geometry and mode is resolved here */
     static const int8_t k_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
                                         -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };      /* hevcpred_template.c:430-433 */
@@ -692,6 +702,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.db = (const OhDeblockCtb *)(base + seg[s_db].off);
     hd.sao = has_sao ? (const OhSaoCtb *)(base + seg[s_sao].off) : nullptr;
     hd.n_pu = f->n_pu; hd.n_mc_luma = (uint32_t)mc_luma.size(); hd.n_mc_chroma = (uint32_t)mc_chroma.size(); hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
+    for (int k = 0; k < 4; k++) { hd.tu_first[k] = tu_first[k]; hd.tu_cnt[k] = tu_cnt[k]; }
     hd.dbg = e->dbg;
     (void)s_hdr;
 
@@ -715,6 +726,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     df->d = (DevFrame *)base;
     df->p = p;
     df->n_mc_luma = hd.n_mc_luma; df->n_mc_chroma = hd.n_mc_chroma; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
+    for (int k = 0; k < 4; k++) df->tu_cnt[k] = tu_cnt[k];
     df->has_sao = has_sao;
     if (f->n_intra) {
         df->levels = levels;
@@ -761,12 +773,12 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
 #define MARK(k) do { if (prof) HIPCHK(e, hipEventRecord(es.ev[(k) + 1], st)); } while (0)
         OhBatch all;
         memset(&all, 0, sizeof(all));
-        uint32_t max_luma = 0, max_chroma = 0, max_tu = 0;
+        uint32_t max_luma = 0, max_chroma = 0, max_tu[4] = { 0, 0, 0, 0 };
         size_t max_levels = 0;
         for (int i = 0; i < nb; i++) {
             all.f[i] = fr[i]->d;
             max_luma = std::max(max_luma, fr[i]->n_mc_luma); max_chroma = std::max(max_chroma, fr[i]->n_mc_chroma);
-            max_tu = std::max(max_tu, fr[i]->n_tu);
+            for (int k = 0; k < 4; k++) max_tu[k] = std::max(max_tu[k], fr[i]->tu_cnt[k]);
             max_levels = std::max(max_levels, fr[i]->levels.size());
         }
         ohk_inter(&all, nb, p, max_luma, max_chroma, st);

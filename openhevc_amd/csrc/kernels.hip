@@ -343,154 +343,189 @@ __global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
  * inter blocks are added to the prediction here (transform_add, :45-111), intra blocks leave
  * their residual in f->res for pass 3.
  *
- * One wave per transform block; a lane owns groups of 4 consecutive elements (g = lane + 64k), so
- * coefficients, prediction samples and results move as 8-byte (4-byte for 8-bit samples) vectors.
- * Every HBM load of the block (coefficients, basis, prediction) is issued before the first wait.
- * The two 1-D passes go through LDS once (pass 1 output is read transposed by pass 2); pass 2 ends in
- * registers in the layout the epilogue stores.
+ * The engine sorts the transform blocks by size (DevFrame.tu_first / tu_cnt) and one launch per size runs
+ * residual_kernel<PX, LOG2>: a lane owns groups of 4 consecutive elements, so a wave holds sixteen 4x4,
+ * four 8x8 or one 16x16 block (a 32x32 block takes 4 groups per lane) and all 64 lanes work whatever the
+ * size.  Coefficients, prediction samples and results move as 8-byte (4-byte for 8-bit samples) vectors;
+ * every HBM load of a block is issued before the first wait.  The two 1-D passes go through LDS once
+ * (pass 1 output is read transposed by pass 2); pass 2 ends in registers in the layout the epilogue stores.
  * ======================================================================================= */
 __device__ int8_t g_basis[5][1024];                 /* [log2-2] n x n DCT basis rows, [4] DST-VII; filled by ohk_init() */
 
-template <typename PX>
+template <typename PX, int LOG2>
 __global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
 {
-    const DevFrame *__restrict__ f = B.f[blockIdx.y];
-    if (blockIdx.x >= f->n_tu)
-        return;
-    __shared__ __attribute__((aligned(16))) int16_t a[1024];
-    __shared__ __attribute__((aligned(16))) int16_t b[1024];
-    __shared__ __attribute__((aligned(16))) int8_t  m[32 * 32];
+    constexpr int N = 1 << LOG2, NG = N * N / 4;                  /* groups of 4 elements per block */
+    constexpr int SLOTS = NG >= 64 ? 1 : 64 / NG, LPS = 64 / SLOTS, K = NG > 64 ? NG / 64 : 1;
+    __shared__ __attribute__((aligned(16))) int16_t a[SLOTS][N * N];
+    __shared__ __attribute__((aligned(16))) int16_t b[SLOTS][N * N];
+    __shared__ __attribute__((aligned(16))) int8_t  m[LOG2 == 2 ? 2 : 1][N * N];      /* [1]: DST-VII */
     __shared__ int bbox[2];
-    const int lane = threadIdx.x;
-    const OhTu tu = gload(f->tu + blockIdx.x);
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t cnt = f->tu_cnt[LOG2 - 2], t0 = blockIdx.x * SLOTS;
+    if (t0 >= cnt)
+        return;
+    const int lane = threadIdx.x, slot = lane / LPS, sl = lane % LPS;
+    const bool live = t0 + slot < cnt;                            /* a dead slot repeats the wave's first block and stores nothing */
+    const OhTu tu = gload(f->tu + f->tu_first[LOG2 - 2] + t0 + (live ? slot : 0));
     const int bd = f->pp.bit_depth;
-    const int log2 = tu.log2_size, n = 1 << log2, ng = (n * n) >> 2;     /* groups of 4 elements */
     const bool is_tr = tu.kind == OH_TU_IDCT || tu.kind == OH_TU_DST4;
     const bool to_pic = tu.kind == OH_TU_PCM || (tu.flags & OH_TUF_ADD_NOW);
     const bool add = to_pic && tu.kind != OH_TU_PCM;
     const GLOBAL short4v *__restrict__ cin = (const GLOBAL short4v *)(f->coeffs + tu.coeff_off);
-    const GLOBAL unsigned *__restrict__ basis = (const GLOBAL unsigned *)g_basis[tu.kind == OH_TU_DST4 ? 4 : log2 - 2];
-    const int ds = f->cur.stride[tu.c_idx];
-    GLOBAL PX *__restrict__ dst = G_MUT(PX, f->cur.p[tu.c_idx]) + (size_t)tu.y * ds + tu.x;
+    const uint64_t p0 = (uint64_t)f->cur.p[0], p1 = (uint64_t)f->cur.p[1], p2 = (uint64_t)f->cur.p[2];
+    const int ds = tu.c_idx ? f->cur.stride[1] : f->cur.stride[0];
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, tu.c_idx == 0 ? p0 : (tu.c_idx == 1 ? p1 : p2)) + (size_t)tu.y * ds + tu.x;
 
-    /* issue every load of the block */
-    short4v cv[4];
-    unsigned mv[4];
-    int pv[4][4];
-    if (lane < 2) bbox[lane] = 0;
+    /* issue every load of the block(s) */
+    short4v cv[K];
+    int pv[K][4];
+    if (LOG2 >= 4 && lane < 2) bbox[lane] = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int g = lane + 64 * k;
-        cv[k] = short4v{ 0, 0, 0, 0 };
-        mv[k] = 0;
-        if (g < ng) {
-            cv[k] = cin[g];
-            if (is_tr) mv[k] = basis[g];
-            if (add) load4<PX>(dst + (size_t)((4 * g) >> log2) * ds + ((4 * g) & (n - 1)), pv[k]);
-        }
+    for (int k = 0; k < K; k++) {
+        const int g = sl + 64 * k;
+        cv[k] = cin[g];
+        if (add) load4<PX>(dst + (size_t)((4 * g) >> LOG2) * ds + ((4 * g) & (N - 1)), pv[k]);
     }
-    /* LDS: coefficients, basis, bounding box of the non-zero coefficients (zero rows / columns contribute
-     * nothing: what the reference's col_limit exploits, hevc_cabac.c:1927-1934) */
+    {
+        const GLOBAL unsigned *__restrict__ basis = (const GLOBAL unsigned *)g_basis[LOG2 - 2];
+#pragma unroll
+        for (int k = 0; k < (NG + 63) / 64; k++)
+            if (lane + 64 * k < NG) ((unsigned *)m[0])[lane + 64 * k] = basis[lane + 64 * k];
+        if (LOG2 == 2 && lane >= 32 && lane < 36) ((unsigned *)m[LOG2 == 2 ? 1 : 0])[lane - 32] = ((const GLOBAL unsigned *)g_basis[4])[lane - 32];
+    }
+    /* LDS: coefficients; for the big sizes the bounding box of the non-zero coefficients (zero rows /
+     * columns contribute nothing: what the reference's col_limit exploits, hevc_cabac.c:1927-1934) */
     int my_r = 0, my_c = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int g = lane + 64 * k;
-        if (g < ng) {
-            *(short4v *)(a + 4 * g) = cv[k];
-            if (is_tr) *(unsigned *)(m + 4 * g) = mv[k];
+    for (int k = 0; k < K; k++) {
+        const int g = sl + 64 * k;
+        *(short4v *)(a[slot] + 4 * g) = cv[k];
+        if (LOG2 >= 4) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (cv[k][j]) { my_r = max(my_r, (4 * g) >> log2); my_c = max(my_c, ((4 * g) & (n - 1)) + j); }
+                if (cv[k][j]) { my_r = max(my_r, (4 * g) >> LOG2); my_c = max(my_c, ((4 * g) & (N - 1)) + j); }
         }
     }
     __syncthreads();
-    int res[4][4];
-    if (is_tr) {
+    int nr = N, nc = N;
+    if (LOG2 >= 4) {
         if (my_r) atomicMax(&bbox[0], my_r);
         if (my_c) atomicMax(&bbox[1], my_c);
         __syncthreads();
-        const int nr = bbox[0] + 1, nc = bbox[1] + 1;   /* rows / columns that hold coefficients */
-        /* pass 1: down the columns, shift 7; group = output row i, four consecutive columns */
+        nr = bbox[0] + 1; nc = bbox[1] + 1;                       /* rows / columns that hold coefficients */
+    }
+    const int8_t *__restrict__ mm = m[LOG2 == 2 && tu.kind == OH_TU_DST4 ? 1 : 0];
+    int res[K][4];
+
+    /* stage 1 -> b: transform blocks run pass 1 (down the columns, shift 7; group = output row i, four
+     * consecutive columns); the others scale / rotate their coefficients */
+    if (is_tr) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int g = lane + 64 * k;
-            if (g >= ng) break;
-            const int i = (4 * g) >> log2, col = (4 * g) & (n - 1);
+        for (int k = 0; k < K; k++) {
+            const int g = sl + 64 * k;
+            const int i = (4 * g) >> LOG2, col = (4 * g) & (N - 1);
             int acc[4] = { 0, 0, 0, 0 };
-            if (col < nc)
-                for (int kk = 0; kk < nr; kk++) {
-                    const int mm = m[kk * n + i];
-                    const short4v av = *(const short4v *)(a + kk * n + col);
+            if (col < nc) {
+                if (LOG2 <= 3) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[j] += mm * av[j];
+                    for (int kk = 0; kk < N; kk++) {
+                        const int c = mm[kk * N + i];
+                        const short4v av = *(const short4v *)(a[slot] + kk * N + col);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[j] += c * av[j];
+                    }
+                } else {
+                    for (int kk = 0; kk < nr; kk++) {
+                        const int c = mm[kk * N + i];
+                        const short4v av = *(const short4v *)(a[slot] + kk * N + col);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[j] += c * av[j];
+                    }
                 }
+            }
             short4v o;
 #pragma unroll
             for (int j = 0; j < 4; j++) o[j] = (short)clip16((acc[j] + 64) >> 7);
-            *(short4v *)(b + 4 * g) = o;
+            *(short4v *)(b[slot] + 4 * g) = o;
+        }
+    } else {
+        const bool skip = tu.kind == OH_TU_SKIP;
+        const int shift = 15 - bd - LOG2;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int g = sl + 64 * k;
+            short4v o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = 4 * g + j;
+                int c0 = LOG2 == 2 && skip && (tu.flags & OH_TUF_ROTATE) ? a[slot][15 - e] : cv[k][j];   /* hevc_cabac.c:1879-1882, 4x4 only */
+                if (skip) c0 = shift > 0 ? (int16_t)((c0 + (1 << (shift - 1))) >> shift) : (int16_t)(c0 << -shift);
+                o[j] = (short)c0;
+            }
+            *(short4v *)(b[slot] + 4 * g) = o;
+        }
+    }
+    __syncthreads();
+    /* stage 2: rdpcm accumulation (hevcdsp_template.c:114-136), serial along the direction, one lane per line */
+    const bool any_plain = __builtin_amdgcn_ballot_w64(!is_tr) != 0;
+    if (any_plain) {
+        if (!is_tr && (tu.kind == OH_TU_SKIP || tu.kind == OH_TU_BYPASS) && (tu.flags & OH_TUF_RDPCM) && sl < N) {
+            int16_t *bb = b[slot];
+            if (tu.flags & OH_TUF_RDPCM_VER)
+                for (int y = 1; y < N; y++) bb[y * N + sl] = (int16_t)(bb[y * N + sl] + bb[(y - 1) * N + sl]);
+            else
+                for (int x = 1; x < N; x++) bb[sl * N + x] = (int16_t)(bb[sl * N + x] + bb[sl * N + x - 1]);
         }
         __syncthreads();
-        /* pass 2: along the rows; group = row, four consecutive outputs i */
+    }
+    /* stage 3 -> registers: pass 2 along the rows (group = row, four consecutive outputs i) / plain read */
+    if (is_tr) {
         const int shift = 20 - bd, addc = 1 << (shift - 1);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int g = lane + 64 * k;
-            if (g >= ng) break;
-            const int row = (4 * g) >> log2, i0 = (4 * g) & (n - 1);
+        for (int k = 0; k < K; k++) {
+            const int g = sl + 64 * k;
+            const int row = (4 * g) >> LOG2, i0 = (4 * g) & (N - 1);
             int acc[4] = { 0, 0, 0, 0 };
-            for (int kk = 0; kk < nc; kk++) {
-                const unsigned mm = *(const unsigned *)(m + kk * n + i0);
-                const int bv = b[row * n + kk];
+            if (LOG2 <= 3) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(mm >> (8 * j)) * bv;
+                for (int kk = 0; kk < N; kk++) {
+                    const unsigned c4 = *(const unsigned *)(mm + kk * N + i0);
+                    const int bv = b[slot][row * N + kk];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(c4 >> (8 * j)) * bv;
+                }
+            } else {
+                for (int kk = 0; kk < nc; kk++) {
+                    const unsigned c4 = *(const unsigned *)(mm + kk * N + i0);
+                    const int bv = b[slot][row * N + kk];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] += (int)(int8_t)(c4 >> (8 * j)) * bv;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) res[k][j] = clip16((acc[j] + addc) >> shift);
         }
     } else {
-        if (tu.kind == OH_TU_SKIP) {
-            if (tu.flags & OH_TUF_ROTATE) {            /* hevc_cabac.c:1879-1882, 4x4 only */
-                int16_t t0 = lane < 16 ? a[15 - lane] : 0;
-                __syncthreads();
-                if (lane < 16) a[lane] = t0;
-                __syncthreads();
-            }
-            const int shift = 15 - bd - log2;
-            for (int e = lane; e < n * n; e += 64) {
-                int c0 = a[e];
-                a[e] = shift > 0 ? (int16_t)((c0 + (1 << (shift - 1))) >> shift) : (int16_t)(c0 << -shift);
-            }
-            __syncthreads();
-        }
-        if ((tu.kind == OH_TU_SKIP || tu.kind == OH_TU_BYPASS) && (tu.flags & OH_TUF_RDPCM)) {   /* hevcdsp_template.c:114-136 */
-            if (lane < n) {
-                if (tu.flags & OH_TUF_RDPCM_VER)
-                    for (int y = 1; y < n; y++) a[y * n + lane] = (int16_t)(a[y * n + lane] + a[(y - 1) * n + lane]);
-                else
-                    for (int x = 1; x < n; x++) a[lane * n + x] = (int16_t)(a[lane * n + x] + a[lane * n + x - 1]);
-            }
-            __syncthreads();
-        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int g = lane + 64 * k;
-            if (g >= ng) break;
-            const short4v o = *(const short4v *)(a + 4 * g);
+        for (int k = 0; k < K; k++) {
+            const short4v o = *(const short4v *)(b[slot] + 4 * (sl + 64 * k));
 #pragma unroll
             for (int j = 0; j < 4; j++) res[k][j] = o[j];
         }
     }
 
     /* epilogue */
+    if (!live)
+        return;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int g = lane + 64 * k;
-        if (g >= ng) break;
+    for (int k = 0; k < K; k++) {
+        const int g = sl + 64 * k;
         if (to_pic) {
             int o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) o[j] = add ? clip_px(pv[k][j] + res[k][j], bd) : (res[k][j] & (sizeof(PX) == 1 ? 0xff : 0xffff));
-            store4<PX>(dst + (size_t)((4 * g) >> log2) * ds + ((4 * g) & (n - 1)), o[0], o[1], o[2], o[3]);
+            store4<PX>(dst + (size_t)((4 * g) >> LOG2) * ds + ((4 * g) & (N - 1)), o[0], o[1], o[2], o[3]);
         } else {
             short4v o;
 #pragma unroll
@@ -1272,11 +1307,18 @@ extern "C" void ohk_inter(const OhBatch *B, int n, const OhPicParams *p, uint32_
     }
 }
 
-extern "C" void ohk_residual(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_tu, hipStream_t st)
+extern "C" void ohk_residual(const OhBatch *B, int n, const OhPicParams *p, const uint32_t max_cnt[4], hipStream_t st)
 {
-    if (!max_tu) return;
-    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<uint8_t>), dim3(max_tu, n), dim3(64), 0, st, *B);
-    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<uint16_t>), dim3(max_tu, n), dim3(64), 0, st, *B);
+    /* one launch per transform size; a wave holds 16 / 4 / 1 / 1 blocks */
+#define RES_LAUNCH(PX)                                                                                                       \
+    do {                                                                                                                     \
+        if (max_cnt[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<PX, 2>), dim3((max_cnt[0] + 15) / 16, n), dim3(64), 0, st, *B); \
+        if (max_cnt[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<PX, 3>), dim3((max_cnt[1] + 3) / 4, n), dim3(64), 0, st, *B);   \
+        if (max_cnt[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<PX, 4>), dim3(max_cnt[2], n), dim3(64), 0, st, *B);             \
+        if (max_cnt[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(residual_kernel<PX, 5>), dim3(max_cnt[3], n), dim3(64), 0, st, *B);             \
+    } while (0)
+    if (p->bit_depth == 8) RES_LAUNCH(uint8_t); else RES_LAUNCH(uint16_t);
+#undef RES_LAUNCH
 }
 
 extern "C" void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st)

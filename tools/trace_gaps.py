@@ -22,6 +22,19 @@ def main():
     print(f"traced interval {(t1 - t0) / 1e6:.2f} ms, {len(rows)} dispatches, {len(qs)} queues")
     for k, (n, us) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
         print(f"  {k:40s} n={n:7d} total {us / 1e3:9.2f} ms  avg {us / n:8.1f} us")
+    # the intra pass by launch size
+    big = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        if "intra_ctu_kernel" in r["Kernel_Name"]:
+            wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) * int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1)
+            b = 1
+            while b < wg:
+                b *= 4
+            key = (b, int(r["Workgroup_Size_X"]), int(r.get("LDS_Block_Size", 0) or 0) // 8192 * 8)
+            big[key][0] += 1
+            big[key][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    for k, (n, us) in sorted(big.items()):
+        print(f"    intra launches with <= {k[0]:6d} workgroups of {k[1]:3d} threads, ~{k[2]:3d} KiB LDS: n={n:6d} total {us / 1e3:9.2f} ms avg {us / n:8.1f} us")
     tot_busy = 0.0
     for q, iv in sorted(qs.items()):
         iv.sort()

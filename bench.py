@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
-    ap.add_argument("--chains", type=int, default=32, help="closed GOPs (steps) in flight per GPU")
+    ap.add_argument("--chains", type=int, default=64, help="closed GOPs (steps) in flight per GPU")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
@@ -108,13 +108,14 @@ def main():
         plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + k)
         plan_k = P.make_step_plan(world, rank, **plan_kwargs)
         g = groups[k % n_streams]
-        if not g:                                          # [0] = (stream, engine) of the group
+        if not g:                                          # [0] = (stream, engine, process group) of the group
             stream = torch.cuda.Stream()
-            g.append((stream, Engine(local_rank, stream=stream.cuda_stream)))
-        stream, engine = g[0]
+            # the collectives of one stream are issued in the same order on every rank, so its chains share a
+            # communicator; different streams must not (their collectives interleave differently per rank)
+            g.append((stream, Engine(local_rank, stream=stream.cuda_stream), dist.new_group() if world > 1 else None))
+        stream, engine, group = g[0]
         with torch.cuda.stream(stream):
             be_k = P.EngineBackend(torch, local_rank, params, plan_k, engine=engine)
-        group = dist.new_group() if world > 1 else None    # collectives of different chains must not share a communicator
         g.append((plan_k, be_k, group))
         chains.append((plan_k, be_k, stream, group))
     engines = [g[0][1] for g in groups]
@@ -142,7 +143,8 @@ def main():
     barrier()
     for eng in engines:
         eng.pass_times(reset=True)
-        eng.profile(0 if args.no_profile else 1)
+        eng.n_batches = 0
+        eng.profile(0 if args.no_profile else 2)          # events between passes and around every intra launch
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -151,18 +153,6 @@ def main():
     dt = time.perf_counter() - t0
     for eng in engines:
         eng.profile(0)
-    # roofline leg: with many streams overlapping, events around a launch measure queueing as much as
-    # the kernel, so the per-launch durations of the multi-launch intra pass are taken on ONE chain
-    # running alone right after the timed region (rocprofv3's per-dispatch average agrees with it)
-    if rank == 0 and not args.no_profile:
-        plan_k, be_k, stream, group = chains[0]
-        if world == 1:
-            with torch.cuda.stream(stream):
-                be_k.engine.profile(2)
-                for _ in range(2):
-                    P.run_step(plan_k, be_k, None, None)
-            torch.cuda.synchronize()
-            be_k.engine.profile(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -186,28 +176,27 @@ def main():
         roofline = None
         if n_exec:
             # algorithmic bytes of this rank's step, per pass (openhevc_amd/parallel.py)
-            abytes = {k: 0.0 for k in pass_ms}
-            launches = {k: 0 for k in pass_ms}
-            for pic in plan.pictures():
-                st = be.stats[pic.name]
-                for k, v in P.algorithmic_bytes(st, b).items():
-                    abytes[k] += v
-                launches["inter"] += 1 if st["n_pu"] else 0
-                launches["residual"] += 1 if st["n_tu"] else 0
-                launches["intra"] += st["n_levels"]
-                launches["deblock_v"] += 2
-                launches["deblock_h"] += 2
-                launches["sao"] += 1
+            abytes = {k: 0.0 for k in pass_ms}             # per step: mean over the chains (their streams differ by seed)
+            for plan_k, be_k, _, _ in chains:
+                for pic in plan_k.pictures():
+                    for k, v in P.algorithmic_bytes(be_k.stats[pic.name], b).items():
+                        abytes[k] += v / n_chains
             dom = max(pass_ms, key=lambda k: pass_ms[k])
             steps_timed = n_exec / float(pics_per_step)
             ms_per_step_pass = pass_ms[dom] / steps_timed
-            n_launch = max(launches[dom], 1)
-            avg_launch_us = ms_per_step_pass * 1e3 / n_launch
-            launch_source = "pass time / launches, timed region"
-            if dom == "intra" and intra_n:                 # every launch bracketed by its own events (roofline leg)
+            # launches of the dominant pass in the timed region: every launch covers a batch of pictures
+            # (<= 32), so count what was launched, not pictures
+            if dom == "intra" and intra_n:                 # every launch bracketed by its own events
+                n_launch_total = intra_n
                 avg_launch_us = intra_ms * 1e3 / intra_n
-                launch_source = "HIP events around every launch, one chain alone after the timed region"
-            achieved = (abytes[dom] / n_launch) / (avg_launch_us * 1e-6) / 1e9
+                launch_source = "HIP events around every launch of the pass, timed region, all streams"
+            else:
+                per_batch = dict(inter=2, residual=4, deblock_v=2, deblock_h=2, sao=1)[dom] if dom != "intra" else 1
+                n_launch_total = max(sum(e.n_batches for e in engines) * per_batch, 1)
+                avg_launch_us = pass_ms[dom] * 1e3 / n_launch_total
+                launch_source = "pass time between HIP events / launches, timed region, all streams"
+            n_launch = n_launch_total / steps_timed        # per step (GOP); fractional: a launch serves many GOPs
+            achieved = (abytes[dom] * steps_timed / n_launch_total) / (avg_launch_us * 1e-6) / 1e9
             # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
             # rocprofv3 --pmc passes of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes
             # for gfx950); recorded under profiles/ because bench.py cannot run the profiler on itself
@@ -221,8 +210,8 @@ def main():
                             break
             roofline = dict(bound="hbm", kernel=PASS_KERNEL[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
-                            launches_per_step=n_launch, avg_launch_us=round(avg_launch_us, 3), avg_launch_source=launch_source,
-                            algorithmic_bytes_per_launch=round(abytes[dom] / n_launch, 1),
+                            launches_per_step=round(n_launch, 3), avg_launch_us=round(avg_launch_us, 3), avg_launch_source=launch_source,
+                            algorithmic_bytes_per_launch=round(abytes[dom] * steps_timed / n_launch_total, 1),
                             pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
                             pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms})
         knobs = P.default_synth_knobs()

@@ -833,7 +833,8 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
         const int x0 = cx0 >> hs, y0 = cy0 >> vs, pw = f->cur.w[c], ph = f->cur.h[c], stride = f->cur.stride[c];
         const int px0 = ctu.bx0 >> hs, px1 = (ctu.bx1 + (1 << hs) - 1) >> hs, py0 = ctu.by0 >> vs, py1 = (ctu.by1 + (1 << vs) - 1) >> vs;
         const GLOBAL PX *__restrict__ g = G_CONST(PX, f->cur.p[c]);
-        uint16_t *__restrict__ Mm = M + ar.main[c], *__restrict__ Mt = M + ar.top[c];
+        uint16_t *__restrict__ Mm = M + (c == 0 ? ar.main[0] : c == 1 ? ar.main[1] : ar.main[2]);      /* selects: no indexed struct on the stack */
+        uint16_t *__restrict__ Mt = M + (c == 0 ? ar.top[0] : c == 1 ? ar.top[1] : ar.top[2]);
         const int r0 = max(py0, 0), r1 = min(min(py1, hc), ph - y0);
         const int cs = max(px0, 0) & ~3, ce = min(min((px1 + 3) & ~3, wc), pw - x0);
         const int seg = tid & 15;

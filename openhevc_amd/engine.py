@@ -153,10 +153,12 @@ class Engine:
 
     def frame_execute(self, df):
         self._chk(self.L.oh_frame_execute(self.h, df), "oh_frame_execute")
+        self.n_batches = getattr(self, "n_batches", 0) + 1
 
     def frames_execute(self, dfs):
         """one launch per pass over all the (mutually independent) pictures in dfs"""
         arr = (C.c_void_p * len(dfs))(*[d.value if isinstance(d, C.c_void_p) else d for d in dfs])
+        self.n_batches = getattr(self, "n_batches", 0) + (len(dfs) + 31) // 32
         self._chk(self.L.oh_frames_execute(self.h, arr, len(dfs)), "oh_frames_execute")
 
     def frame_free(self, df):

@@ -85,6 +85,7 @@ struct DevIntraCtu {
     uint32_t sub_first;
     uint16_t n_sub, ctu;
     uint32_t res_lo, res_cnt;     /* int16 elements; res_cnt == 0: blocks read their residual from HBM */
+    uint32_t item0, n_items;      /* the CTU's blocks: intra[item0 .. item0 + n_items) (= sub_start range, resolved on the host) */
     int16_t  bx0, bx1, by0, by1;  /* CTU-local luma rectangle [x0,x1) x [y0,y1) that covers every sample a block of the
                                      CTU reads (its row above and column to the left, up to 2n): what gets staged */
 };

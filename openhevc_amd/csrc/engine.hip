@@ -607,6 +607,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         const OhIntraCtu &c = f->ictu[k];
         DevIntraCtu &d = dictu[k];
         d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu;
+        d.item0 = f->sub_start[c.sub_first]; d.n_items = f->sub_start[c.sub_first + c.n_sub] - d.item0;
         uint64_t lo = UINT64_MAX, hi = 0;
         int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
         for (uint32_t b = f->sub_start[c.sub_first]; b < f->sub_start[c.sub_first + c.n_sub]; b++) {
@@ -806,7 +807,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             IL.level = (uint32_t)l;
             /* waves per CTU: as many as blocks run side by side in a sub-level (more only hold LDS and wave slots) */
             const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;
-            IL.waves = wenv ? (uint32_t)atoi(wenv) : par > 2.5 ? 8 : par > 1.25 ? 4 : 2;
+            IL.waves = wenv ? (uint32_t)atoi(wenv) : par > 4.5 ? 8 : par > 1.25 ? 4 : 2;
             if (IL.waves < 1 || IL.waves > 8) IL.waves = 8;
             size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
             IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);

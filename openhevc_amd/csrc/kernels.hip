@@ -205,18 +205,26 @@ __global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
             return;
         const GLOBAL PX *__restrict__ src = (const GLOBAL PX *)refp[job.ref[l]][LUMA ? 0 : job.c_idx - 1];
         const int gx = job.x + ix - before + 4 * seg, wy0 = job.y + iy - before;
-        const bool inside = gx >= 0 && gx + 3 < pw;
+        /* row offsets fit 24 bits x 24 bits (v_mul_u32_u24 is full rate); the in-picture test of a lane's
+         * segment does not depend on the row, so it is taken once */
+        if (gx >= 0 && gx + 3 < pw) {
+            const GLOBAL PX *__restrict__ col = src + gx;
 #pragma unroll
-        for (int it = 0; it < G::NIT; it++) {
-            const int row = 4 * it + lrow;
-            if (row >= wh)
-                continue;
-            const GLOBAL PX *rowp = src + (size_t)clip3(wy0 + row, 0, ph - 1) * stride;
-            if (inside)
-                W[it] = load4_pairs(rowp + gx);
-            else
-                W[it] = uint2v{ pack2(rowp[clip3(gx, 0, pw - 1)], rowp[clip3(gx + 1, 0, pw - 1)]),
-                                pack2(rowp[clip3(gx + 2, 0, pw - 1)], rowp[clip3(gx + 3, 0, pw - 1)]) };
+            for (int it = 0; it < G::NIT; it++) {
+                const int row = 4 * it + lrow;
+                if (row < wh)
+                    W[it] = load4_pairs(col + __umul24(clip3(wy0 + row, 0, ph - 1), stride));
+            }
+        } else {
+            const int x0 = clip3(gx, 0, pw - 1), x1 = clip3(gx + 1, 0, pw - 1), x2 = clip3(gx + 2, 0, pw - 1), x3 = clip3(gx + 3, 0, pw - 1);
+#pragma unroll
+            for (int it = 0; it < G::NIT; it++) {
+                const int row = 4 * it + lrow;
+                if (row >= wh)
+                    continue;
+                const GLOBAL PX *rowp = src + __umul24(clip3(wy0 + row, 0, ph - 1), stride);
+                W[it] = uint2v{ pack2(rowp[x0], rowp[x1]), pack2(rowp[x2], rowp[x3]) };
+            }
         }
     };
     /* one list: registers -> LDS window -> h-pass -> vertical pairs -> v-pass -> v[0..3] = (row 0: col 0, col 1; row 1: col 0, col 1) */
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
     pr.stride[0] = f->cur.stride[0]; pr.stride[1] = f->cur.stride[1];
 
     /* stage: block descriptors, sub-level table, residual blocks */
-    const uint32_t item0 = ss[0], n_items = min(ss[n_sub] - item0, (uint32_t)OH_MAX_CTU_BLOCKS);
+    const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items, (uint32_t)OH_MAX_CTU_BLOCKS);
     {
         const GLOBAL uint4v *__restrict__ src = (const GLOBAL uint4v *)(f->intra + item0);
         uint4v *dst = (uint4v *)items;

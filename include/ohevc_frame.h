@@ -198,6 +198,39 @@ static inline uint64_t oh_pic_half_layout(const OhPicParams *p, int32_t stride[3
     return total;
 }
 
+/* ---- SHVC inter-layer up-sampling ------------------------------------------------
+ * Parameters of the resampling of a base-layer picture into the enhancement layer's geometry: the
+ * reference's UpsamplInf (hevc.h:347-357) plus the scaled reference layer window (HEVCWindow,
+ * hevc.h:384-389) the slots receive as `Enhscal`. */
+enum { OH_UP_DEFAULT = 0, OH_UP_X2 = 1, OH_UP_X1_5 = 2, OH_UP_SNR = 3 };      /* hevc.h:340-345 */
+typedef struct OhUpsample {
+    int32_t add_x_lum, add_y_lum, scale_x_lum, scale_y_lum;
+    int32_t add_x_cr, add_y_cr, scale_x_cr, scale_y_cr;
+    int32_t idx;                                   /* OH_UP_* : which slot variant the reference picks */
+    int32_t win_left, win_right, win_top, win_bottom;
+} OhUpsample;
+
+/* hevc.c:446-501 (set_sps of an enhancement layer): sizes are the layers' luma sizes inside their windows */
+static inline void oh_upsample_setup(OhUpsample *u, int width_bl, int height_bl, int width_el_pic, int height_el_pic,
+                                     int win_left, int win_right, int win_top, int win_bottom, int phase_align_flag)
+{
+    const int phase_xc = 0, phase_yc = 1, phase_x = phase_align_flag << 1, phase_y = phase_align_flag << 1;
+    const int height_el = height_el_pic - win_bottom - win_top, width_el = width_el_pic - win_left - win_right;
+    u->win_left = win_left; u->win_right = win_right; u->win_top = win_top; u->win_bottom = win_bottom;
+    u->scale_x_lum = ((width_bl << 16) + (width_el >> 1)) / width_el;
+    u->scale_y_lum = ((height_bl << 16) + (height_el >> 1)) / height_el;
+    u->add_x_lum = ((phase_x * u->scale_x_lum + 2) >> 2) + (1 << 11);
+    u->add_y_lum = ((phase_y * u->scale_y_lum + 2) >> 2) + (1 << 11);
+    u->add_x_cr = (((phase_xc + phase_align_flag) * u->scale_x_lum + 2) >> 2) + (1 << 11);
+    u->add_y_cr = (((phase_yc + phase_align_flag) * u->scale_y_lum + 2) >> 2) + (1 << 11);
+    u->scale_x_cr = u->scale_x_lum;
+    u->scale_y_cr = u->scale_y_lum;
+    if (u->scale_x_lum == 65536 && u->scale_y_lum == 65536) u->idx = OH_UP_SNR;
+    else if (u->scale_x_lum == 32768 && u->scale_y_lum == 32768) u->idx = OH_UP_X2;
+    else if (u->scale_x_lum == 43691 && u->scale_y_lum == 43691) u->idx = OH_UP_X1_5;
+    else u->idx = OH_UP_DEFAULT;
+}
+
 #ifdef __cplusplus
 }
 #endif

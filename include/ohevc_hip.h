@@ -35,7 +35,7 @@ enum {
     OH_E_HIP = -1,        /* HIP runtime error (see oh_engine_last_error) */
     OH_E_ARG = -2,        /* invalid argument / inconsistent work list    */
     OH_E_NOMEM = -3,
-    OH_E_UNSUPPORTED = -4 /* feature not built yet (e.g. 4:2:2)           */
+    OH_E_UNSUPPORTED = -4 /* outside what the path covers (e.g. up-sampling of >8-bit pictures) */
 };
 
 enum OhPass {             /* indices into oh_engine_pass_times()          */
@@ -72,6 +72,12 @@ int oh_pic_set_final_half(OhEngine *e, int pic_id, int half);
 /* planes: tightly described by byte strides, sample type uint8_t (8 bit) or uint16_t (>8 bit) */
 int oh_pic_upload(OhEngine *e, int pic_id, const uint8_t *const planes[3], const ptrdiff_t strides[3]);
 int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3], const ptrdiff_t strides[3]);
+
+/* SHVC inter-layer reference picture: resample the finished base-layer picture src_pic into
+ * the enhancement-layer picture dst_pic, bit-exact with the reference's whole-picture slot
+ * HEVCDSPContext.upsample_base_layer_frame (hevcdsp_template.c:2164-2438, call site hevc.c:3241).
+ * 8-bit 4:2:0 only, like that routine (OH_E_UNSUPPORTED otherwise).  u: oh_upsample_setup(). */
+int oh_pic_upsample(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u);
 
 /* work lists.  OhFrame.cur_pic / ref_pics[] hold engine picture ids.
  * upload copies every array to HBM (after it returns the host arrays may be reused);

@@ -117,6 +117,15 @@ struct DevFrame {
     uint64_t *dbg;                    /* diagnostic builds only (OH_STAMPS), null otherwise       */
 };
 
+/* one plane of the SHVC up-sampling pass (kernel argument) */
+struct OhUpPlane {
+    const void *src; int32_t sstride, w_bl, h_bl;
+    void *dst;       int32_t dstride, w_el, h_el;
+    int16_t *tmp;                                  /* [h_bl][w_el] */
+    int32_t left, right_end_h, right_end_v, top, bottom_end;
+    int32_t scale_x, add_x, scale_y, add_y, y_bias;
+};
+
 /* a batch of mutually independent pictures of one geometry: every pass is ONE launch over all of them
  * (kernel argument; the picture is picked by a grid dimension) */
 #define OH_MAX_BATCH 32

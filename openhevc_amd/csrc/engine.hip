@@ -60,6 +60,8 @@ struct OhEngine {
     double      pass_ms[OH_N_PASSES] = {};
     uint64_t    executes = 0;
     std::vector<OhDevFrame *> deferred;
+    int16_t    *up_tmp = nullptr;        /* intermediate rows of oh_pic_upsample */
+    size_t      up_tmp_elems = 0;
     uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
 };
 
@@ -177,6 +179,8 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &ev : e->lev_pending) (void)hipEventDestroy(ev);
     for (auto &s : e->ev_pending)
         for (auto &ev : s.ev) (void)hipEventDestroy(ev);
+    if (e->up_tmp)
+        (void)hipFree(e->up_tmp);
     if (e->own_stream)
         (void)hipStreamDestroy(e->stream);
     delete e;
@@ -307,6 +311,56 @@ extern "C" int oh_pic_set_final_half(OhEngine *e, int pic_id, int half)
     if (!p || (half != 0 && half != 1))
         FAIL(e, OH_E_ARG, "oh_pic_set_final_half: bad picture or half");
     p->final_b = half == 1;
+    return OH_OK;
+}
+
+/* SHVC inter-layer reference: upsample_base_layer_frame (hevcdsp_template.c:2164-2438, called at hevc.c:3241) */
+extern "C" int oh_pic_upsample(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u)
+{
+    if (!e || !u)
+        return OH_E_ARG;
+    Pic *el = get_pic(e, dst_pic), *bl = get_pic(e, src_pic);
+    if (!el || !bl || el == bl)
+        FAIL(e, OH_E_ARG, "oh_pic_upsample: bad picture ids");
+    if (el->p.bit_depth != 8 || bl->p.bit_depth != 8 || el->p.chroma_format_idc != 1 || bl->p.chroma_format_idc != 1)
+        FAIL(e, OH_E_UNSUPPORTED, "oh_pic_upsample: the reference's frame up-sampler is written for 8-bit 4:2:0 (byte edge buffers, shift 12)");
+    const int w_el = el->p.width, h_el = el->p.height, w_bl = bl->p.width, h_bl = bl->p.height;
+    if (u->win_left < 0 || u->win_right < 0 || u->win_top < 0 || u->win_bottom < 0 || u->win_left + u->win_right >= w_el ||
+        u->win_top + u->win_bottom >= h_el || u->scale_x_lum <= 0 || u->scale_y_lum <= 0 || u->scale_x_cr <= 0 || u->scale_y_cr <= 0)
+        FAIL(e, OH_E_ARG, "oh_pic_upsample: bad window / scale");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t need = (size_t)w_el * (size_t)(h_bl > h_el ? h_bl : h_el);
+    if (need > e->up_tmp_elems) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->up_tmp) (void)hipFree(e->up_tmp);
+        e->up_tmp = nullptr; e->up_tmp_elems = 0;
+        if (hipMalloc((void **)&e->up_tmp, need * sizeof(int16_t)) != hipSuccess)
+            FAIL(e, OH_E_NOMEM, "oh_pic_upsample: hipMalloc(%zu) failed", need * sizeof(int16_t));
+        e->up_tmp_elems = need;
+    }
+    void *const *src = bl->final_b ? bl->b : bl->a;
+    OhUpPlane a;
+    /* luma: BL rows = min(BL height, EL height) (:2220); x clipped to [left, right_end] inclusive (:2223) */
+    a.src = src[0]; a.sstride = bl->stride[0]; a.w_bl = w_bl; a.h_bl = h_bl <= h_el ? h_bl : h_el;
+    a.dst = el->a[0]; a.dstride = el->stride[0]; a.w_el = w_el; a.h_el = h_el; a.tmp = e->up_tmp;
+    a.left = u->win_left; a.right_end_h = w_el - u->win_right; a.right_end_v = w_el - u->win_right;
+    a.top = u->win_top; a.bottom_end = h_el - u->win_bottom;
+    a.scale_x = u->scale_x_lum; a.add_x = u->add_x_lum; a.scale_y = u->scale_y_lum; a.add_y = u->add_y_lum; a.y_bias = 0;
+    ohk_upsample_plane(&a, 8, e->stream);
+    /* chroma: BL rows = max(BL height, EL chroma height) >> 1 (:2317-2320); x clipped to [left, right_end - 1] (:2324);
+     * the vertical position carries the -4 of :2384 */
+    const int wc_el = w_el >> 1, hc_el = h_el >> 1;
+    for (int c = 1; c <= 2; c++) {
+        a.src = src[c]; a.sstride = bl->stride[c]; a.w_bl = w_bl >> 1; a.h_bl = (h_bl > hc_el ? h_bl : hc_el) >> 1;
+        if (a.h_bl > bl->h[c]) a.h_bl = bl->h[c];
+        a.dst = el->a[c]; a.dstride = el->stride[c]; a.w_el = wc_el; a.h_el = hc_el;
+        a.left = u->win_left >> 1; a.right_end_v = wc_el - (u->win_right >> 1); a.right_end_h = a.right_end_v - 1;
+        a.top = u->win_top >> 1; a.bottom_end = hc_el - (u->win_bottom >> 1);
+        a.scale_x = u->scale_x_cr; a.add_x = u->add_x_cr; a.scale_y = u->scale_y_cr; a.add_y = u->add_y_cr; a.y_bias = 4;
+        ohk_upsample_plane(&a, 4, e->stream);
+    }
+    HIPCHK(e, hipGetLastError());
+    el->final_b = false;                                   /* the resampled picture is a finished picture in half 0 */
     return OH_OK;
 }
 

@@ -54,6 +54,7 @@ def lib():
         L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
         L.oh_frame_execute.argtypes = [V, V]
+        L.oh_pic_upsample.argtypes = [V, C.c_int, C.c_int, V]
         L.oh_frames_execute.argtypes = [V, C.POINTER(C.c_void_p), C.c_int]
         L.oh_frame_free.argtypes = [V, V]
         L.oh_frame_submit.argtypes = [V, C.POINTER(F.OhFrame)]
@@ -144,6 +145,10 @@ class Engine:
         st, w, h = (C.c_int32 * 3)(), (C.c_int32 * 3)(), (C.c_int32 * 3)()
         self._chk(self.L.oh_pic_device_planes(self.h, pid, p, st, w, h), "oh_pic_device_planes")
         return [(p[c], st[c], w[c], h[c]) for c in range(3)]
+
+    def pic_upsample(self, dst_pid, src_pid, u):
+        """SHVC inter-layer reference: resample picture src_pid into dst_pid (u: frame.upsample_setup)"""
+        self._chk(self.L.oh_pic_upsample(self.h, dst_pid, src_pid, C.byref(u)), "oh_pic_upsample")
 
     # ---- work lists ----
     def frame_upload(self, frame):

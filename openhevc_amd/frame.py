@@ -88,6 +88,35 @@ assert C.sizeof(OhPu) == 20 and C.sizeof(OhWeights) == 28 and C.sizeof(OhTu) == 
 assert C.sizeof(OhIntra) == 12 and C.sizeof(OhSaoCtb) == 40 and C.sizeof(OhDeblockCtb) == 2
 
 
+class OhUpsample(C.Structure):
+    """include/ohevc_frame.h: parameters of the SHVC inter-layer up-sampling (UpsamplInf + scaled window)"""
+    _fields_ = [(n, C.c_int32) for n in ("add_x_lum", "add_y_lum", "scale_x_lum", "scale_y_lum", "add_x_cr", "add_y_cr",
+                                         "scale_x_cr", "scale_y_cr", "idx", "win_left", "win_right", "win_top", "win_bottom")]
+
+
+OH_UP_DEFAULT, OH_UP_X2, OH_UP_X1_5, OH_UP_SNR = 0, 1, 2, 3
+
+
+def upsample_setup(width_bl, height_bl, width_el, height_el, win=(0, 0, 0, 0), phase_align_flag=0):
+    """oh_upsample_setup (hevc.c:446-501) restated for Python callers; win = (left, right, top, bottom)"""
+    u = OhUpsample()
+    wl, wr, wt, wb = win
+    w_el, h_el = width_el - wl - wr, height_el - wt - wb
+    u.win_left, u.win_right, u.win_top, u.win_bottom = wl, wr, wt, wb
+    u.scale_x_lum = ((width_bl << 16) + (w_el >> 1)) // w_el
+    u.scale_y_lum = ((height_bl << 16) + (h_el >> 1)) // h_el
+    ph = phase_align_flag << 1
+    u.add_x_lum = ((ph * u.scale_x_lum + 2) >> 2) + (1 << 11)
+    u.add_y_lum = ((ph * u.scale_y_lum + 2) >> 2) + (1 << 11)
+    u.add_x_cr = (((0 + phase_align_flag) * u.scale_x_lum + 2) >> 2) + (1 << 11)
+    u.add_y_cr = (((1 + phase_align_flag) * u.scale_y_lum + 2) >> 2) + (1 << 11)
+    u.scale_x_cr, u.scale_y_cr = u.scale_x_lum, u.scale_y_lum
+    sx, sy = u.scale_x_lum, u.scale_y_lum
+    u.idx = OH_UP_SNR if (sx, sy) == (65536, 65536) else OH_UP_X2 if (sx, sy) == (32768, 32768) else \
+        OH_UP_X1_5 if (sx, sy) == (43691, 43691) else OH_UP_DEFAULT
+    return u
+
+
 def pic_params(width, height, bit_depth=8, chroma_format_idc=1, log2_ctb_size=6, log2_min_cb_size=3,
                log2_min_tb_size=2, sao=1, deblock=1, strong_intra_smoothing=1, pcm_loop_filter_disable=0,
                transquant_bypass_enable=0, cb_qp_offset=0, cr_qp_offset=0, intra_smoothing_disabled=0):

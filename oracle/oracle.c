@@ -639,3 +639,158 @@ int oh_or_frame(const OhFrame *f, OhHostPic *pics)
     free(c);
     return r;
 }
+
+/* =====================================================================================================
+ * SHVC inter-layer up-sampling.  Restated from hevcdsp_template.c:1834-2438 and the
+ * filter tables hevcdsp.c:948-1024: 16-phase 8-tap (luma) / 4-tap (chroma) separable resampling, the x2 and
+ * x1.5 slot variants pick their phases by parity / modulo 3 instead of the 16.16 position.
+ * ===================================================================================================== */
+static const int8_t up_luma16[16][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { -1, 2, -5, 62, 8, -3, 1, 0 }, { -1, 3, -8, 60, 13, -4, 1, 0 },
+    { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 52, 26, -8, 3, -1 }, { -1, 3, -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 }, { -1, 4, -10, 34, 45, -11, 4, -1 }, { -1, 4, -10, 31, 47, -9, 3, -1 }, { -1, 3, -8, 26, 52, -11, 4, -1 },
+    { 0, 1, -5, 17, 58, -10, 4, -1 }, { 0, 1, -4, 13, 60, -8, 3, -1 }, { 0, 1, -3, 8, 62, -5, 2, -1 }, { 0, 1, -2, 4, 63, -3, 1, 0 } };
+static const int8_t up_chroma16[16][4] = {
+    { 0, 64, 0, 0 }, { -2, 62, 4, 0 }, { -2, 58, 10, -2 }, { -4, 56, 14, -2 }, { -4, 54, 16, -2 }, { -6, 52, 20, -2 }, { -6, 46, 28, -4 }, { -4, 42, 30, -4 },
+    { -4, 36, 36, -4 }, { -4, 30, 42, -4 }, { -4, 28, 46, -6 }, { -2, 20, 52, -6 }, { -2, 16, 54, -4 }, { -2, 14, 56, -4 }, { -2, 10, 58, -2 }, { 0, 4, 62, -2 } };
+/* the variants' own small tables are rows of the 16-phase ones: phase of luma x2 {0,8}, x1.5 {0,11,5};
+ * chroma h x2 {0,8}, x1.5 {0,11,5}; chroma v x2 {14,6}, x1.5 {15,9,4} (hevcdsp.c:988-1022) */
+static const int up_lx2[2] = { 0, 8 }, up_lx15[3] = { 0, 11, 5 }, up_cvx2[2] = { 14, 6 }, up_cvx15[3] = { 15, 9, 4 };
+#define UP_SHIFT 12                              /* N_SHIFT = 20 - 8 whatever the bit depth, hevcdsp.h:40 */
+
+static inline int up_get(const uint8_t *p, int bd, ptrdiff_t i) { return bd > 8 ? ((const uint16_t *)p)[i] : p[i]; }
+static inline void up_put(uint8_t *p, int bd, ptrdiff_t i, int v)
+{
+    v = v < 0 ? 0 : (v > (1 << bd) - 1 ? (1 << bd) - 1 : v);
+    if (bd > 8) ((uint16_t *)p)[i] = (uint16_t)v; else p[i] = (uint8_t)v;
+}
+
+void oh_or_up_luma_h(int variant, int bd, int16_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                     int x_el, int x_bl, int block_w, int block_h, int width_el, const OhUpsample *u)
+{
+    const int left = u->win_left, right_end = width_el - u->win_right;
+    for (int i = 0; i < block_w; i++) {
+        int x = oh_clip3(i + x_el, left, right_end), phase, pos;                  /* upper bound inclusive: :1852 */
+        if (variant == OH_UP_X2) { phase = up_lx2[x & 1]; pos = ((x - left) >> 1) - x_bl; }
+        else if (variant == OH_UP_X1_5) { phase = up_lx15[(x - left) % 3]; pos = (((x - left) << 1) / 3) - x_bl; }
+        else { int r16 = ((x - left) * u->scale_x_lum + u->add_x_lum) >> 12; phase = r16 & 15; pos = (r16 >> 4) - x_bl; }
+        for (int j = 0; j < block_h; j++) {
+            int s = 0;
+            for (int k = 0; k < 8; k++) s += up_luma16[phase][k] * up_get(src, bd, j * srcstride + pos + k - 3);
+            dst[j * dststride + i] = (int16_t)s;
+        }
+    }
+}
+
+void oh_or_up_cr_h(int variant, int bd, int16_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                   int x_el, int x_bl, int block_w, int block_h, int width_el, const OhUpsample *u)
+{
+    const int left = u->win_left >> 1, right_end = width_el - (u->win_right >> 1);
+    for (int i = 0; i < block_w; i++) {
+        int x = oh_clip3(i + x_el, left, right_end), phase, pos;
+        if (variant == OH_UP_X2) { phase = up_lx2[x & 1]; pos = (x >> 1) - x_bl; }                /* no window offset: :2014 */
+        else if (variant == OH_UP_X1_5) { phase = up_lx15[(x - left) % 3]; pos = (((x - left) << 1) / 3) - x_bl; }
+        else { int r16 = ((x - left) * u->scale_x_cr + u->add_x_cr) >> 12; phase = r16 & 15; pos = (r16 >> 4) - x_bl; }
+        for (int j = 0; j < block_h; j++) {
+            int s = 0;
+            for (int k = 0; k < 4; k++) s += up_chroma16[phase][k] * up_get(src, bd, j * srcstride + pos + k - 1);
+            dst[j * dststride + i] = (int16_t)s;
+        }
+    }
+}
+
+void oh_or_up_luma_v(int variant, int bd, uint8_t *dst, ptrdiff_t dststride, const int16_t *src, ptrdiff_t srcstride,
+                     int y_bl, int x_el, int y_el, int block_w, int block_h, int width_el, int height_el, const OhUpsample *u)
+{
+    const int top = u->win_top, bottom_end = height_el - u->win_bottom, right_end = width_el - u->win_right, left = u->win_left;
+    for (int j = 0; j < block_h; j++) {
+        int y = oh_clip3(y_el + j, top, bottom_end - 1), phase, row;
+        if (variant == OH_UP_X2) { phase = up_lx2[(y - top) & 1]; row = ((y - top) >> 1) - y_bl; }
+        else if (variant == OH_UP_X1_5) { phase = up_lx15[(y - top) % 3]; row = (((y - top) << 1) / 3) - y_bl; }
+        else { int r16 = ((y - top) * u->scale_y_lum + u->add_y_lum) >> 12; phase = r16 & 15; row = (r16 >> 4) - y_bl; }
+        int col = 0;                                 /* the source column only advances inside the window: :1925 */
+        for (int i = 0; i < block_w; i++) {
+            int s = 0;
+            for (int k = 0; k < 8; k++) s += up_luma16[phase][k] * src[(row + k - 3) * srcstride + col];
+            up_put(dst, bd, (ptrdiff_t)(y_el + j) * dststride + x_el + i, (s + (1 << (UP_SHIFT - 1))) >> UP_SHIFT);
+            if (x_el + i >= left && x_el + i <= right_end - 2) col++;
+        }
+    }
+}
+
+void oh_or_up_cr_v(int variant, int bd, uint8_t *dst, ptrdiff_t dststride, const int16_t *src, ptrdiff_t srcstride,
+                   int y_bl, int x_el, int y_el, int block_w, int block_h, int width_el, int height_el, const OhUpsample *u)
+{
+    const int left = u->win_left >> 1, right_end = width_el - (u->win_right >> 1), top = u->win_top >> 1, bottom_end = height_el - (u->win_bottom >> 1);
+    for (int j = 0; j < block_h; j++) {
+        int y = oh_clip3(y_el + j, top, bottom_end - 1);
+        int r16 = (((y - top) * u->scale_y_cr + u->add_y_cr) >> 12) - 4;
+        int phase = variant == OH_UP_X2 ? up_cvx2[y & 1] : (variant == OH_UP_X1_5 ? up_cvx15[y % 3] : (r16 & 15));
+        int row = (r16 >> 4) - y_bl, col = 0;
+        for (int i = 0; i < block_w; i++) {
+            int s = 0;
+            for (int k = 0; k < 4; k++) s += up_chroma16[phase][k] * src[(row + k - 1) * srcstride + col];
+            up_put(dst, bd, (ptrdiff_t)y * dststride + x_el + i, (s + (1 << (UP_SHIFT - 1))) >> UP_SHIFT);      /* row y, the CLIPPED one: :1952 */
+            if (x_el + i >= left && x_el + i <= right_end - 2) col++;
+        }
+    }
+}
+
+/* one plane of upsample_base_layer_frame: horizontal pass into tmp[h_bl][w_el] (int16), vertical pass to the picture */
+static void up_frame_plane(const uint8_t *src, ptrdiff_t sstride, int w_bl, int h_bl, uint8_t *dst, ptrdiff_t dstride, int w_el, int h_el,
+                           int taps, int left, int right_end_h, int right_end_v, int top, int bottom_end,
+                           int scale_x, int add_x, int scale_y, int add_y, int y_bias, int16_t *tmp)
+{
+    const int before = taps / 2 - 1;
+    for (int i = 0; i < w_el; i++) {
+        int x = oh_clip3(i, left, right_end_h);
+        int r16 = ((x - left) * scale_x + add_x) >> 12, phase = r16 & 15, pos = (r16 >> 4) - before;
+        for (int j = 0; j < h_bl; j++) {
+            int s = 0;
+            for (int k = 0; k < taps; k++) {
+                int c = taps == 8 ? up_luma16[phase][k] : up_chroma16[phase][k];
+                s += c * src[j * sstride + oh_clip3(pos + k, 0, w_bl - 1)];           /* memset/memcpy edge buffers = clamping */
+            }
+            tmp[j * w_el + i] = (int16_t)s;
+        }
+    }
+    for (int j = 0; j < h_el; j++) {
+        int y = oh_clip3(j, top, bottom_end - 1);
+        int r16 = (((y - top) * scale_y + add_y) >> 12) - y_bias, phase = r16 & 15, pos = (r16 >> 4) - before;
+        for (int i = 0; i < w_el; i++) {
+            int col = oh_clip3(i, left, right_end_v - 1) - left;                      /* srcY1++ only inside [left, right_end - 2] */
+            int s = 0;
+            for (int k = 0; k < taps; k++) {
+                int c = taps == 8 ? up_luma16[phase][k] : up_chroma16[phase][k];
+                s += c * tmp[oh_clip3(pos + k, 0, h_bl - 1) * w_el + col];
+            }
+            s = (s + (1 << (UP_SHIFT - 1))) >> UP_SHIFT;
+            dst[j * dstride + i] = (uint8_t)(s < 0 ? 0 : (s > 255 ? 255 : s));
+        }
+    }
+}
+
+int oh_or_upsample_frame(const OhHostPic *bl, OhHostPic *el, const OhUpsample *u)
+{
+    if (bl->bit_depth != 8 || el->bit_depth != 8 || !bl->data[1] || !el->data[1])
+        return -1;
+    const int w_el = el->width[0], h_el = el->height[0], w_bl = bl->width[0];
+    int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)w_el * (size_t)(bl->height[0] > h_el ? bl->height[0] : h_el));
+    if (!tmp)
+        return -1;
+    /* luma: heightBL = min(BL height, EL height) (:2220); x clipped to [left, right_end] inclusive (:2223) */
+    up_frame_plane(bl->data[0], bl->stride[0], w_bl, bl->height[0] <= h_el ? bl->height[0] : h_el, el->data[0], el->stride[0], w_el, h_el, 8,
+                   u->win_left, w_el - u->win_right, w_el - u->win_right, u->win_top, h_el - u->win_bottom,
+                   u->scale_x_lum, u->add_x_lum, u->scale_y_lum, u->add_y_lum, 0, tmp);
+    /* chroma: heightBL = max(BL height, EL chroma height) >> 1 (:2317-2320); x clipped to [left, right_end - 1] (:2324);
+     * the vertical position carries the -4 of :2384 */
+    const int wc_el = w_el >> 1, hc_el = h_el >> 1, wc_bl = w_bl >> 1;
+    const int hc_bl = (bl->height[0] > hc_el ? bl->height[0] : hc_el) >> 1;
+    const int left_c = u->win_left >> 1, right_end_c = wc_el - (u->win_right >> 1), top_c = u->win_top >> 1, bottom_end_c = hc_el - (u->win_bottom >> 1);
+    for (int c = 1; c <= 2; c++)
+        up_frame_plane(bl->data[c], bl->stride[c], wc_bl, hc_bl, el->data[c], el->stride[c], wc_el, hc_el, 4,
+                       left_c, right_end_c - 1, right_end_c, top_c, bottom_end_c,
+                       u->scale_x_cr, u->add_x_cr, u->scale_y_cr, u->add_y_cr, 4, tmp);
+    free(tmp);
+    return 0;
+}

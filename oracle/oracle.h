@@ -101,6 +101,20 @@ int oh_or_pass_sao     (const OhFrame *f, OhHostPic *pics);   /* hevc_filter.c:1
 /* all five in order; coefficients are copied internally (f->coeffs stays const) */
 int oh_or_frame        (const OhFrame *f, OhHostPic *pics);
 
+/* ---- SHVC up-sampling slots, hevcdsp_template.c:1834-2438.  variant: OH_UP_DEFAULT / X2 / X1_5;
+ * strides in ELEMENTS of the pointed type, exactly as the slots use them. */
+void oh_or_up_luma_h(int variant, int bd, int16_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                     int x_el, int x_bl, int block_w, int block_h, int width_el, const OhUpsample *u);
+void oh_or_up_cr_h  (int variant, int bd, int16_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                     int x_el, int x_bl, int block_w, int block_h, int width_el, const OhUpsample *u);
+void oh_or_up_luma_v(int variant, int bd, uint8_t *dst, ptrdiff_t dststride, const int16_t *src, ptrdiff_t srcstride,
+                     int y_bl, int x_el, int y_el, int block_w, int block_h, int width_el, int height_el, const OhUpsample *u);
+void oh_or_up_cr_v  (int variant, int bd, uint8_t *dst, ptrdiff_t dststride, const int16_t *src, ptrdiff_t srcstride,
+                     int y_bl, int x_el, int y_el, int block_w, int block_h, int width_el, int height_el, const OhUpsample *u);
+/* whole picture, 8-bit 4:2:0 only like the reference's routine (its edge code and shift are written for bytes):
+ * upsample_base_layer_frame, hevcdsp_template.c:2164-2438.  el/bl: coded sizes = width[0]/height[0]. */
+int  oh_or_upsample_frame(const OhHostPic *bl, OhHostPic *el, const OhUpsample *u);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,3 +342,48 @@ API int ref_filter_picture(const OhFrame *f, uint8_t *const data[3], const ptrdi
     ctx_free(r);
     return 0;
 }
+
+/* ---------------- SHVC up-sampling slots (hevcdsp.h:98-123) ---------------- */
+static void up_fill(const OhUpsample *u, struct HEVCWindow *w, struct UpsamplInf *inf)
+{
+    w->left_offset = u->win_left; w->right_offset = u->win_right; w->top_offset = u->win_top; w->bottom_offset = u->win_bottom;
+    inf->addXLum = u->add_x_lum; inf->addYLum = u->add_y_lum; inf->scaleXLum = u->scale_x_lum; inf->scaleYLum = u->scale_y_lum;
+    inf->addXCr = u->add_x_cr; inf->addYCr = u->add_y_cr; inf->scaleXCr = u->scale_x_cr; inf->scaleYCr = u->scale_y_cr;
+    inf->idx = u->idx;
+}
+/* which: 0 luma_h, 1 cr_h (dst int16) ; 2 luma_v, 3 cr_v (src int16) */
+API void ref_up_block_h(int bd, int cr, int variant, int16_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                        int x_el, int x_bl, int block_w, int block_h, int width_el, const OhUpsample *u)
+{
+    struct HEVCWindow w; struct UpsamplInf inf;
+    tables(bd); up_fill(u, &w, &inf);
+    (cr ? g_dsp[bd].upsample_filter_block_cr_h : g_dsp[bd].upsample_filter_block_luma_h)[variant](dst, dststride, src, srcstride, x_el, x_bl,
+                                                                                            block_w, block_h, width_el, &w, &inf);
+}
+API void ref_up_block_v(int bd, int cr, int variant, uint8_t *dst, ptrdiff_t dststride, int16_t *src, ptrdiff_t srcstride,
+                        int y_bl, int x_el, int y_el, int block_w, int block_h, int width_el, int height_el, const OhUpsample *u)
+{
+    struct HEVCWindow w; struct UpsamplInf inf;
+    tables(bd); up_fill(u, &w, &inf);
+    (cr ? g_dsp[bd].upsample_filter_block_cr_v : g_dsp[bd].upsample_filter_block_luma_v)[variant](dst, dststride, src, srcstride, y_bl, x_el, y_el,
+                                                                                            block_w, block_h, width_el, height_el, &w, &inf);
+}
+/* the whole-picture slot (hevc.c:3241); planes/strides in bytes, 8-bit */
+API void ref_up_frame(uint8_t *const el[3], const int el_stride[3], int el_w, int el_h,
+                      uint8_t *const bl[3], const int bl_stride[3], int bl_w, int bl_h, const OhUpsample *u)
+{
+    struct HEVCWindow w; struct UpsamplInf inf;
+    AVFrame fe, fb;
+    short *buf[3];
+    size_t n = (size_t)el_w * (size_t)(el_h > bl_h ? el_h : bl_h);
+    tables(8); up_fill(u, &w, &inf);
+    memset(&fe, 0, sizeof(fe)); memset(&fb, 0, sizeof(fb));
+    for (int c = 0; c < 3; c++) {
+        fe.data[c] = el[c]; fe.linesize[c] = el_stride[c];
+        fb.data[c] = bl[c]; fb.linesize[c] = bl_stride[c];
+        buf[c] = (short *)malloc(n * sizeof(short));
+    }
+    fe.coded_width = el_w; fe.coded_height = el_h; fb.coded_width = bl_w; fb.coded_height = bl_h;
+    g_dsp[8].upsample_base_layer_frame(&fe, &fb, buf, &w, &inf, 1);
+    for (int c = 0; c < 3; c++) free(buf[c]);
+}

@@ -128,7 +128,34 @@ def picture_case(name, w, h, bd, chroma, lc, st, seed, knobs):
             "counts": [int(f.n_pu), int(f.n_tu), int(f.n_intra), int(f.n_levels), int(f.n_coeff)]}
 
 
+UPSAMPLE_CASES = [
+    # name, BL size, EL size, scaled reference layer window (left, right, top, bottom), phase_align_flag, seed
+    ("x2", (208, 120), (416, 240), (0, 0, 0, 0), 0, 31),
+    ("x1_5", (176, 96), (264, 144), (0, 0, 0, 0), 0, 32),
+    ("snr", (264, 144), (264, 144), (0, 0, 0, 0), 0, 33),
+    ("ratio_1_64_window", (200, 112), (328, 200), (8, 4, 4, 8), 0, 34),
+    ("x2_phase_align_1080p", (960, 544), (1920, 1088), (0, 0, 0, 0), 1, 35),
+]
+
+
+def upsample_case(name, bl_size, el_size, win, pa, seed):
+    """MD5s of the enhancement-layer planes the reference's upsample_base_layer_frame slot produces"""
+    (wb, hb), (we, he) = bl_size, el_size
+    u = F.upsample_setup(wb, hb, we, he, win, pa)
+    bl = F.HostPic(F.pic_params(wb, hb), rng=np.random.default_rng(seed))
+    el = F.HostPic(F.pic_params(we, he), fill=0)
+    el_p = (C.c_void_p * 3)(*[pl.ctypes.data for pl in el.planes])
+    bl_p = (C.c_void_p * 3)(*[pl.ctypes.data for pl in bl.planes])
+    el_s = (C.c_int * 3)(*[pl.strides[0] for pl in el.planes])
+    bl_s = (C.c_int * 3)(*[pl.strides[0] for pl in bl.planes])
+    ref().ref_up_frame(el_p, el_s, we, he, bl_p, bl_s, wb, hb, C.byref(u))
+    return md5_planes(el)
+
+
 def main():
+    import json
+    with open(os.path.join(HERE, "upsample.json"), "w") as fh:
+        json.dump({"cases": [list(c) for c in UPSAMPLE_CASES], "expected": {c[0]: upsample_case(*c) for c in UPSAMPLE_CASES}}, fh, indent=1)
     for bd in (8, 10):
         np.savez_compressed(os.path.join(HERE, f"slots_{bd}bit.npz"), **slot_vectors(bd))
     import json

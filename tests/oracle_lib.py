@@ -69,6 +69,9 @@ _ORACLE_SIGS = {
     "oh_or_sao_edge": [I, U8, U8, P, P, I16, I, IP, I, I, I, U8, U8, U8],
     "oh_or_pass_inter": [V, V], "oh_or_pass_residual": [V, V, I16], "oh_or_pass_intra": [V, V, I16],
     "oh_or_pass_deblock": [V, V], "oh_or_pass_sao": [V, V], "oh_or_frame": [V, V],
+    "oh_or_up_luma_h": [I, I, I16, P, U8, P, I, I, I, I, I, V], "oh_or_up_cr_h": [I, I, I16, P, U8, P, I, I, I, I, I, V],
+    "oh_or_up_luma_v": [I, I, U8, P, I16, P, I, I, I, I, I, I, I, V], "oh_or_up_cr_v": [I, I, U8, P, I16, P, I, I, I, I, I, I, I, V],
+    "oh_or_upsample_frame": [V, V, V],
 }
 _REF_SIGS = {
     "ref_transform_add": [I, I, U8, I16, P],
@@ -87,6 +90,9 @@ _REF_SIGS = {
     "ref_sao_edge": [I, I, U8, U8, P, P, I16, I, IP, I, I, I, U8, U8, U8],
     "ref_intra_picture": [V, V, V, I16],
     "ref_filter_picture": [V, V, V, V],
+    "ref_up_block_h": [I, I, I, I16, P, U8, P, I, I, I, I, I, V],
+    "ref_up_block_v": [I, I, I, U8, P, I16, P, I, I, I, I, I, I, I, V],
+    "ref_up_frame": [V, V, I, I, V, V, I, I, V],
 }
 
 
@@ -94,7 +100,7 @@ def _declare(lib, sigs):
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int if ("pass_" in name or name.endswith("_frame") or name.endswith("_picture")) else None
+        fn.restype = C.c_int if ("pass_" in name or name.endswith("_frame") or name.endswith("_picture")) and name != "ref_up_frame" else None
     return lib
 
 

@@ -105,3 +105,37 @@ def test_picture_fixtures(idx):
     assert oracle().oh_or_frame(C.byref(f), arr) == 0
     assert md5_planes(pics[2]) == want["final"]
     rec.close()
+
+
+def load_upsample_cases():
+    with open(os.path.join(GOLD, "upsample.json")) as fh:
+        return json.load(fh)
+
+
+def upsample_inputs(case):
+    """(parameters, base-layer picture, EL picture parameters) of one golden up-sampling case"""
+    name, bl_size, el_size, win, pa, seed = case
+    u = F.upsample_setup(bl_size[0], bl_size[1], el_size[0], el_size[1], tuple(win), pa)
+    bl = F.HostPic(F.pic_params(*bl_size), rng=np.random.default_rng(seed))
+    return u, bl, F.pic_params(*el_size)
+
+
+def test_oracle_upsample_matches_reference_md5s():
+    """SHVC up-sampling: the oracle's whole-picture routine reproduces the MD5s recorded from
+    the reference's upsample_base_layer_frame slot (tests/golden/make_golden.py)"""
+    import ctypes as C
+    from oracle_lib import OhHostPicC, oracle
+    gold = load_upsample_cases()
+    for case in gold["cases"]:
+        u, bl, pe = upsample_inputs(case)
+        el = F.HostPic(pe, fill=0)
+        hps = []
+        for hp_, p_ in ((bl, bl.params), (el, pe)):
+            h = OhHostPicC()
+            for c, pl in enumerate(hp_.planes):
+                w, hh = F.plane_dims(p_, c)
+                h.data[c], h.stride[c], h.width[c], h.height[c] = pl.ctypes.data, pl.strides[0], w, hh
+            h.bit_depth = 8
+            hps.append(h)
+        assert oracle().oh_or_upsample_frame(C.byref(hps[0]), C.byref(hps[1]), C.byref(u)) == 0
+        assert md5_planes(el) == gold["expected"][case[0]], case[0]

@@ -263,3 +263,44 @@ def test_batched_pictures(eng, n, w, h, bd):
     for v in list(ids.values()) + cur_ids:
         eng.pic_free(v)
     rec.close()
+
+
+def test_shvc_upsample_pictures(eng):
+    """oh_pic_upsample against the MD5s recorded from the reference's
+    upsample_base_layer_frame slot, and the resampled picture used as a reference by a B picture"""
+    from test_golden import load_upsample_cases, md5_planes, upsample_inputs
+    from openhevc_amd.engine import EngineError, remap_frame
+    gold = load_upsample_cases()
+    for case in gold["cases"]:
+        u, bl, pe = upsample_inputs(case)
+        b_id, e_id = eng.pic_alloc(bl.params), eng.pic_alloc(pe)
+        eng.pic_upload(b_id, bl)
+        eng.pic_upsample(e_id, b_id, u)
+        eng.sync()
+        got = eng.pic_download(e_id, pe)
+        assert md5_planes(got) == gold["expected"][case[0]], case[0]
+        if case[0] == "x2":                                 # inter-layer prediction: the EL picture predicts from it
+            rec = F.Recorder(pe)
+            f = rec.synth(F.synth_params(2, 4242), 2, [0, 1])
+            rng = np.random.default_rng(3)
+            other, cur = F.HostPic(pe, rng=rng), F.HostPic(pe, rng=rng)
+            o_id, c_id = eng.pic_alloc(pe), eng.pic_alloc(pe)
+            eng.pic_upload(o_id, other)
+            eng.pic_upload(c_id, cur)
+            eng.frame_submit(remap_frame(f, {0: e_id, 1: o_id, 2: c_id}))
+            eng.sync()
+            pics = {0: got.copy(), 1: other.copy(), 2: cur.copy()}
+            assert oracle().oh_or_frame(C.byref(f), host_pic_array(pics)) == 0
+            assert_same(pics[2], eng.pic_download(c_id, pe), "EL picture predicted from the up-sampled BL picture")
+            eng.pic_free(o_id)
+            eng.pic_free(c_id)
+            rec.close()
+        eng.pic_free(b_id)
+        eng.pic_free(e_id)
+    # the reference's routine is 8-bit only: a 10-bit request is refused, not approximated
+    p10 = F.pic_params(416, 240, bit_depth=10)
+    a, b = eng.pic_alloc(p10), eng.pic_alloc(p10)
+    with pytest.raises(EngineError):
+        eng.pic_upsample(a, b, F.upsample_setup(416, 240, 416, 240))
+    eng.pic_free(a)
+    eng.pic_free(b)

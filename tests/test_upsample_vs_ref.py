@@ -1,0 +1,98 @@
+"""SHVC inter-layer up-sampling: the oracle's restatement against the reference's own slots
+(upsample_filter_block_{luma,cr}_{h,v}[3], upsample_base_layer_frame) compiled from /root/reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from openhevc_amd import frame as F
+from oracle_lib import OhHostPicC, have_ref, i16p, off_i16p, off_u8p, oracle, ref, u8p
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="reference tree not present")
+
+# (BL size, EL size, window) -> the reference picks X2 / X1_5 / DEFAULT by the resulting scale factors
+GEOMS = {
+    F.OH_UP_X2: ((208, 120), (416, 240), (0, 0, 0, 0)),
+    F.OH_UP_X1_5: ((176, 96), (264, 144), (0, 0, 0, 0)),
+    F.OH_UP_DEFAULT: ((200, 112), (328, 200), (8, 4, 4, 8)),
+}
+
+
+@pytest.mark.parametrize("variant", [F.OH_UP_DEFAULT, F.OH_UP_X2, F.OH_UP_X1_5])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_block_slots(variant, bd):
+    (wb, hb), (we, he), win = GEOMS[variant]
+    u = F.upsample_setup(wb, hb, we, he, win)
+    assert u.idx == variant
+    rng = np.random.default_rng(variant * 10 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    for cr in (0, 1):
+        sh = 1 if cr else 0
+        w_el, h_el = we >> sh, he >> sh
+        # horizontal slots: a block of EL columns from a window of BL rows (margin for the taps on both sides)
+        src = rng.integers(0, 1 << bd, size=(40, 256)).astype(dt)
+        for x_el in (0, 16, w_el - 24):
+            bw, bh = 24, 20
+            x = max(x_el - (win[0] >> sh), 0)
+            x_bl = max(((x * u.scale_x_lum + u.add_x_lum) >> 16) - 4, 0)          # the driver's bl_x, up to the margin
+            want = np.zeros((bh, 32), np.int16)
+            got = np.zeros((bh, 32), np.int16)
+            sp = off_u8p(src, (8 * 256 + 16) * src.itemsize)
+            ref().ref_up_block_h(bd, cr, variant, i16p(want), 32, sp, 256, x_el, x_bl, bw, bh, w_el, C.byref(u))
+            (oracle().oh_or_up_cr_h if cr else oracle().oh_or_up_luma_h)(variant, bd, i16p(got), 32, sp, 256, x_el, x_bl, bw, bh, w_el, C.byref(u))
+            assert np.array_equal(want, got), (cr, x_el)
+        # vertical slots: int16 rows -> pixels of the EL plane
+        tmp = rng.integers(-8000, 24000, size=(64, 64)).astype(np.int16)
+        for x_el, y_el in ((0, 0), (16, 8), (w_el - 24, h_el - 16)):
+            bw, bh = 24, 16
+            y = max(y_el - (win[2] >> sh), 0)
+            y_bl = max(((y * u.scale_y_lum + u.add_y_lum) >> 16) - 4, 0)
+            want = np.zeros((h_el, w_el + 8), dt)
+            got = np.zeros((h_el, w_el + 8), dt)
+            tp = off_i16p(tmp, 8 * 64)
+            ref().ref_up_block_v(bd, cr, variant, u8p(want), w_el + 8, tp, 64, y_bl, x_el, y_el, bw, bh, w_el, h_el, C.byref(u))
+            (oracle().oh_or_up_cr_v if cr else oracle().oh_or_up_luma_v)(variant, bd, u8p(got), w_el + 8, tp, 64, y_bl, x_el, y_el, bw, bh, w_el, h_el, C.byref(u))
+            assert np.array_equal(want, got), (cr, x_el, y_el)
+
+
+def host_pic(p, planes):
+    hp = OhHostPicC()
+    for c, pl in enumerate(planes):
+        w, h = F.plane_dims(p, c)
+        hp.data[c] = pl.ctypes.data
+        hp.stride[c] = pl.strides[0]
+        hp.width[c], hp.height[c] = w, h
+    hp.bit_depth = 8
+    return hp
+
+
+def run_frame_both(bl_size, el_size, win, seed, phase_align=0):
+    (wb, hb), (we, he) = bl_size, el_size
+    u = F.upsample_setup(wb - 0, hb - 0, we, he, win, phase_align)
+    pb, pe = F.pic_params(wb, hb), F.pic_params(we, he)
+    rng = np.random.default_rng(seed)
+    bl = F.HostPic(pb, rng=rng)
+    want, got = F.HostPic(pe, fill=0), F.HostPic(pe, fill=0)
+    el_p = (C.c_void_p * 3)(*[pl.ctypes.data for pl in want.planes])
+    bl_p = (C.c_void_p * 3)(*[pl.ctypes.data for pl in bl.planes])
+    el_s = (C.c_int * 3)(*[pl.strides[0] for pl in want.planes])
+    bl_s = (C.c_int * 3)(*[pl.strides[0] for pl in bl.planes])
+    ref().ref_up_frame(el_p, el_s, we, he, bl_p, bl_s, wb, hb, C.byref(u))
+    hb_, he_ = host_pic(pb, bl.planes), host_pic(pe, got.planes)
+    assert oracle().oh_or_upsample_frame(C.byref(hb_), C.byref(he_), C.byref(u)) == 0
+    return u, bl, want, got
+
+
+@pytest.mark.parametrize("name,bl_size,el_size,win,pa", [
+    ("x2", (208, 120), (416, 240), (0, 0, 0, 0), 0),
+    ("x1_5", (176, 96), (264, 144), (0, 0, 0, 0), 0),
+    ("snr", (264, 144), (264, 144), (0, 0, 0, 0), 0),
+    ("ratio_1_64_window", (200, 112), (328, 200), (8, 4, 4, 8), 0),
+    ("x2_phase_align", (208, 120), (416, 240), (0, 0, 0, 0), 1),
+    ("x2_window", (200, 112), (416, 240), (8, 8, 8, 8), 0),
+])
+def test_frame_slot(name, bl_size, el_size, win, pa):
+    """upsample_base_layer_frame (hevcdsp_template.c:2164-2438), 8 bit"""
+    _, _, want, got = run_frame_both(bl_size, el_size, win, 77, pa)
+    for c in range(3):
+        assert np.array_equal(want.visible(c), got.visible(c)), (name, c)

@@ -47,7 +47,8 @@ typedef struct OhPicParams {
     int32_t cb_qp_offset, cr_qp_offset; /* pps offsets used by chroma_tc (hevc_filter.c:62-89) */
     int32_t sao_enabled;              /* sps->sao_enabled                                      */
     int32_t deblock_enabled;          /* 0: skip pass 4 entirely (all BS would be 0)           */
-    int32_t reserved[4];
+    int32_t constrained_intra_pred;   /* pps->constrained_intra_pred_flag (hevcpred_template.c:116-249)  */
+    int32_t reserved[3];
 } OhPicParams;
 
 /* ---- pass 1: inter prediction.  One item = one PU rectangle, already cut to <= 64x64 luma. ---- */
@@ -157,6 +158,8 @@ typedef struct OhFrame {
     const uint8_t      *is_pcm;       /* min_pu_width x min_pu_height, may be NULL (hevc.c:147)   */
     const OhDeblockCtb *deblock;      /* ctb_width x ctb_height                                   */
     const OhSaoCtb     *sao;          /* ctb_width x ctb_height, may be NULL when !sao_enabled    */
+    const uint8_t      *is_intra;     /* min_pu_width x min_pu_height: 1 where the covering CU is intra (tab_mvf[].pred_flag ==
+                                         PF_INTRA, incl. PCM CUs); required when constrained_intra_pred, else may be NULL */
 } OhFrame;
 
 /* ---- derived geometry helpers (all integer, shared by every consumer) ---- */

@@ -57,6 +57,8 @@ uint8_t      *oh_rec_vertical_bs(OhRecorder *r);
 uint8_t      *oh_rec_horizontal_bs(OhRecorder *r);
 int8_t       *oh_rec_qp_y_tab(OhRecorder *r);
 uint8_t      *oh_rec_is_pcm(OhRecorder *r);
+uint8_t      *oh_rec_is_intra(OhRecorder *r);   /* min-PU map of intra CUs (tab_mvf pred_flag), zeroed by oh_rec_begin; only
+                                                 consumed when OhPicParams.constrained_intra_pred */
 OhDeblockCtb *oh_rec_deblock(OhRecorder *r);
 OhSaoCtb     *oh_rec_sao(OhRecorder *r);
 

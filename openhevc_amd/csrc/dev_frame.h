@@ -60,7 +60,8 @@ struct OhIntraLaunch {                             /* one wavefront level of a b
     uint32_t waves;                                /* waves per workgroup (CTU)                               */
 };
 
-enum { OH_IF_FILTER = 1, OH_IF_STRONG_CAND = 2, OH_IF_EDGE = 4 };            /* DevIntra.flags bits 0..2 */
+enum { OH_IF_FILTER = 1, OH_IF_STRONG_CAND = 2, OH_IF_EDGE = 4,              /* DevIntra.flags bits 0..2 */
+       OH_IF_CIP = 8, OH_IF_CIP_CORNER = 128 };                              /* constrained intra pred: slow path; corner sample intra */
 enum { OH_IC_PLANAR = 0, OH_IC_DC, OH_IC_ANG_V, OH_IC_ANG_H, OH_IC_PURE_V, OH_IC_PURE_H };   /* flags >> 4 */
 
 /* intra block as the kernel wants it: OhIntra plus everything that only depends on the block's
@@ -77,7 +78,8 @@ struct DevIntra {
     uint8_t  flags;               /* OH_IF_* | (OH_IC_* << 4)                                   */
     int16_t  inv_angle;           /* invAngle when the side projection is needed, else 0        */
     uint32_t res_lds;             /* offset of the residual inside the staged span (res_off - res_lo) */
-    uint32_t pad;
+    uint16_t cip_left, cip_top;   /* constrained intra pred: bit k = the 4-sample group k of the left column / top row
+                                     belongs to an intra CU (IS_INTRA(-1, 4k) / IS_INTRA(4k, -1), hevcpred_template.c:37-41) */
 };
 
 /* OhIntraCtu plus the span of the residual pool its blocks use (staged in LDS when it fits) */

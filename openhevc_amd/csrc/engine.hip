@@ -509,6 +509,8 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
         if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
             FAIL(e, OH_E_ARG, "TU %u: rotation is 4x4 only", i);
     }
+    if (f->n_intra && p.constrained_intra_pred && !f->is_intra)
+        FAIL(e, OH_E_ARG, "constrained_intra_pred without the is_intra map");
     if (f->n_intra) {
         /* CTU wavefront tables: levels -> ictu[] -> sub_start[] -> intra[] must nest exactly */
         if (!f->level_start || !f->n_levels || !f->ictu || !f->n_ictu || !f->sub_start || !f->n_sub ||
@@ -650,6 +652,45 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         if (mode >= 2) {
             d.angle = k_angle[mode - 2];
             if (d.angle < 0 && ((n * d.angle) >> 5) < -1) d.inv_angle = k_inv_angle[mode - 11];
+        }
+        if (p.constrained_intra_pred) {
+            /* hevcpred_template.c:116-163: candidates that lie in inter CUs do not count; the kernel's slow path then
+             * patches the gathered edges from the per-group intra masks (:185-249) */
+            const uint8_t *map = f->is_intra;
+            const int lpu = p.log2_min_pu_size, mpw = p.width >> lpu, mph = p.height >> lpu;
+            const int X0 = it.x << hs, Y0 = it.y << vs, sl_h = n << hs, sl_v = n << vs;
+            auto cell = [&](int px, int py) { return px >= 0 && py >= 0 && px < mpw && py < mph && map[px + py * mpw] != 0; };
+            auto isi = [&](int dx, int dy) { return cell((X0 + dx * (1 << hs)) >> lpu, (Y0 + dy * (1 << vs)) >> lpu); };
+            int pu_v = sl_v >> lpu, pu_h = sl_h >> lpu, av = it.avail;
+            const bool on_x = !(X0 & ((1 << lpu) - 1)), on_y = !(Y0 & ((1 << lpu) - 1));
+            if (!pu_h) pu_h++;
+            auto any2 = [&](int px, int py, int dx, int dy, int cnt) { bool r = false; for (int i = 0; i < cnt; i += 2) r |= cell(px + i * dx, py + i * dy); return r; };
+            if ((av & OH_AV_BOTTOM_LEFT) && on_x) {
+                int yb = (Y0 + sl_v) >> lpu;
+                if (!any2((X0 - 1) >> lpu, yb, 0, 1, std::min(pu_v, mph - yb))) av &= ~OH_AV_BOTTOM_LEFT;
+            }
+            if ((av & OH_AV_LEFT) && on_x) {
+                int yl = Y0 >> lpu;
+                if (!any2((X0 - 1) >> lpu, yl, 0, 1, std::min(pu_v, mph - yl))) av &= ~OH_AV_LEFT;
+            }
+            if ((av & OH_AV_UP_LEFT) && !cell((X0 - 1) >> lpu, (Y0 - 1) >> lpu)) av &= ~OH_AV_UP_LEFT;
+            if ((av & OH_AV_UP) && on_y) {
+                int xt = X0 >> lpu;
+                if (!any2(xt, (Y0 - 1) >> lpu, 1, 0, std::min(pu_h, mpw - xt))) av &= ~OH_AV_UP;
+            }
+            if ((av & OH_AV_UP_RIGHT) && on_y) {
+                int xr = (X0 + sl_h) >> lpu;
+                if (!any2(xr, (Y0 - 1) >> lpu, 1, 0, std::min(pu_h, mpw - xr))) av &= ~OH_AV_UP_RIGHT;
+            }
+            d.avail = (uint8_t)av;
+            unsigned lm = 0, tm = 0;
+            for (int k = 0; 4 * k < 2 * n; k++) {
+                if (it.x > 0 && isi(-1, 4 * k)) lm |= 1u << k;
+                if (it.y > 0 && isi(4 * k, -1)) tm |= 1u << k;
+            }
+            d.cip_left = (uint16_t)lm; d.cip_top = (uint16_t)tm;
+            flags |= OH_IF_CIP;
+            if (it.x > 0 && it.y > 0 && isi(-1, -1)) flags |= OH_IF_CIP_CORNER;
         }
         d.flags = (uint8_t)(flags | (cls << 4));
     }

@@ -591,6 +591,97 @@ static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, GLOBAL P
     else                 *(GLOBAL uint2v *)g = pk16;
 }
 
+/* constrained_intra_pred (hevcpred_template.c:185-286) for one block, run by ONE lane over the wave's edge arrays
+ * left[k] = E[1 + k], top[k] = E[67 + k] (k = -1..63) after the gather with the re-derived candidate flags.
+ * lm / tm: bit g = the 4-sample group g of the left column / top row lies in an intra CU; corner likewise. */
+typedef __attribute__((address_space(3))) int lds_int;     /* keeps the accesses ds_* (a generic pointer would make them flat_*,
+                                                              which are not ordered against ds_* of the same wave) */
+static __device__ __forceinline__ void cip_patch(lds_int *E, const int n, const int avail, const unsigned lm, const unsigned tm, const bool corner_intra,
+                                              const int size_max_x, const int size_max_y, const int bl_size,
+                                              const bool x_nz, const bool y_nz, const int bd)
+{
+    lds_int *left = E + 1, *top = E + 67;
+    bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT, a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
+    auto isl = [&](int j) { return j < 0 ? corner_intra : ((lm >> (j >> 2)) & 1) != 0; };
+    auto ist = [&](int j) { return j < 0 ? corner_intra : ((tm >> (j >> 2)) & 1) != 0; };
+    if (a_bl || a_l || a_ul || a_u || a_ur) {
+        int j = n + bl_size - 1;
+        if (a_bl || a_l || a_ul) {
+            while (j > -1 && !isl(j)) j--;
+            if (!isl(j)) {
+                j = 0;
+                while (j < size_max_x && !ist(j)) j++;
+                for (int i = j; i > -1; i--)
+                    if (!ist(i - 1)) top[i - 1] = top[i];
+                left[-1] = top[-1];
+            }
+        } else {
+            j = 0;
+            while (j < size_max_x && !ist(j)) j++;
+            if (j > 0) {
+                for (int i = j; i > (x_nz ? -1 : 0); i--)
+                    if (!ist(i - 1)) top[i - 1] = top[i];
+                if (!x_nz) top[-1] = top[0];
+            }
+        }
+        left[-1] = top[-1];
+        if (a_bl || a_l) {
+            int a = left[-1];
+            for (int i = 0; i < size_max_y; i += 4) {
+                if (!isl(i)) { left[i] = a; left[i + 1] = a; left[i + 2] = a; left[i + 3] = a; }
+                else a = left[i + 3];
+            }
+        }
+        if (!a_l)  for (int i = 0; i < n; i++) left[i] = left[-1];
+        if (!a_bl) { const int v = left[n - 1]; for (int i = 0; i < n; i++) left[n + i] = v; }
+        if (!x_nz) {
+            for (int i = 0; i < size_max_y; i++) left[i] = 0;
+        } else {
+            int a = left[size_max_y - 1];
+            for (int i = size_max_y - 1; i > -1; i -= 4) {
+                if (!isl(i - 3)) { left[i - 3] = a; left[i - 2] = a; left[i - 1] = a; left[i] = a; }
+                else a = left[i - 3];
+            }
+            if (y_nz && !corner_intra) left[-1] = left[0];
+        }
+        top[-1] = left[-1];
+        if (y_nz) {
+            int a = left[-1];
+            for (int i = 0; i < size_max_x; i += 4) {
+                if (!ist(i)) { top[i] = a; top[i + 1] = a; top[i + 2] = a; top[i + 3] = a; }
+                else a = top[i + 3];
+            }
+        }
+    }
+    /* missing samples, :251-286 */
+    if (!a_bl) {
+        if (a_l) {
+            const int v = left[n - 1];
+            for (int i = 0; i < n; i++) left[n + i] = v;
+        } else if (a_ul) {
+            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            a_l = true;
+        } else if (a_u) {
+            left[-1] = top[0];
+            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            a_ul = a_l = true;
+        } else if (a_ur) {
+            for (int i = 0; i < n; i++) top[i] = top[n];
+            left[-1] = top[n];
+            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            a_u = a_ul = a_l = true;
+        } else {
+            left[-1] = 1 << (bd - 1);
+            for (int i = 0; i < 2 * n; i++) { top[i] = left[-1]; left[i] = left[-1]; }
+        }
+    }
+    if (!a_l)  { const int v = left[n]; for (int i = 0; i < n; i++) left[i] = v; }
+    if (!a_ul) left[-1] = left[0];
+    if (!a_u)  for (int i = 0; i < n; i++) top[i] = left[-1];
+    if (!a_ur) { const int v = top[n - 1]; for (int i = 0; i < n; i++) top[n + i] = v; }
+    top[-1] = left[-1];
+}
+
 template <typename PX>
 static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
                                                    const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
@@ -607,7 +698,8 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
     const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
     const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
-    const int n = 1 << log2, cls = flags >> 4;
+    const int n = 1 << log2, cls = (flags >> 4) & 7;
+    const uint32_t w7 = __builtin_amdgcn_readfirstlane(q1[3]);           /* cip_left | cip_top << 16 */
     const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
     const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
     const int i = lane;                                                /* element this lane owns */
@@ -628,10 +720,10 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
 
     /* gather (:164-183) from the staged CTU: lane i owns top[i] and left[i]; branch-free addresses */
     int tv = 0, lv = 0, cv = 0;
+    const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
     {
         const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
         const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
-        const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
         if (t_ok) tv = M[top_off + ti];
         if (l_ok) lv = M[cm_off - 1 + li * rs];
         if (a_ul) cv = M[top_off - 1];
@@ -641,14 +733,29 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const int l_0 = __builtin_amdgcn_readlane(lv, 0), l_n1 = __builtin_amdgcn_readlane(lv, n - 1), l_n = __builtin_amdgcn_readlane(lv, n & 63);
     const int t_0 = __builtin_amdgcn_readlane(tv, 0), t_n1 = __builtin_amdgcn_readlane(tv, n - 1), t_n = __builtin_amdgcn_readlane(tv, n & 63);
     int corner, left_i, top_i;
-    if (a_bl || a_l) {
+    if (flags & OH_IF_CIP) {
+        /* constrained intra prediction: rare, so one lane replays the reference's sweeps over the published edges
+         * (cip_patch) instead of a lane-parallel closed form */
+        const int fill = sizeof(PX) == 1 ? 128 : 0x8080;                   /* memset(.., 128, ..) over 16-bit samples, :158-160 */
+        int *E = s.E;
+        E[1 + i] = l_ok ? lv : fill;
+        E[67 + i] = t_ok ? tv : fill;
+        if (lane == 0) { E[0] = a_ul ? cv : 0; E[66] = a_ul ? cv : 128; }
+        WSYNC();
+        if (lane == 0)
+            cip_patch((lds_int *)E, n, avail, w7 & 0xffff, w7 >> 16, (flags & OH_IF_CIP_CORNER) != 0, a_ur ? n + tr_size : n, a_bl ? n + bl_size : n,
+                      a_bl ? bl_size : 0, bx != 0, by != 0, bd);
+        WSYNC();
+        left_i = E[1 + i]; top_i = E[67 + i]; corner = E[0];
+    } else if (a_bl || a_l) {
         left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
         corner = a_ul ? cv : (a_l ? l_0 : l_n);
     } else {
         corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : (1 << (bd - 1))));
         left_i = corner;
     }
-    top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
+    if (!(flags & OH_IF_CIP))
+        top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
 
     /* smoothing (:288-326) with whole-wave DPP shifts; the mode/size test was done on the host */
     if (flags & OH_IF_FILTER) {

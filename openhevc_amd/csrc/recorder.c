@@ -38,7 +38,7 @@ struct OhRecorder {
     uint32_t  *sub_start; uint32_t cap_sub;
     uint32_t  *level_start;
     /* side arrays */
-    uint8_t *vbs, *hbs, *is_pcm;
+    uint8_t *vbs, *hbs, *is_pcm, *is_intra;
     int8_t  *qp;
     OhDeblockCtb *deblock;
     OhSaoCtb *sao;
@@ -88,6 +88,7 @@ OhRecorder *oh_rec_create(const OhPicParams *p)
     r->hbs = (uint8_t *)calloc(r->f.bs_size, 1);
     r->qp = (int8_t *)calloc(oh_qp_tab_size(p), 1);
     r->is_pcm = (uint8_t *)calloc((size_t)oh_min_pu_width(p) * oh_min_pu_height(p) + 1, 1);
+    r->is_intra = (uint8_t *)calloc((size_t)oh_min_pu_width(p) * oh_min_pu_height(p) + 1, 1);
     r->deblock = (OhDeblockCtb *)calloc((size_t)r->n_ctb, sizeof(OhDeblockCtb));
     r->sao = (OhSaoCtb *)calloc((size_t)r->n_ctb, sizeof(OhSaoCtb));
     return r;
@@ -102,7 +103,7 @@ void oh_rec_destroy(OhRecorder *r)
     free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->it_ctu); free(r->it_sub);
     free(r->sorted); free(r->ctu_dep); free(r->ctu_nsub); free(r->ctu_level); free(r->ctu_entry); free(r->ictu);
     free(r->sub_start); free(r->level_start);
-    free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->qp); free(r->deblock); free(r->sao);
+    free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->qp); free(r->deblock); free(r->sao);
     for (int c = 0; c < 3; c++)
         free(r->lvl[c]);
     free(r->decoded);
@@ -120,6 +121,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
     memset(r->is_pcm, 0, (size_t)oh_min_pu_width(p) * oh_min_pu_height(p));
+    memset(r->is_intra, 0, (size_t)oh_min_pu_width(p) * oh_min_pu_height(p));
     memset(r->sao, 0, (size_t)r->n_ctb * sizeof(OhSaoCtb));
     memset(r->deblock, 0, (size_t)r->n_ctb * sizeof(OhDeblockCtb));
     memset(r->ctu_dep, 0, (size_t)r->n_ctb);
@@ -246,6 +248,7 @@ uint8_t      *oh_rec_vertical_bs(OhRecorder *r)   { return r->vbs; }
 uint8_t      *oh_rec_horizontal_bs(OhRecorder *r) { return r->hbs; }
 int8_t       *oh_rec_qp_y_tab(OhRecorder *r)      { return r->qp; }
 uint8_t      *oh_rec_is_pcm(OhRecorder *r)        { return r->is_pcm; }
+uint8_t      *oh_rec_is_intra(OhRecorder *r)      { return r->is_intra; }
 OhDeblockCtb *oh_rec_deblock(OhRecorder *r)       { return r->deblock; }
 OhSaoCtb     *oh_rec_sao(OhRecorder *r)           { return r->sao; }
 
@@ -321,6 +324,7 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     f->n_levels = max_level; f->level_start = r->level_start;
     f->vertical_bs = r->vbs; f->horizontal_bs = r->hbs; f->qp_y_tab = r->qp;
     f->is_pcm = (f->p.pcm_loop_filter_disable || f->p.transquant_bypass_enable) ? r->is_pcm : NULL;
+    f->is_intra = f->p.constrained_intra_pred ? r->is_intra : NULL;
     f->deblock = r->deblock;
     f->sao = f->p.sao_enabled ? r->sao : NULL;
     return f;

@@ -24,7 +24,7 @@ class OhPicParams(C.Structure):
         "width", "height", "bit_depth", "chroma_format_idc", "log2_ctb_size", "log2_min_cb_size",
         "log2_min_tb_size", "log2_min_pu_size", "pcm_loop_filter_disable", "transquant_bypass_enable",
         "strong_intra_smoothing", "intra_smoothing_disabled", "cb_qp_offset", "cr_qp_offset",
-        "sao_enabled", "deblock_enabled")] + [("reserved", C.c_int32 * 4)]
+        "sao_enabled", "deblock_enabled", "constrained_intra_pred")] + [("reserved", C.c_int32 * 3)]
 
 
 class OhPu(C.Structure):
@@ -73,7 +73,7 @@ class OhFrame(C.Structure):
         ("n_levels", C.c_uint32), ("level_start", C.POINTER(C.c_uint32)),
         ("bs_size", C.c_uint32), ("vertical_bs", C.POINTER(C.c_uint8)), ("horizontal_bs", C.POINTER(C.c_uint8)),
         ("qp_y_tab", C.POINTER(C.c_int8)), ("is_pcm", C.POINTER(C.c_uint8)),
-        ("deblock", C.POINTER(OhDeblockCtb)), ("sao", C.POINTER(OhSaoCtb)),
+        ("deblock", C.POINTER(OhDeblockCtb)), ("sao", C.POINTER(OhSaoCtb)), ("is_intra", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -119,7 +119,8 @@ def upsample_setup(width_bl, height_bl, width_el, height_el, win=(0, 0, 0, 0), p
 
 def pic_params(width, height, bit_depth=8, chroma_format_idc=1, log2_ctb_size=6, log2_min_cb_size=3,
                log2_min_tb_size=2, sao=1, deblock=1, strong_intra_smoothing=1, pcm_loop_filter_disable=0,
-               transquant_bypass_enable=0, cb_qp_offset=0, cr_qp_offset=0, intra_smoothing_disabled=0):
+               transquant_bypass_enable=0, cb_qp_offset=0, cr_qp_offset=0, intra_smoothing_disabled=0,
+               constrained_intra_pred=0):
     p = OhPicParams()
     p.width, p.height, p.bit_depth, p.chroma_format_idc = width, height, bit_depth, chroma_format_idc
     p.log2_ctb_size, p.log2_min_cb_size, p.log2_min_tb_size = log2_ctb_size, log2_min_cb_size, log2_min_tb_size
@@ -127,6 +128,7 @@ def pic_params(width, height, bit_depth=8, chroma_format_idc=1, log2_ctb_size=6,
     p.sao_enabled, p.deblock_enabled, p.strong_intra_smoothing = sao, deblock, strong_intra_smoothing
     p.pcm_loop_filter_disable, p.transquant_bypass_enable = pcm_loop_filter_disable, transquant_bypass_enable
     p.cb_qp_offset, p.cr_qp_offset, p.intra_smoothing_disabled = cb_qp_offset, cr_qp_offset, intra_smoothing_disabled
+    p.constrained_intra_pred = constrained_intra_pred
     assert width % (1 << log2_min_cb_size) == 0 and height % (1 << log2_min_cb_size) == 0
     return p
 
@@ -189,7 +191,7 @@ def host():
         lib.oh_rec_avail.argtypes = [V, I, I, I, I]
         lib.oh_rec_mark_decoded.argtypes = [V, I, I, I, I]
         for n, t in (("oh_rec_vertical_bs", C.c_uint8), ("oh_rec_horizontal_bs", C.c_uint8), ("oh_rec_qp_y_tab", C.c_int8),
-                     ("oh_rec_is_pcm", C.c_uint8), ("oh_rec_deblock", OhDeblockCtb), ("oh_rec_sao", OhSaoCtb)):
+                     ("oh_rec_is_pcm", C.c_uint8), ("oh_rec_is_intra", C.c_uint8), ("oh_rec_deblock", OhDeblockCtb), ("oh_rec_sao", OhSaoCtb)):
             getattr(lib, n).argtypes = [V]
             getattr(lib, n).restype = C.POINTER(t)
         lib.oh_synth_defaults.argtypes = [C.POINTER(OhSynthParams), I, C.c_uint64]

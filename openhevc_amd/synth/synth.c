@@ -24,7 +24,7 @@ typedef struct Gen {
     uint64_t s;
     Cell *cells; int cw, ch;
     int32_t ref_pics[OH_MAX_REFS]; int n_ref;
-    int8_t *qp; uint8_t *is_pcm;
+    int8_t *qp; uint8_t *is_pcm, *is_intra;
     int16_t blk[32 * 32];
 } Gen;
 
@@ -283,6 +283,12 @@ static void gen_cu(Gen *g, int x, int y, int log2)
     cu.intra = sp->slice_type == 0 || pct(g, sp->intra_pct);
     cu.bypass = g->p.transquant_bypass_enable && pct(g, sp->bypass_pct);
     int pcm = cu.intra && log2 >= 3 && log2 <= 5 && pct(g, sp->pcm_pct);
+    if (cu.intra) {                                     /* tab_mvf[].pred_flag = PF_INTRA for every PU of the CU, hevc.c:2380-2395 */
+        int lp = g->p.log2_min_pu_size, mpw = oh_min_pu_width(&g->p);
+        for (int yy = y >> lp; yy < (y + n) >> lp; yy++)
+            for (int xx = x >> lp; xx < (x + n) >> lp; xx++)
+                g->is_intra[yy * mpw + xx] = 1;
+    }
     if ((cu.bypass) || (pcm && g->p.pcm_loop_filter_disable)) {   /* set_deblocking_bypass, hevc.c:1428-1441 */
         int lp = g->p.log2_min_pu_size, mpw = oh_min_pu_width(&g->p);
         for (int yy = y >> lp; yy < (y + n) >> lp; yy++)
@@ -446,6 +452,7 @@ const OhFrame *oh_synth_picture(OhRecorder *rec, const OhSynthParams *sp, int cu
     oh_rec_begin(rec, cur_pic, ref_pics, n_ref_pics);
     g.qp = oh_rec_qp_y_tab(rec);
     g.is_pcm = oh_rec_is_pcm(rec);
+    g.is_intra = oh_rec_is_intra(rec);
     memset(g.qp, sp->qp_base, oh_qp_tab_size(&g.p));
 
     int ctb = 1 << g.p.log2_ctb_size;

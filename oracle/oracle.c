@@ -232,10 +232,10 @@ void oh_or_pred_angular(int bd, uint8_t *dst, const uint8_t *top, const uint8_t 
                  pred_angular_16(bd, (uint16_t *)dst, (const uint16_t *)top, (const uint16_t *)left, stride, log2, c_idx, mode));
 }
 void oh_or_intra_pred(const OhPicParams *p, uint8_t *plane, ptrdiff_t stride, int pw, int ph,
-                      int x, int y, int c_idx, int log2, int mode, int avail)
+                      int x, int y, int c_idx, int log2, int mode, int avail, const uint8_t *is_intra)
 {
-    DISPATCH(p->bit_depth, intra_pred_8(p, plane, stride, pw, ph, x, y, c_idx, log2, mode, avail),
-                           intra_pred_16(p, (uint16_t *)plane, stride / 2, pw, ph, x, y, c_idx, log2, mode, avail));
+    DISPATCH(p->bit_depth, intra_pred_8(p, plane, stride, pw, ph, x, y, c_idx, log2, mode, avail, is_intra),
+                           intra_pred_16(p, (uint16_t *)plane, stride / 2, pw, ph, x, y, c_idx, log2, mode, avail, is_intra));
 }
 void oh_or_loop_filter_luma(int bd, uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys, int beta, const int *tc,
                             const uint8_t *no_p, const uint8_t *no_q)
@@ -409,7 +409,7 @@ int oh_or_pass_intra(const OhFrame *f, OhHostPic *pics, const int16_t *residuals
         const OhIntra *it = &f->intra[i];
         int c = it->c_idx;
         oh_or_intra_pred(&f->p, cur->data[c], cur->stride[c], cur->width[c], cur->height[c],
-                         it->x, it->y, c, it->log2_size, it->mode, it->avail);
+                         it->x, it->y, c, it->log2_size, it->mode, it->avail, f->is_intra);
         if (it->tu != OH_NO_COEFF) {
             const OhTu *tu = &f->tu[it->tu];
             tu_store(f, cur, tu, residuals + tu->coeff_off);

@@ -68,7 +68,7 @@ void oh_or_pred_angular(int bd, uint8_t *dst, const uint8_t *top, const uint8_t 
  * plane using the RESOLVED candidate flags, substitution, smoothing, prediction.
  * plane/stride(bytes)/pw/ph describe plane c_idx; x,y are in samples of that plane. */
 void oh_or_intra_pred(const OhPicParams *p, uint8_t *plane, ptrdiff_t stride, int pw, int ph,
-                      int x, int y, int c_idx, int log2, int mode, int avail);
+                      int x, int y, int c_idx, int log2, int mode, int avail, const uint8_t *is_intra);   /* is_intra: OhFrame.is_intra, NULL unless constrained_intra_pred */
 
 /* hevcdsp_template.c:1629-1757; xstride/ystride in bytes as in the reference's inner functions */
 void oh_or_loop_filter_luma  (int bd, uint8_t *pix, ptrdiff_t xstride, ptrdiff_t ystride, int beta,

@@ -202,6 +202,7 @@ static RefCtx *ctx_new(const OhPicParams *p, uint8_t *const data[3], const ptrdi
 
     pps->cb_qp_offset = p->cb_qp_offset; pps->cr_qp_offset = p->cr_qp_offset;
     pps->transquant_bypass_enable_flag = (uint8_t)p->transquant_bypass_enable;
+    pps->constrained_intra_pred_flag = (uint8_t)p->constrained_intra_pred;
     pps->loop_filter_across_tiles_enabled_flag = 1;
     ctbs = sps->ctb_size;
     r->rs_to_ts = malloc(sizeof(int) * (size_t)(ctbs + 1));
@@ -253,7 +254,14 @@ API int ref_intra_picture(const OhFrame *f, uint8_t *const data[3], const ptrdif
     HEVCContext *s = &r->s;
     HEVCLocalContext *lc = &r->lc;
     int ctb = 1 << p->log2_ctb_size;
+    MvField *mvf = NULL;
 
+    if (p->constrained_intra_pred && f->is_intra) {            /* IS_INTRA() reads s->ref->tab_mvf[].pred_flag (hevcpred_template.c:34-41) */
+        size_t n = (size_t)r->sps.min_pu_width * r->sps.min_pu_height;
+        mvf = calloc(n, sizeof(*mvf));
+        for (size_t k = 0; k < n; k++) mvf[k].pred_flag = f->is_intra[k] ? PF_INTRA : PF_L0;
+        r->ref.tab_mvf = mvf;
+    }
     for (uint32_t i = 0; i < f->n_intra; i++) {
         const OhIntra *it = &f->intra[i];
         int c = it->c_idx, hs = oh_hshift(p, c), vs = oh_vshift(p, c);
@@ -286,6 +294,7 @@ API int ref_intra_picture(const OhFrame *f, uint8_t *const data[3], const ptrdif
             s->hevcdsp.transform_add[tu->log2_size - 2](dst, (int16_t *)(residuals + tu->coeff_off), stride[c]);
         }
     }
+    free(mvf);
     ctx_free(r);
     return 0;
 }

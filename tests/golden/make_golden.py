@@ -98,6 +98,8 @@ PICTURE_CASES = [
     ("p_10b_420", 416, 240, 10, 1, 5, 1, 13, {"tskip_pct": 10}),
     ("b_10b_444", 200, 136, 10, 3, 4, 2, 14, {}),
     ("b_8b_pcm", 264, 200, 8, 1, 6, 2, 15, {"pcm_pct": 10, "bypass_pct": 10, "vary_deblock_offsets": 1}),
+    # constrained_intra_pred_flag = 1: the intra stage of this one is produced by the reference's intra_pred slots
+    ("b_10b_cip", 264, 200, 10, 1, 6, 2, 16, {"intra_pct": 50}),
 ]
 
 
@@ -106,9 +108,9 @@ def picture_case(name, w, h, bd, chroma, lc, st, seed, knobs):
     expected picture come from the oracle (their slots are pinned one by one against the
     reference above and in test_oracle_vs_ref.py); the in-loop filters then run through the
     reference's own ff_hevc_hls_filters driver, so the stored MD5s are reference output."""
-    pcm = "pcm" in name
+    pcm, cip = "pcm" in name, "cip" in name
     p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
-                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm))
+                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm), constrained_intra_pred=int(cip))
     rec = F.Recorder(p)
     f = rec.synth(F.synth_params(st, seed, **knobs), 2, [0, 1])
     rng = np.random.default_rng(seed)
@@ -118,7 +120,13 @@ def picture_case(name, w, h, bd, chroma, lc, st, seed, knobs):
     co = np.ctypeslib.as_array(f.coeffs, shape=(int(f.n_coeff),)).copy()
     assert o.oh_or_pass_inter(C.byref(f), arr) == 0
     assert o.oh_or_pass_residual(C.byref(f), arr, i16p(co)) == 0
-    assert o.oh_or_pass_intra(C.byref(f), arr, i16p(co)) == 0
+    if cip:                                                # the reference's own intra_pred slots, blocks in decode order
+        sys.path.insert(0, os.path.dirname(HERE))
+        from test_oracle_picture_vs_ref import decode_order
+        d, s = plane_ptrs(pics[2])
+        assert ref().ref_intra_picture(C.byref(decode_order(rec, f)), d, s, i16p(co)) == 0
+    else:
+        assert o.oh_or_pass_intra(C.byref(f), arr, i16p(co)) == 0
     recon = md5_planes(pics[2])
     scratch = pics[2].copy()
     d, s = plane_ptrs(pics[2])

@@ -62,7 +62,7 @@ _ORACLE_SIGS = {
     "oh_or_pred_planar": [I, U8, U8, U8, P, I],
     "oh_or_pred_dc": [I, U8, U8, U8, P, I, I],
     "oh_or_pred_angular": [I, U8, U8, U8, P, I, I, I],
-    "oh_or_intra_pred": [V, U8, P, I, I, I, I, I, I, I, I],
+    "oh_or_intra_pred": [V, U8, P, I, I, I, I, I, I, I, I, V],
     "oh_or_loop_filter_luma": [I, U8, P, P, I, IP, U8, U8],
     "oh_or_loop_filter_chroma": [I, U8, P, P, IP, U8, U8],
     "oh_or_sao_band": [I, U8, U8, P, P, I16, I, I, I],

@@ -81,9 +81,9 @@ def load_picture_cases():
 def build_case(case):
     """(frame, pics, recorder) for one golden picture case — shared with the GPU parity tests"""
     name, w, h, bd, chroma, lc, st, seed, knobs = case
-    pcm = "pcm" in name
+    pcm, cip = "pcm" in name, "cip" in name
     p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
-                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm))
+                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm), constrained_intra_pred=int(cip))
     rec = F.Recorder(p)
     f = rec.synth(F.synth_params(st, seed, **knobs), 2, [0, 1])
     rng = np.random.default_rng(seed)
@@ -91,7 +91,7 @@ def build_case(case):
     return f, pics, rec
 
 
-@pytest.mark.parametrize("idx", range(5))
+@pytest.mark.parametrize("idx", range(6))
 def test_picture_fixtures(idx):
     """whole pipeline (passes 1-5) of the oracle reproduces the recorded MD5s; the stored final
     MD5 was produced by the reference's own in-loop filter driver"""

@@ -72,6 +72,11 @@ CASES = [
     ("b8_farmv", 128, 72, 8, 1, 6, 2, {"mv_range": 2000, "skip_pct": 80}),
     ("b8_dense", 416, 240, 8, 1, 6, 2, {"split_pct": 85, "cbf_pct": 95, "skip_pct": 0}),
     ("tiny", 8, 8, 8, 1, 4, 0, {}),
+    # constrained_intra_pred_flag = 1 (hevcpred_template.c:116-249): half the CUs intra, PCM CUs count as intra
+    ("b8_cip", 264, 200, 8, 1, 6, 2, {"intra_pct": 50}),
+    ("b10_cip_pcm", 200, 136, 10, 1, 5, 2, {"intra_pct": 60, "pcm_pct": 10, "split_pct": 70}),
+    ("b8_444_cip", 136, 88, 8, 3, 5, 2, {"intra_pct": 40}),
+    ("b10_422_cip", 200, 136, 10, 2, 6, 2, {"intra_pct": 50}),
 ]
 
 
@@ -80,7 +85,7 @@ def test_picture_parity(eng, case):
     name, w, h, bd, chroma, lc, st, knobs = case
     pcm = "pcm" in name
     p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
-                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm),
+                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm), constrained_intra_pred=int("cip" in name),
                      cb_qp_offset=2 if "weighted" in name else 0, cr_qp_offset=-3 if "weighted" in name else 0)
     rec = F.Recorder(p)
     for seed in range(2):

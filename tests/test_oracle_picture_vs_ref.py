@@ -67,6 +67,41 @@ def test_intra_picture(w, h, bd, chroma, lc, strong):
     rec.close()
 
 
+@pytest.mark.parametrize("w,h,bd,chroma,lc", CASES)
+def test_intra_picture_constrained_intra_pred(w, h, bd, chroma, lc):
+    """constrained_intra_pred_flag = 1 (hevcpred_template.c:116-163, 185-249): intra blocks of P/B pictures must
+    not use samples of inter CUs; the reference reads tab_mvf[].pred_flag, the oracle OhFrame.is_intra.
+    Mixed pictures with about half the CUs intra (and PCM CUs, which count as intra) exercise every sweep."""
+    if chroma == 0:
+        pytest.skip("covered by the 4:2:0 cases (the path does not depend on chroma)")
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc, constrained_intra_pred=1,
+                     pcm_loop_filter_disable=1)
+    rec = F.Recorder(p)
+    n_diff_plain = 0
+    for seed in range(4):
+        sp = F.synth_params(2, 2000 + seed, intra_pct=(30, 50, 70, 50)[seed], split_pct=35 + 15 * seed, cbf_pct=50,
+                            pcm_pct=(0, 0, 10, 10)[seed])
+        f = rec.synth(sp, 0, [1, 2])
+        assert f.n_intra > 0 and bool(f.is_intra)
+        res = residuals_of(f)
+        rng = np.random.default_rng(seed)
+        start = F.HostPic(p, rng=rng)             # "inter" samples: whatever passes 1-2 left there
+        a, b, plain = start.copy(), start.copy(), start.copy()
+        assert oracle().oh_or_pass_intra(C.byref(f), host_pic_array({0: a}), res.ctypes.data_as(C.POINTER(C.c_int16))) == 0
+        d, s = plane_ptrs(b)
+        assert ref().ref_intra_picture(C.byref(decode_order(rec, f)), d, s, res.ctypes.data_as(C.POINTER(C.c_int16))) == 0
+        for c in range(F.n_planes(p)):
+            assert np.array_equal(a.visible(c), b.visible(c)), (seed, c)
+        # the flag matters: the same list without it predicts from the inter samples and differs
+        g = F.OhFrame()
+        C.memmove(C.byref(g), C.byref(f), C.sizeof(F.OhFrame))
+        g.p.constrained_intra_pred = 0
+        assert oracle().oh_or_pass_intra(C.byref(g), host_pic_array({0: plain}), res.ctypes.data_as(C.POINTER(C.c_int16))) == 0
+        n_diff_plain += int(not plain.equal(a))
+    assert n_diff_plain > 0
+    rec.close()
+
+
 def decode_order(rec, f):
     """Copy of OhFrame f whose intra[] is in decode (z-scan) order.  Items of equal level keep
     recording order (stable counting sort), and z-scan order is recoverable as: CTB raster

@@ -19,11 +19,7 @@
 #include "kernels.h"
 
 /* ---- constant tables (H.265 facts; same numbers as hevcdsp.c:879-944,1028-1042, hevcpred_template.c:430-437,
- *      hevc_filter.c:50-60) ---- */
-__constant__ int8_t  c_qpel[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
-                                      { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
-__constant__ int8_t  c_epel[8][8] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
-                                      { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+ *      hevc_filter.c:50-60); the interpolation taps live in ohk_init(), which packs them for mc_kernel ---- */
 __constant__ int8_t  c_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
                                      -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
 __constant__ int16_t c_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
@@ -108,6 +104,9 @@ static __device__ __forceinline__ void store4(GLOBAL PX *p, int a, int b, int c,
  *   - the windows of both lists are fetched before the first wait.
  * The h-pass result is kept as int16 exactly like the reference's tmp_array (:776).
  * ======================================================================================= */
+/* packed tap pairs of every fraction, [luma / chroma][bit_depth - 8][McGeom::CS * (NFR + 1)]; filled by ohk_init() */
+__device__ unsigned g_mctab[2][5][64];
+
 template <int TAPS> struct McGeom {
     static constexpr int WROWS = 8 + TAPS;                 /* window rows kept: bh + TAPS - 1 <= WROWS - 1 */
     static constexpr int NSEG  = TAPS == 8 ? 4 : 3;        /* 4-sample segments per window row              */
@@ -169,18 +168,8 @@ __global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
         const int r = LUMA ? lane : lane >> 1, pl = LUMA ? 0 : lane & 1;
         refp[r][pl] = f->refs[r].p[LUMA ? 0 : 1 + pl];
     }
-    if (lane < (G::NFR + 1) * G::NCO) {
-        const int fr = lane / G::NCO, q = lane - fr * G::NCO;
-        int k0, k1;                                         /* tap indices of the pair; -1 / TAPS = outside */
-        if (q < HT) { k0 = 2 * q; k1 = 2 * q + 1; } else { k0 = 2 * (q - HT) - 1; k1 = 2 * (q - HT); }
-        auto tap = [&](int k) -> int {
-            if (k < 0 || k >= TAPS) return 0;
-            if (fr == 0) return k == before;
-            if (fr == G::NFR) return k == before ? 1 << (14 - bd) : 0;
-            return LUMA ? c_qpel[fr][k] : c_epel[fr][k];
-        };
-        ctab[fr * G::CS + q] = pack2(tap(k0), tap(k1));
-    }
+    if (lane < (G::NFR + 1) * G::CS)                        /* packed taps, built once by ohk_init() in the LDS layout */
+        ctab[lane] = g_mctab[LUMA ? 0 : 1][bd - 8][lane];
     const int pw = f->cur.w[LUMA ? 0 : 1], ph = f->cur.h[LUMA ? 0 : 1], stride = f->cur.stride[LUMA ? 0 : 1];
     const int bw = job.w, bh = job.h, wh = bh + TAPS - 1;
     const bool two = job.ref[1] != OH_NO_REF;
@@ -1251,7 +1240,7 @@ static __device__ __forceinline__ void store8(GLOBAL PX *p, const int v[8])
 #pragma unroll
         for (int j = 0; j < 4; j++) r[j] = v[2 * j] | (v[2 * j + 1] << 16);
     }
-    *(GLOBAL typename Vec8<PX>::T *)p = r;
+    __builtin_nontemporal_store(r, (GLOBAL typename Vec8<PX>::T *)p);     /* the output is next read by another picture's MC: stream it past the L2 */
 }
 
 struct SaoEdgeCtx { int x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd; };
@@ -1401,6 +1390,31 @@ extern "C" int ohk_init(void)
         for (int i = 0; i < 4; i++) basis[4][k * 4 + i] = dst7[k][i];
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_basis), basis, sizeof(basis)) != hipSuccess)
         return -1;
+    {   /* mc_kernel's tap table: per fraction TAPS/2 pairs for even positions, then TAPS/2+1 pairs shifted by one tap
+         * for odd positions; fraction 0 = unit filter, entry NFR = unit << (14 - bit_depth) (full-sample copy) */
+        static const int8_t qpel[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+        static const int8_t epel[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+        static unsigned tab[2][5][64];
+        for (int luma = 1; luma >= 0; luma--) {
+            const int taps = luma ? 8 : 4, ht = taps / 2, nco = taps + 1, cs = taps + 2, nfr = luma ? 4 : 8, before = ht - 1;
+            for (int bd = 8; bd <= 12; bd++)
+                for (int fr = 0; fr <= nfr; fr++)
+                    for (int q = 0; q < nco; q++) {
+                        int k[2];
+                        if (q < ht) { k[0] = 2 * q; k[1] = 2 * q + 1; } else { k[0] = 2 * (q - ht) - 1; k[1] = 2 * (q - ht); }
+                        int v[2];
+                        for (int j = 0; j < 2; j++) {
+                            if (k[j] < 0 || k[j] >= taps) v[j] = 0;
+                            else if (fr == 0) v[j] = k[j] == before;
+                            else if (fr == nfr) v[j] = k[j] == before ? 1 << (14 - bd) : 0;
+                            else v[j] = luma ? qpel[fr][k[j]] : epel[fr][k[j]];
+                        }
+                        tab[luma ? 0 : 1][bd - 8][fr * cs + q] = ((unsigned)v[0] & 0xffffu) | ((unsigned)v[1] << 16);
+                    }
+        }
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_mctab), tab, sizeof(tab)) != hipSuccess)
+            return -1;
+    }
     /* the intra kernel's LDS block is sized per launch and exceeds 64 KiB for 4:4:4 CTUs full of 4x4 blocks */
     const int max_lds = 128 * 1024;
     if (hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||

@@ -902,7 +902,9 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             IL.level = (uint32_t)l;
             /* waves per CTU: as many as blocks run side by side in a sub-level (more only hold LDS and wave slots) */
             const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;
-            IL.waves = wenv ? (uint32_t)atoi(wenv) : par > 4.5 ? 8 : par > 1.25 ? 4 : 2;
+            /* a small batch cannot fill the chip anyway: spend the waves on the single picture's latency (8 as soon as
+             * sub-levels hold more than ~2 blocks); a large batch is issue-bound and runs best with 4 */
+            IL.waves = wenv ? (uint32_t)atoi(wenv) : par > (nb < 8 ? 2.5 : 4.5) ? 8 : par > 1.25 ? 4 : 2;
             if (IL.waves < 1 || IL.waves > 8) IL.waves = 8;
             size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
             IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);

@@ -39,6 +39,7 @@ struct OhDevFrame {
     uint32_t   n_mc_luma = 0, n_mc_chroma = 0, n_tu = 0, n_intra = 0;
     uint32_t   tu_cnt[4] = { 0, 0, 0, 0 };
     bool       has_sao = false;
+    int        cur_pic = -1;      /* engine id of the picture the list reconstructs */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
         uint64_t sum_items, sum_sub;
@@ -828,6 +829,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         df->levels = levels;
     }
     cur->final_b = has_sao;
+    df->cur_pic = f->cur_pic;
     *out = df;
     return OH_OK;
 }
@@ -867,6 +869,9 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             HIPCHK(e, hipEventRecord(es.ev[0], st));
         }
 #define MARK(k) do { if (prof) HIPCHK(e, hipEventRecord(es.ev[(k) + 1], st)); } while (0)
+        for (int i = 0; i < nb; i++)                       /* which half holds the finished picture once this has run */
+            if (Pic *c = get_pic(e, fr[i]->cur_pic))
+                c->final_b = fr[i]->has_sao;
         OhBatch all;
         memset(&all, 0, sizeof(all));
         uint32_t max_luma = 0, max_chroma = 0, max_tu[4] = { 0, 0, 0, 0 };

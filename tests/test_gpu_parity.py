@@ -151,9 +151,13 @@ def test_reference_chain_and_reexecute(eng):
         first = eng.pic_download(ids[cur], p)
         eng.frame_execute(df)
         again = eng.pic_download(ids[cur], p)
+        eng.pic_upload(ids[cur], F.HostPic(p))        # an upload in between must not confuse which half is final
+        eng.frame_execute(df)
+        third = eng.pic_download(ids[cur], p)
         eng.frame_free(df)
         assert_same(host[cur], first, f"chain pic {cur}")
         assert_same(first, again, f"re-execute pic {cur}")
+        assert_same(first, third, f"upload + re-execute pic {cur}")
     for v in ids.values():
         eng.pic_free(v)
     rec.close()

@@ -26,7 +26,8 @@
  *   hpc.intra_pred[n](s, x0, y0, c_idx)               -> oh_rec_intra(); mode and candidate flags come from the
  *                                                        accessor registered with oh_tables_set_intra_accessor()
  *   hevc_*_loop_filter_*, sao_*                       no-ops: passes 4-5 run from the BS/QP/SAO arrays
- *   put_pcm, upsample_*                               left untouched
+ *   put_pcm                                           reads the samples (get_bits) and records OH_TU_PCM blocks
+ *   upsample_*                                        left untouched (oh_pic_upsample replaces them)
  */
 #ifndef OHEVC_TABLES_H
 #define OHEVC_TABLES_H
@@ -39,7 +40,9 @@
 extern "C" {
 #endif
 
-struct GetBitContext; struct SAOParams; struct AVFrame; struct HEVCWindow; struct UpsamplInf; struct HEVCContext;
+/* layout of libavcodec/get_bits.h:54-59; the put_pcm slot reads its samples through it */
+struct GetBitContext { const uint8_t *buffer, *buffer_end; int index; int size_in_bits; int size_in_bits_plus8; };
+struct SAOParams; struct AVFrame; struct HEVCWindow; struct UpsamplInf; struct HEVCContext;
 
 /* hevcdsp.h:44-124 */
 typedef struct HEVCDSPContext {

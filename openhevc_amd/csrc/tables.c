@@ -158,6 +158,38 @@ static void s_transform_add1(uint8_t *d, int16_t *c, ptrdiff_t s) { transform_ad
 static void s_transform_add2(uint8_t *d, int16_t *c, ptrdiff_t s) { transform_add_n(d, c, s, 4); }
 static void s_transform_add3(uint8_t *d, int16_t *c, ptrdiff_t s) { transform_add_n(d, c, s, 5); }
 
+/* ---- put_pcm (hevcdsp_template.c:30-43, called by hls_pcm_sample hevc.c:1587-1640): the samples are read from the
+ * bitstream exactly like the C template does (get_bits, MSB first) and recorded as PCM blocks ---- */
+static unsigned gb_read(struct GetBitContext *gb, int n)
+{
+    unsigned v = 0;
+    for (int i = 0; i < n; i++, gb->index++)
+        v = (v << 1) | ((gb->buffer[gb->index >> 3] >> (7 - (gb->index & 7))) & 1u);
+    return v;
+}
+static void s_put_pcm(uint8_t *dst, ptrdiff_t stride, int width, int height, struct GetBitContext *gb, int pcm_bit_depth)
+{
+    int c, x, y;
+    flush_pu();
+    if (!T.rec || !gb || width < 4 || height < 4 || width > 32 || height > 32 || (width & (width - 1)) || (height & (height - 1)) ||
+        !resolve_dst(dst, stride, &c, &x, &y)) {
+        T.untranslated++;
+        return;
+    }
+    int16_t rect[32 * 32], blk[32 * 32];
+    for (int i = 0; i < width * height; i++)
+        rect[i] = (int16_t)(gb_read(gb, pcm_bit_depth) << (T.p.bit_depth - pcm_bit_depth));
+    /* the work list holds square blocks: a 4:2:2 chroma rectangle (w x 2w) goes as two squares */
+    int s = width < height ? width : height, log2 = 0;
+    while ((1 << log2) < s) log2++;
+    for (int oy = 0; oy < height; oy += s)
+        for (int ox = 0; ox < width; ox += s) {
+            for (int yy = 0; yy < s; yy++)
+                memcpy(blk + yy * s, rect + (oy + yy) * width + ox, sizeof(int16_t) * (size_t)s);
+            (void)oh_rec_tu(T.rec, c, x + ox, y + oy, log2, OH_TU_PCM, OH_TUF_ADD_NOW, blk);
+        }
+}
+
 /* ---- intra slots (hevc.c:1215-1417) ---- */
 static void intra_pred_n(struct HEVCContext *s, int x0, int y0, int c_idx, int log2)
 {
@@ -325,7 +357,8 @@ void ff_hevcdsp_init_hip(HEVCDSPContext *c, const int bit_depth)
     c->hevc_h_loop_filter_luma_c = c->hevc_v_loop_filter_luma_c = s_lf_luma;
     c->hevc_h_loop_filter_chroma = c->hevc_v_loop_filter_chroma = s_lf_chroma;
     c->hevc_h_loop_filter_chroma_c = c->hevc_v_loop_filter_chroma_c = s_lf_chroma;
-    /* put_pcm and the SHVC upsample_* slots keep whatever ff_hevc_dsp_init() installed */
+    c->put_pcm = s_put_pcm;
+    /* the SHVC upsample_* slots keep whatever ff_hevc_dsp_init() installed: oh_pic_upsample replaces their caller */
 }
 
 void ff_hevcpred_init_hip(HEVCPredContext *c, const int bit_depth)

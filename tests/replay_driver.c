@@ -172,9 +172,18 @@ int replay_through_tables(const OhFrame *f, OhRecorder *out, uint8_t *const cur[
         const OhTu *tu = &f->tu[i];
         if (tu_done[i])
             continue;
-        if (tu->kind == OH_TU_PCM)                        /* hls_pcm_sample shim records PCM blocks directly */
-            oh_rec_tu(out, tu->c_idx, tu->x, tu->y, tu->log2_size, OH_TU_PCM, OH_TUF_ADD_NOW, f->coeffs + tu->coeff_off);
-        else
+        if (tu->kind == OH_TU_PCM) {                      /* hls_pcm_sample (hevc.c:1587-1640): put_pcm reads the samples from the bitstream */
+            int n = 1 << tu->log2_size, bd = p->bit_depth, bit = 0;
+            uint8_t bits[32 * 32 * 2 + 8];
+            struct GetBitContext gb;
+            memset(bits, 0, sizeof(bits));
+            for (int i = 0; i < n * n; i++)
+                for (int b = bd - 1; b >= 0; b--, bit++)
+                    bits[bit >> 3] |= (uint8_t)(((f->coeffs[tu->coeff_off + i] >> b) & 1) << (7 - (bit & 7)));
+            gb.buffer = bits; gb.buffer_end = bits + sizeof(bits); gb.index = 0; gb.size_in_bits = bit; gb.size_in_bits_plus8 = bit + 8;
+            k->d.put_pcm(k->cur[tu->c_idx] + (ptrdiff_t)tu->y * k->cur_ls[tu->c_idx] + (ptrdiff_t)tu->x * k->bpp, k->cur_ls[tu->c_idx],
+                         n, n, &gb, bd);
+        } else
             replay_residual(k, tu);
     }
     int bad = oh_tables_finish();

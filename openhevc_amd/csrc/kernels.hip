@@ -671,7 +671,7 @@ static __device__ __forceinline__ void cip_patch(lds_int *E, const int n, const 
     top[-1] = left[-1];
 }
 
-template <typename PX>
+template <typename PX, bool CIP>
 static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
                                                    const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
                                                    const int16_t *__restrict__ res_lds_base, const bool STAGED, const int lane, unsigned long long *acc)
@@ -722,8 +722,8 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const int l_0 = __builtin_amdgcn_readlane(lv, 0), l_n1 = __builtin_amdgcn_readlane(lv, n - 1), l_n = __builtin_amdgcn_readlane(lv, n & 63);
     const int t_0 = __builtin_amdgcn_readlane(tv, 0), t_n1 = __builtin_amdgcn_readlane(tv, n - 1), t_n = __builtin_amdgcn_readlane(tv, n & 63);
     int corner, left_i, top_i;
-    if (flags & OH_IF_CIP) {
-        /* constrained intra prediction: rare, so one lane replays the reference's sweeps over the published edges
+    if (CIP && (flags & OH_IF_CIP)) {
+        /* constrained intra prediction (own kernel instantiation, so the common one carries none of this): rare, so one lane replays the reference's sweeps over the published edges
          * (cip_patch) instead of a lane-parallel closed form */
         const int fill = sizeof(PX) == 1 ? 128 : 0x8080;                   /* memset(.., 128, ..) over 16-bit samples, :158-160 */
         int *E = s.E;
@@ -743,7 +743,7 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
         corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : (1 << (bd - 1))));
         left_i = corner;
     }
-    if (!(flags & OH_IF_CIP))
+    if (!(CIP && (flags & OH_IF_CIP)))
         top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
 
     /* smoothing (:288-326) with whole-wave DPP shifts; the mode/size test was done on the host */
@@ -888,7 +888,7 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     ACC(2, ta, tb); ACC(3, tb, tc); ACC(4, tc, td);
 }
 
-template <typename PX>
+template <typename PX, bool CIP>
 __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
 {
     const DevFrame *__restrict__ f = B.f[blockIdx.y];
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
         STAMP(t0);
         const uint32_t b1 = sub[s + 1];
         for (uint32_t b = sub[s] + wave; b < b1; b += nwaves)
-            intra_block<PX>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, STAGED, lane, acc);
+            intra_block<PX, CIP>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, STAGED, lane, acc);
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
         STAMP(t2);
@@ -1417,8 +1417,10 @@ extern "C" int ohk_init(void)
     }
     /* the intra kernel's LDS block is sized per launch and exceeds 64 KiB for 4:4:4 CTUs full of 4x4 blocks */
     const int max_lds = 128 * 1024;
-    if (hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
         return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dct), m, sizeof(m)) == hipSuccess ? 0 : -1;
 }
@@ -1517,8 +1519,13 @@ extern "C" void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, c
 {
     if (!max_ctu) return;
     dim3 g(max_ctu, n), b(64 * l->waves);
-    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t>), g, b, l->lds_bytes, st, *B, *l);
-    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t>), g, b, l->lds_bytes, st, *B, *l);
+    if (p->constrained_intra_pred) {                      /* the instantiation that carries the constrained-intra slow path */
+        if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, true>), g, b, l->lds_bytes, st, *B, *l);
+        else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, true>), g, b, l->lds_bytes, st, *B, *l);
+    } else {
+        if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, false>), g, b, l->lds_bytes, st, *B, *l);
+        else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, false>), g, b, l->lds_bytes, st, *B, *l);
+    }
 }
 
 extern "C" void ohk_deblock(const OhBatch *B, int n, const OhPicParams *p, int horiz, hipStream_t st)

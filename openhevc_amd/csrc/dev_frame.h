@@ -55,9 +55,10 @@ static __host__ __device__ inline OhCtuAreas oh_ctu_areas(int log2_ctb, int chro
     return a;
 }
 struct OhIntraLaunch {                             /* one wavefront level of a batch of pictures = one launch */
-    uint32_t level;                                /* index into DevFrame.lvl_start / lvl_staged              */
+    uint32_t level;                                /* index into DevFrame.lvl_start                           */
     uint32_t off_items, off_sub, off_res, off_wave, lds_bytes;   /* byte offsets into the dynamic LDS block */
     uint32_t waves;                                /* waves per workgroup (CTU)                               */
+    uint32_t staged;                               /* 1: every CTU of the launch has its residual span contiguous: staged in LDS */
 };
 
 enum { OH_IF_FILTER = 1, OH_IF_STRONG_CAND = 2, OH_IF_EDGE = 4,              /* DevIntra.flags bits 0..2 */
@@ -109,7 +110,6 @@ struct DevFrame {
     const DevIntraCtu *ictu;          /* CTUs with intra blocks in wavefront order             */
     const uint32_t  *sub_start;       /* sub-level ranges into intra[]                         */
     const uint32_t  *lvl_start;       /* wavefront level ranges into ictu[]                    */
-    const uint8_t   *lvl_staged;      /* per level: 1 = every CTU has its residual span contiguous (staged in LDS) */
     const uint8_t   *vbs, *hbs;
     const int8_t    *qp;
     const uint8_t   *is_pcm;          /* may be null                                          */

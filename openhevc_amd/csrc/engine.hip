@@ -42,6 +42,7 @@ struct OhDevFrame {
     int        cur_pic = -1;      /* engine id of the picture the list reconstructs */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
+        bool     staged;                  /* every CTU has its residual span contiguous (stageable in LDS) */
         uint64_t sum_items, sum_sub;
     };
     std::vector<Level> levels;
@@ -733,18 +734,17 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             if (dintra[b].res_off != OH_NO_COEFF && dictu[k].res_cnt)
                 dintra[b].res_lds = dintra[b].res_off - dictu[k].res_lo;
     std::vector<OhDevFrame::Level> levels(f->n_intra ? f->n_levels : 0);
-    std::vector<uint8_t> lvl_staged(levels.size(), 1);
     for (size_t l = 0; l < levels.size(); l++) {
         OhDevFrame::Level &L = levels[l];
         L.n_ctu = f->level_start[l + 1] - f->level_start[l];
-        L.max_items = 1; L.max_sub = 1; L.max_res = 0; L.sum_items = 0; L.sum_sub = 0;
+        L.max_items = 1; L.max_sub = 1; L.max_res = 0; L.sum_items = 0; L.sum_sub = 0; L.staged = true;
         for (uint32_t k = f->level_start[l]; k < f->level_start[l + 1]; k++) {
             const uint32_t b0 = f->sub_start[dictu[k].sub_first], b1 = f->sub_start[dictu[k].sub_first + dictu[k].n_sub];
             bool any_res = false;
             for (uint32_t b = b0; b < b1 && !any_res; b++)
                 any_res = dintra[b].res_off != OH_NO_COEFF;
             if (any_res && !dictu[k].res_cnt)
-                lvl_staged[l] = 0;
+                L.staged = false;
             L.max_items = std::max(L.max_items, std::min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
             L.max_sub = std::max(L.max_sub, std::min((uint32_t)dictu[k].n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
             L.max_res = std::max(L.max_res, dictu[k].res_cnt);
@@ -753,7 +753,6 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     }
     int s_ictu = add(dictu.data(), dictu.size() * sizeof(DevIntraCtu));
     int s_lvl = add(levels.empty() ? nullptr : f->level_start, levels.empty() ? 0 : (levels.size() + 1) * sizeof(uint32_t));
-    int s_lst = add(lvl_staged.data(), lvl_staged.size());
     int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
     int s_vbs = add(has_db ? f->vertical_bs : nullptr, has_db ? f->bs_size : 0);
     int s_hbs = add(has_db ? f->horizontal_bs : nullptr, has_db ? f->bs_size : 0);
@@ -791,7 +790,6 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.ictu = (const DevIntraCtu *)(base + seg[s_ictu].off);
     hd.sub_start = (const uint32_t *)(base + seg[s_sub].off);
     hd.lvl_start = (const uint32_t *)(base + seg[s_lvl].off);
-    hd.lvl_staged = (const uint8_t *)(base + seg[s_lst].off);
     hd.vbs = (const uint8_t *)(base + seg[s_vbs].off);
     hd.hbs = (const uint8_t *)(base + seg[s_hbs].off);
     hd.qp = (const int8_t *)(base + seg[s_qp].off);
@@ -893,6 +891,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             memset(&sub, 0, sizeof(sub));
             int ns = 0;
             uint32_t max_ctu = 0, max_items = 1, max_sub = 1, max_res = 0;
+            bool staged = true;
             uint64_t sum_items = 0, sum_sub = 0;
             for (int i = 0; i < nb; i++) {
                 if (l >= fr[i]->levels.size())
@@ -902,8 +901,10 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
                 max_ctu = std::max(max_ctu, L.n_ctu); max_items = std::max(max_items, L.max_items);
                 max_sub = std::max(max_sub, L.max_sub); max_res = std::max(max_res, L.max_res);
                 sum_items += L.sum_items; sum_sub += L.sum_sub;
+                staged = staged && L.staged;
             }
             OhIntraLaunch IL;
+            IL.staged = staged;
             IL.level = (uint32_t)l;
             /* waves per CTU: as many as blocks run side by side in a sub-level (more only hold LDS and wave slots) */
             const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;

@@ -671,10 +671,10 @@ static __device__ __forceinline__ void cip_patch(lds_int *E, const int n, const 
     top[-1] = left[-1];
 }
 
-template <typename PX, bool CIP>
+template <typename PX, bool CIP, bool STAGED>
 static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
                                                    const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
-                                                   const int16_t *__restrict__ res_lds_base, const bool STAGED, const int lane, unsigned long long *acc)
+                                                   const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
 {
     unsigned long long ta = 0, tb = 0, tc = 0, td = 0; (void)ta; (void)tb; (void)tc; (void)td; (void)acc;
     STAMP(ta);
@@ -888,14 +888,13 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     ACC(2, ta, tb); ACC(3, tb, tc); ACC(4, tc, td);
 }
 
-template <typename PX, bool CIP>
+template <typename PX, bool CIP, bool STAGED>
 __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
 {
     const DevFrame *__restrict__ f = B.f[blockIdx.y];
     const uint32_t first_ctu = f->lvl_start[L.level];
     if (blockIdx.x >= f->lvl_start[L.level + 1] - first_ctu)
         return;
-    const bool STAGED = f->lvl_staged[L.level];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *__restrict__ M = (uint16_t *)smem;                                  /* sample area, oh_ctu_areas() */
     DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
@@ -965,7 +964,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
         STAMP(t0);
         const uint32_t b1 = sub[s + 1];
         for (uint32_t b = sub[s] + wave; b < b1; b += nwaves)
-            intra_block<PX, CIP>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, STAGED, lane, acc);
+            intra_block<PX, CIP, STAGED>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, lane, acc);
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
         STAMP(t2);
@@ -1417,11 +1416,14 @@ extern "C" int ohk_init(void)
     }
     /* the intra kernel's LDS block is sized per launch and exceeds 64 KiB for 4:4:4 CTUs full of 4x4 blocks */
     const int max_lds = 128 * 1024;
-    if (hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)intra_ctu_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
-        return -1;
+    const void *intra_kernels[8] = {
+        (const void *)intra_ctu_kernel<uint8_t, false, false>, (const void *)intra_ctu_kernel<uint8_t, false, true>,
+        (const void *)intra_ctu_kernel<uint8_t, true, false>, (const void *)intra_ctu_kernel<uint8_t, true, true>,
+        (const void *)intra_ctu_kernel<uint16_t, false, false>, (const void *)intra_ctu_kernel<uint16_t, false, true>,
+        (const void *)intra_ctu_kernel<uint16_t, true, false>, (const void *)intra_ctu_kernel<uint16_t, true, true> };
+    for (const void *k : intra_kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+            return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dct), m, sizeof(m)) == hipSuccess ? 0 : -1;
 }
 
@@ -1519,13 +1521,17 @@ extern "C" void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, c
 {
     if (!max_ctu) return;
     dim3 g(max_ctu, n), b(64 * l->waves);
-    if (p->constrained_intra_pred) {                      /* the instantiation that carries the constrained-intra slow path */
-        if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, true>), g, b, l->lds_bytes, st, *B, *l);
-        else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, true>), g, b, l->lds_bytes, st, *B, *l);
-    } else {
-        if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint8_t, false>), g, b, l->lds_bytes, st, *B, *l);
-        else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<uint16_t, false>), g, b, l->lds_bytes, st, *B, *l);
-    }
+    /* instantiations: constrained intra pred carries a slow path the common one must not pay for; STAGED = every CTU of the
+     * launch has its residual span in LDS (otherwise the blocks read it from HBM) */
+#define INTRA_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l)
+#define INTRA_BY_FLAGS(PX)                                                                     \
+    do {                                                                                       \
+        if (p->constrained_intra_pred) { if (l->staged) INTRA_LAUNCH(PX, true, true); else INTRA_LAUNCH(PX, true, false); }   \
+        else                           { if (l->staged) INTRA_LAUNCH(PX, false, true); else INTRA_LAUNCH(PX, false, false); } \
+    } while (0)
+    if (p->bit_depth == 8) INTRA_BY_FLAGS(uint8_t); else INTRA_BY_FLAGS(uint16_t);
+#undef INTRA_BY_FLAGS
+#undef INTRA_LAUNCH
 }
 
 extern "C" void ohk_deblock(const OhBatch *B, int n, const OhPicParams *p, int horiz, hipStream_t st)

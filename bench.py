@@ -4,11 +4,11 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One STEP is one wave-scheduled group of pictures per GPU (openhevc_amd/parallel.py): 1 I picture,
-3 reference B pictures and 12 non-reference B pictures of the workload's geometry, work lists
-already resident in HBM (uploaded before the timed region; the PCIe-inclusive rate is a separate
-figure in DESIGN.md).  Steps are closed GOPs (they start with an I picture), so --chains of them are
-kept in flight per GPU: the GPU form of the reference's frame threads (pthread_frame.c).  The chains
+The unit of work is a closed GOP (openhevc_amd/parallel.py): 1 I picture, 3 reference B pictures and 12
+non-reference B pictures of the workload's geometry, work lists already resident in HBM (uploaded before
+the timed region; the PCIe-inclusive rate is a separate figure in DESIGN.md).  GOPs are independent, so
+--chains of them are kept in flight per GPU: the GPU form of the reference's frame threads
+(pthread_frame.c).  One STEP advances every chain by one GOP (chains x 16 pictures per GPU).  The chains
 are split over --streams HIP streams; the chains of one stream advance in LOCKSTEP, i.e. picture k of
 all of them is one batch of independent pictures and every pass is one launch over the batch
 (oh_frames_execute), which fills the GPU where a single picture's dependency chain cannot.  With N GPUs every rank decodes its own 16 pictures per step and the four
@@ -55,13 +55,13 @@ def cpu_baseline(params, plan_kwargs, budget_s=12.0):
             break
     pics = steps * P.pictures_per_step(plan)
     return dict(value=round(pics * params.width * params.height / dt / 1e6, 2), unit="Mpixels/s", cores=1, kind="port",
-                sample=f"{steps} step(s) = {pics} pictures of the same synthetic stream in {dt:.1f} s, single thread, gcc -O2 oracle/oracle.c")
+                sample=f"{steps} GOP(s) = {pics} pictures of the same synthetic stream in {dt:.1f} s, single thread, gcc -O2 oracle/oracle.c")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
@@ -121,7 +121,7 @@ def main():
     engines = [g[0][1] for g in groups]
     plan, be = chains[0][0], chains[0][1]
     plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643)
-    pics_per_step = P.pictures_per_step(plan)
+    pics_per_step = P.pictures_per_step(plan) * n_chains      # a step advances every chain in flight by one GOP
 
     def barrier():
         if world > 1:
@@ -129,17 +129,13 @@ def main():
         torch.cuda.synchronize()
 
     def run(n_steps):
-        """n_steps GOPs: the streams take turns, each turn advances every chain of the stream by one step"""
-        done, turn = 0, 0
-        while done < n_steps:
-            g = groups[turn % n_streams]
-            m = min(len(g) - 1, n_steps - done)
-            with torch.cuda.stream(g[0][0]):
-                P.run_steps_batched(g[1:1 + m], dist if world > 1 else None)
-            done += m
-            turn += 1
+        """one step = every chain in flight advances by one GOP: each stream runs its chains as lockstep batches"""
+        for _ in range(n_steps):
+            for g in groups:
+                with torch.cuda.stream(g[0][0]):
+                    P.run_steps_batched(g[1:], dist if world > 1 else None)
 
-    run(max(args.warmup, n_chains))
+    run(max(args.warmup, 1))
     barrier()
     for eng in engines:
         eng.pass_times(reset=True)
@@ -176,11 +172,11 @@ def main():
         roofline = None
         if n_exec:
             # algorithmic bytes of this rank's step, per pass (openhevc_amd/parallel.py)
-            abytes = {k: 0.0 for k in pass_ms}             # per step: mean over the chains (their streams differ by seed)
+            abytes = {k: 0.0 for k in pass_ms}             # per step: all chains (their streams differ by seed)
             for plan_k, be_k, _, _ in chains:
                 for pic in plan_k.pictures():
                     for k, v in P.algorithmic_bytes(be_k.stats[pic.name], b).items():
-                        abytes[k] += v / n_chains
+                        abytes[k] += v
             dom = max(pass_ms, key=lambda k: pass_ms[k])
             steps_timed = n_exec / float(pics_per_step)
             ms_per_step_pass = pass_ms[dom] / steps_timed
@@ -195,7 +191,7 @@ def main():
                 n_launch_total = max(sum(e.n_batches for e in engines) * per_batch, 1)
                 avg_launch_us = pass_ms[dom] * 1e3 / n_launch_total
                 launch_source = "pass time between HIP events / launches, timed region, all streams"
-            n_launch = n_launch_total / steps_timed        # per step (GOP); fractional: a launch serves many GOPs
+            n_launch = n_launch_total / steps_timed        # per step; a launch serves a batch of up to 32 pictures
             achieved = (abytes[dom] * steps_timed / n_launch_total) / (avg_launch_us * 1e-6) / 1e9
             # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
             # rocprofv3 --pmc passes of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes
@@ -224,7 +220,8 @@ def main():
             "dtype": "u8" if params.bit_depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "width": params.width, "height": params.height, "bit_depth": params.bit_depth,
                        "chroma_format_idc": params.chroma_format_idc, "pictures_per_step_per_gpu": pics_per_step,
-                       "step": f"1 I + {args.waves - 1} reference B + {args.tail} non-reference B pictures per GPU (a closed GOP)",
+                       "step": f"every chain in flight advances by one closed GOP (1 I + {args.waves - 1} reference B + {args.tail} "
+                               f"non-reference B pictures): {n_chains} GOPs per GPU and step",
                        "chains_in_flight_per_gpu": n_chains, "streams_per_gpu": n_streams,
                        "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
                        "exchange": "one RCCL all-gather of the finished reference pictures per wave" if world > 1 else "none (1 GPU)",

@@ -7,13 +7,13 @@ R=$PWD
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp
-python3 $R/bench.py --steps 128 > $O/bench.json
+python3 $R/bench.py --steps 8 > $O/bench.json
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 128 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 4 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_stats.log
 echo "stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --steps 64 --no-cpu-baseline --no-profile > $O/bench_under_pmc_fetch.json 2> $O/rocprof_fetch.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --steps 1 --no-cpu-baseline --no-profile > $O/bench_under_pmc_fetch.json 2> $O/rocprof_fetch.log
 echo "fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --steps 64 --no-cpu-baseline --no-profile > $O/bench_under_pmc_write.json 2> $O/rocprof_write.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --steps 1 --no-cpu-baseline --no-profile > $O/bench_under_pmc_write.json 2> $O/rocprof_write.log
 echo "write done"
 python3 $R/tools/profile_round.py /tmp/p_stats /tmp/p_fetch /tmp/p_write $O r01
 ls -la $O

@@ -39,12 +39,15 @@ PASS_KERNEL = dict(inter="mc_kernel", residual="residual_kernel", intra="intra_c
 
 
 def cpu_baseline(params, plan_kwargs, budget_s=12.0):
-    """the CPU checker (oracle/, kind "port") on this host, one thread, on the SAME step plan"""
+    """One host thread on the SAME step plan: the reference's own C kernels when oracle/_ref/libohevc_ref.so is there
+    (kind "reference": built in the container from the reference sources, shipped to the GPU box as a binary),
+    else the CPU checker oracle/ (kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from openhevc_amd import parallel as P
-    from oracle_backend import OracleBackend
+    from oracle_backend import OracleBackend, RefBackend
     plan = P.make_step_plan(1, 0, **plan_kwargs)
-    be = OracleBackend(params, plan)
+    have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libohevc_ref.so"))
+    be = RefBackend(params, plan) if have_ref else OracleBackend(params, plan)
     t0 = time.perf_counter()
     steps = 0
     while True:
@@ -54,8 +57,10 @@ def cpu_baseline(params, plan_kwargs, budget_s=12.0):
         if dt >= budget_s or steps >= 50:
             break
     pics = steps * P.pictures_per_step(plan)
-    return dict(value=round(pics * params.width * params.height / dt / 1e6, 2), unit="Mpixels/s", cores=1, kind="port",
-                sample=f"{steps} GOP(s) = {pics} pictures of the same synthetic stream in {dt:.1f} s, single thread, gcc -O2 oracle/oracle.c")
+    what = ("the reference's C kernels (gcc -O2 -fno-tree-vectorize on hevcdsp.c, hevcpred.c, hevc_filter.c, videodsp.c; oracle/ref_harness.c drives them)"
+            if have_ref else "gcc -O2 oracle/oracle.c")
+    return dict(value=round(pics * params.width * params.height / dt / 1e6, 2), unit="Mpixels/s", cores=1, kind="reference" if have_ref else "port",
+                sample=f"{steps} GOP(s) = {pics} pictures of the same synthetic stream in {dt:.1f} s, single thread, {what}")
 
 
 def main():

@@ -37,13 +37,7 @@ static void tables(int bd)
     g_ready[bd] = 1;
 }
 
-static int pel_idx(int w)                      /* ff_hevc_pel_weight, hevc.c:42 */
-{
-    switch (w) {
-    case 2: return 0; case 4: return 1; case 6: return 2; case 8: return 3; case 12: return 4;
-    case 16: return 5; case 24: return 6; case 32: return 7; case 48: return 8; default: return 9;
-    }
-}
+#include "replay_slots.inc"                    /* pel_idx(), replay_pu(), replay_inverse(), replay_pcm(): our CTU-loop stand-in */
 
 /* ---------------- residual slots ---------------- */
 API void ref_transform_add(int bd, int log2, uint8_t *dst, int16_t *coeffs, ptrdiff_t stride)
@@ -395,4 +389,74 @@ API void ref_up_frame(uint8_t *const el[3], const int el_stride[3], int el_w, in
     fe.coded_width = el_w; fe.coded_height = el_h; fb.coded_width = bl_w; fb.coded_height = bl_h;
     g_dsp[8].upsample_base_layer_frame(&fe, &fb, buf, &w, &inf, 1);
     for (int c = 0; c < 3; c++) free(buf[c]);
+}
+
+/* ---------------- whole picture through the reference's kernels ----------------
+ * Passes 1-5 of one work list with the reference's own slots and drivers: PUs through put_hevc_{q,e}pel* with
+ * emulated_edge_mc (replay_slots.inc issues the calls the way hevc.c:1641-1949 does), inverse transforms through
+ * idct* / transform_skip / rdpcm, inter and PCM blocks added at once, intra blocks through hpc.intra_pred[] with the
+ * residual added after each block (ref_intra_picture, blocks re-sorted into decode order here), then ff_hevc_hls_filters.
+ * Used to pin the oracle at picture level incl. the MC driver logic, and as bench.py's CPU baseline ("reference"). */
+/* decode (z-scan) order of the intra blocks: CTB raster order, then Morton order of the block's luma position inside the
+ * CTB, then plane; the 4:2:0 chroma blocks of four 4x4 luma blocks are coded after the fourth one (hevc.c:1395) */
+static const OhPicParams *g_sort_p;
+static uint64_t decode_key(const OhIntra *it)
+{
+    const OhPicParams *p = g_sort_p;
+    int hs = oh_hshift(p, it->c_idx), vs = oh_vshift(p, it->c_idx), ctb = 1 << p->log2_ctb_size;
+    int x = it->x << hs, y = it->y << vs, xi = x & (ctb - 1), yi = y & (ctb - 1);
+    uint64_t m = 0;
+    if (it->c_idx && p->chroma_format_idc == 1 && it->log2_size == 2) { xi += 4; yi += 4; }
+    for (int b = 0; b < 7; b++)
+        m |= (uint64_t)((xi >> b) & 1) << (2 * b) | (uint64_t)((yi >> b) & 1) << (2 * b + 1);
+    return ((uint64_t)(y >> p->log2_ctb_size) << 44) | ((uint64_t)(x >> p->log2_ctb_size) << 28) | (m << 4) | it->c_idx;
+}
+static int decode_cmp(const void *a, const void *b)
+{
+    uint64_t ka = decode_key((const OhIntra *)a), kb = decode_key((const OhIntra *)b);
+    return ka < kb ? -1 : ka > kb;
+}
+
+API int ref_frame(const OhFrame *f_in, uint8_t *const cur[3], const ptrdiff_t cur_stride[3],
+                  uint8_t *const refs[][3], int n_refs, const ptrdiff_t ref_stride[3], uint8_t *const sao_scratch[3])
+{
+    OhFrame fcopy = *f_in;
+    const OhFrame *f = &fcopy;
+    const OhPicParams *p = &f->p;
+    ReplayCtx *k = calloc(1, sizeof(*k));
+    int16_t *pool = malloc(sizeof(int16_t) * (size_t)(f->n_coeff ? f->n_coeff : 1));
+    OhIntra *sorted = malloc(sizeof(OhIntra) * (size_t)(f->n_intra ? f->n_intra : 1));
+    int rc = 0;
+    memcpy(sorted, f_in->intra, sizeof(OhIntra) * (size_t)f->n_intra);      /* the work list is in wavefront order */
+    g_sort_p = p;
+    qsort(sorted, f->n_intra, sizeof(OhIntra), decode_cmp);
+    fcopy.intra = sorted;
+    tables(p->bit_depth);
+    k->f = f; k->bpp = p->bit_depth > 8 ? 2 : 1;
+    k->d = g_dsp[p->bit_depth]; k->hp = g_pred[p->bit_depth]; k->v = g_vdsp[p->bit_depth];
+    for (int c = 0; c < 3; c++) { k->cur[c] = cur[c]; k->cur_ls[c] = (int)cur_stride[c]; k->ref_ls[c] = (int)ref_stride[c]; }
+    for (int s = 0; s < n_refs && s < OH_MAX_REFS; s++)
+        for (int c = 0; c < 3; c++) k->ref[s][c] = refs[s][c];
+    for (uint32_t i = 0; i < f->n_pu; i++)
+        replay_pu(k, &f->pu[i]);
+    memcpy(pool, f->coeffs, sizeof(int16_t) * (size_t)f->n_coeff);
+    for (uint32_t i = 0; i < f->n_tu; i++)
+        if (f->tu[i].kind != OH_TU_PCM)
+            replay_inverse(k, &f->tu[i], pool + f->tu[i].coeff_off);
+    for (uint32_t i = 0; i < f->n_tu; i++) {
+        const OhTu *tu = &f->tu[i];
+        if (tu->kind == OH_TU_PCM)
+            replay_pcm(k, tu);
+        else if (tu->flags & OH_TUF_ADD_NOW)
+            k->d.transform_add[tu->log2_size - 2](cur[tu->c_idx] + (ptrdiff_t)tu->y * cur_stride[tu->c_idx] + (ptrdiff_t)tu->x * k->bpp,
+                                                  pool + tu->coeff_off, cur_stride[tu->c_idx]);
+    }
+    if (f->n_intra)
+        rc = ref_intra_picture(f, cur, cur_stride, pool);
+    if (!rc && (p->deblock_enabled || p->sao_enabled))
+        rc = ref_filter_picture(f, cur, cur_stride, sao_scratch);
+    free(pool);
+    free(sorted);
+    free(k);
+    return rc;
 }

@@ -93,6 +93,7 @@ _REF_SIGS = {
     "ref_up_block_h": [I, I, I, I16, P, U8, P, I, I, I, I, I, V],
     "ref_up_block_v": [I, I, I, U8, P, I16, P, I, I, I, I, I, I, I, V],
     "ref_up_frame": [V, V, I, I, V, V, I, I, V],
+    "ref_frame": [V, V, V, V, I, V, V],
 }
 
 

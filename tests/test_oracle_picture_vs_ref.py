@@ -179,3 +179,59 @@ def test_loop_filters_picture(w, h, bd, chroma, lc, flavour):
     assert touched[0]                              # the deblocking filter really changed samples
     assert touched[1] or w * h <= 64 * 64          # and so did SAO
     rec.close()
+
+
+def ref_frame(rec, f, pics):
+    """whole picture (passes 1-5) through the reference's own kernels: oracle/ref_harness.c::ref_frame.
+    pics: {id: HostPic}; pics[f.cur_pic] is reconstructed in place"""
+    cur = pics[f.cur_pic]
+    d, s = plane_ptrs(cur)
+    scratch = cur.copy()
+    d2, _ = plane_ptrs(scratch)
+    n_refs = max([i for i in range(F.OH_MAX_REFS) if f.ref_pics[i] >= 0] + [-1]) + 1
+    RefT = (C.c_void_p * 3) * max(n_refs, 1)
+    refs = RefT()
+    rs = None
+    for i in range(n_refs):
+        hp = pics[f.ref_pics[i]]
+        for c, pl in enumerate(hp.planes):
+            refs[i][c] = pl.ctypes.data
+        rs = plane_ptrs(hp)[1]
+    if rs is None:
+        rs = s
+    return ref().ref_frame(C.byref(f), d, s, C.cast(refs, C.c_void_p), n_refs, rs, d2)      # sorts the blocks into decode order itself
+
+
+PIPELINE_CASES = [
+    # name, w, h, bd, chroma, log2_ctb, slice_type, params, knobs
+    ("b8", 416, 240, 8, 1, 6, 2, {}, {"weighted_pct": 30}),
+    ("p10_ctb32", 264, 200, 10, 1, 5, 1, {}, {"tskip_pct": 20}),
+    ("b8_far_mv", 200, 136, 8, 1, 6, 2, {}, {"mv_range": 3000, "skip_pct": 60}),
+    ("b8_pcm_bypass", 264, 200, 8, 1, 6, 2, {"pcm_loop_filter_disable": 1, "transquant_bypass_enable": 1},
+     {"pcm_pct": 12, "bypass_pct": 12, "intra_pct": 30, "vary_deblock_offsets": 1}),
+    ("b10_cip", 200, 136, 10, 1, 6, 2, {"constrained_intra_pred": 1}, {"intra_pct": 50}),
+    ("b8_422", 200, 136, 8, 2, 5, 2, {}, {"weighted_pct": 25, "intra_pct": 25}),
+    ("b10_444", 136, 88, 10, 3, 5, 2, {}, {}),
+    ("b12", 136, 88, 12, 1, 5, 2, {}, {}),
+    ("i8", 264, 200, 8, 1, 6, 0, {}, {}),
+]
+
+
+@pytest.mark.parametrize("case", PIPELINE_CASES, ids=[c[0] for c in PIPELINE_CASES])
+def test_whole_picture_through_reference_kernels(case):
+    """passes 1-5 of a work list through the reference's slots and drivers (ref_frame) vs the oracle's oh_or_frame:
+    pins the oracle at picture level including the motion-compensation driver arithmetic (MV split, chroma MV
+    derivation, edge emulation = clamping, weights) that the slot-level tests cannot see"""
+    name, w, h, bd, chroma, lc, st, pk, knobs = case
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc, **pk)
+    rec = F.Recorder(p)
+    for seed in range(2):
+        f = rec.synth(F.synth_params(st, 7000 + seed, **knobs), 2, [0, 1] if st else [])
+        rng = np.random.default_rng(seed)
+        pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}
+        want = {k: v.copy() for k, v in pics.items()}
+        assert oracle().oh_or_frame(C.byref(f), host_pic_array(want)) == 0
+        assert ref_frame(rec, f, pics) == 0
+        for c in range(F.n_planes(p)):
+            assert np.array_equal(want[2].visible(c), pics[2].visible(c)), (name, seed, c)
+    rec.close()

@@ -20,7 +20,8 @@ def driver():
     out = os.path.join(HERE, "_replay_driver.so")
     src = os.path.join(HERE, "replay_driver.c")
     lib = os.path.join(F.PKG_DIR, "libohevc_host.so")
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+    inc = os.path.join(os.path.dirname(HERE), "oracle", "replay_slots.inc")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(lib), os.path.getmtime(inc)):
         subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-std=gnu99", "-o", out, src, lib,
                                "-Wl,-rpath," + F.PKG_DIR])
     d = C.CDLL(out)

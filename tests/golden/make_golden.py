@@ -104,10 +104,10 @@ PICTURE_CASES = [
 
 
 def picture_case(name, w, h, bd, chroma, lc, st, seed, knobs):
-    """Reference pictures: seeded noise-on-smooth content.  The reconstruction passes 1-3 of the
-    expected picture come from the oracle (their slots are pinned one by one against the
-    reference above and in test_oracle_vs_ref.py); the in-loop filters then run through the
-    reference's own ff_hevc_hls_filters driver, so the stored MD5s are reference output."""
+    """Seeded reference pictures and a synthetic work list; the expected picture is REFERENCE OUTPUT end to end:
+    passes 1-5 run through the reference's own slots and drivers (oracle/ref_harness.c::ref_frame: put_hevc_{q,e}pel*
+    with emulated_edge_mc, idct*/transform_*, put_pcm, hpc.intra_pred[], ff_hevc_hls_filters).  `recon` is the same
+    with both in-loop filters switched off."""
     pcm, cip = "pcm" in name, "cip" in name
     p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
                      pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm), constrained_intra_pred=int(cip))
@@ -115,24 +115,16 @@ def picture_case(name, w, h, bd, chroma, lc, st, seed, knobs):
     f = rec.synth(F.synth_params(st, seed, **knobs), 2, [0, 1])
     rng = np.random.default_rng(seed)
     pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p)}
-    arr = host_pic_array(pics)
-    o = oracle()
-    co = np.ctypeslib.as_array(f.coeffs, shape=(int(f.n_coeff),)).copy()
-    assert o.oh_or_pass_inter(C.byref(f), arr) == 0
-    assert o.oh_or_pass_residual(C.byref(f), arr, i16p(co)) == 0
-    if cip:                                                # the reference's own intra_pred slots, blocks in decode order
-        sys.path.insert(0, os.path.dirname(HERE))
-        from test_oracle_picture_vs_ref import decode_order
-        d, s = plane_ptrs(pics[2])
-        assert ref().ref_intra_picture(C.byref(decode_order(rec, f)), d, s, i16p(co)) == 0
-    else:
-        assert o.oh_or_pass_intra(C.byref(f), arr, i16p(co)) == 0
-    recon = md5_planes(pics[2])
-    scratch = pics[2].copy()
-    d, s = plane_ptrs(pics[2])
-    d2, _ = plane_ptrs(scratch)
-    assert ref().ref_filter_picture(C.byref(f), d, s, d2) == 0
-    return {"recon": recon, "final": md5_planes(pics[2]),
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_oracle_picture_vs_ref import ref_frame
+    plain = {k: v.copy() for k, v in pics.items()}
+    g = F.OhFrame()
+    C.memmove(C.byref(g), C.byref(f), C.sizeof(F.OhFrame))
+    g.p.deblock_enabled = 0
+    g.p.sao_enabled = 0
+    assert ref_frame(rec, g, plain) == 0
+    assert ref_frame(rec, f, pics) == 0
+    return {"recon": md5_planes(plain[2]), "final": md5_planes(pics[2]),
             "counts": [int(f.n_pu), int(f.n_tu), int(f.n_intra), int(f.n_levels), int(f.n_coeff)]}
 
 

@@ -313,3 +313,38 @@ def test_shvc_upsample_pictures(eng):
         eng.pic_upsample(a, b, F.upsample_setup(416, 240, 416, 240))
     eng.pic_free(a)
     eng.pic_free(b)
+
+
+def test_random_configurations(eng):
+    """seeded sweep over geometry x bit depth x chroma format x CTB size x tool switches x generator knobs:
+    every picture must match the oracle bit for bit (catches interactions the hand-picked cases miss)"""
+    rng = np.random.default_rng(20261004)
+    n_checked = 0
+    for it in range(40):
+        chroma = int(rng.choice([0, 1, 1, 1, 2, 3]))
+        bd = int(rng.choice([8, 8, 10, 10, 12]))
+        lc = int(rng.choice([4, 5, 6]))
+        w, h = 8 * int(rng.integers(2, 34)), 8 * int(rng.integers(2, 26))
+        st = int(rng.choice([0, 1, 2, 2, 2]))
+        pcm, byp, cip = bool(rng.integers(0, 3) == 0), bool(rng.integers(0, 3) == 0), bool(rng.integers(0, 3) == 0)
+        p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
+                         pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(byp), constrained_intra_pred=int(cip),
+                         strong_intra_smoothing=int(rng.integers(0, 2)), intra_smoothing_disabled=int(rng.integers(0, 4) == 0),
+                         sao=int(rng.integers(0, 4) != 0), deblock=int(rng.integers(0, 4) != 0),
+                         cb_qp_offset=int(rng.integers(-4, 5)), cr_qp_offset=int(rng.integers(-4, 5)))
+        knobs = dict(intra_pct=int(rng.integers(0, 80)), skip_pct=int(rng.integers(0, 70)), bi_pct=int(rng.integers(0, 100)),
+                     frac_mv_pct=int(rng.integers(0, 101)), mv_range=int(rng.choice([8, 64, 300, 3000])),
+                     cbf_pct=int(rng.integers(10, 100)), weighted_pct=int(rng.choice([0, 0, 30, 100])),
+                     split_pct=int(rng.integers(10, 90)), tskip_pct=int(rng.choice([0, 0, 30])),
+                     pcm_pct=int(rng.choice([0, 15])) if pcm else 0, bypass_pct=int(rng.choice([0, 15])) if byp else 0,
+                     sao_pct=int(rng.integers(0, 101)), vary_deblock_offsets=int(rng.integers(0, 2)))
+        rec = F.Recorder(p)
+        f = rec.synth(F.synth_params(st, 555000 + it, **knobs), 2, [0, 1] if st else [])
+        prng = np.random.default_rng(it)
+        pics = {0: F.HostPic(p, rng=prng), 1: F.HostPic(p, rng=prng), 2: F.HostPic(p, rng=prng)}
+        want, got = run_both(eng, p, f, pics)
+        assert_same(want, got, f"random configuration {it}: {w}x{h} {bd} bit chroma {chroma} ctb {1 << lc} slice {st} "
+                               f"pcm {pcm} bypass {byp} cip {cip} knobs {knobs}")
+        n_checked += 1
+        rec.close()
+    assert n_checked == 40

@@ -18,6 +18,10 @@
  * reference cannot fail (void returns), so recording never reports errors —
  * they surface here, at submit / sync.  There is NO CPU fallback: every entry point fails with
  * OH_E_HIP when no gfx950 device is usable.
+ *
+ * Threading: an engine is a single-submitter object (one HIP stream, one picture table); calls on the same engine
+ * must be serialised by the caller (the reference's frame threads each record into their own OhRecorder and hand the
+ * finished work list to the thread that owns the engine).  Different engines are independent.
  */
 #ifndef OHEVC_HIP_H
 #define OHEVC_HIP_H

@@ -163,13 +163,16 @@ __global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
     const bool live = jidx < nj;                            /* a dead quarter repeats the last block and stores nothing */
     const DevMcJob job = gload((LUMA ? f->mc_luma : f->mc_chroma) + (live ? jidx : nj - 1));
 
-    /* per-wave tables: reference plane pointers and the packed taps */
-    if (lane < OH_MAX_REFS * (LUMA ? 1 : 2)) {
+    /* per-wave tables: reference plane pointers and the packed taps (built once by ohk_init() in the LDS layout);
+     * both loads are issued before either is waited for */
+    {
+        const bool has_rp = lane < OH_MAX_REFS * (LUMA ? 1 : 2), has_ct = lane < (G::NFR + 1) * G::CS;
         const int r = LUMA ? lane : lane >> 1, pl = LUMA ? 0 : lane & 1;
-        refp[r][pl] = f->refs[r].p[LUMA ? 0 : 1 + pl];
+        const void *rp = has_rp ? f->refs[r & (OH_MAX_REFS - 1)].p[LUMA ? 0 : 1 + pl] : nullptr;
+        const unsigned ct = has_ct ? g_mctab[LUMA ? 0 : 1][bd - 8][lane] : 0u;
+        if (has_rp) refp[r][pl] = rp;
+        if (has_ct) ctab[lane] = ct;
     }
-    if (lane < (G::NFR + 1) * G::CS)                        /* packed taps, built once by ohk_init() in the LDS layout */
-        ctab[lane] = g_mctab[LUMA ? 0 : 1][bd - 8][lane];
     const int pw = f->cur.w[LUMA ? 0 : 1], ph = f->cur.h[LUMA ? 0 : 1], stride = f->cur.stride[LUMA ? 0 : 1];
     const int bw = job.w, bh = job.h, wh = bh + TAPS - 1;
     const bool two = job.ref[1] != OH_NO_REF;

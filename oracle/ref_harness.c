@@ -460,3 +460,50 @@ API int ref_frame(const OhFrame *f_in, uint8_t *const cur[3], const ptrdiff_t cu
     free(k);
     return rc;
 }
+
+/* ---------------- SHVC: the PU-driven block path (ACTIVE_PU_UPSAMPLING, hevc.h:117) ----------------
+ * ff_upsample_block (hevc_filter.c:1370-1426) for every CTB of the enhancement-layer picture: upsample_block_luma / _mc
+ * with emulated_edge_up_h/v and the block slots.  The base-layer planes must carry an edge border like the reference's
+ * frames (the emulation WRITES into it).  Motion fields are left empty (pred_flag 0: ff_upscale_mv_block only clears). */
+API int ref_up_blocks(uint8_t *const el[3], const int el_stride[3], int el_w, int el_h,
+                      uint8_t *const bl[3], const int bl_stride[3], int bl_w, int bl_h, const OhUpsample *u, int log2_ctb)
+{
+    HEVCContext *s = calloc(1, sizeof(*s));
+    HEVCSPS *sps = calloc(1, sizeof(*sps));
+    HEVCVPS *vps = calloc(1, sizeof(*vps));
+    HEVCLocalContext *lc = calloc(1, sizeof(*lc));
+    HEVCFrame *blf = calloc(1, sizeof(*blf)), *ilr = calloc(1, sizeof(*ilr)), *ref0 = calloc(1, sizeof(*ref0));
+    AVFrame *fb = calloc(1, sizeof(*fb)), *fe = calloc(1, sizeof(*fe));
+    struct HEVCWindow w;
+    int ctb = 1 << log2_ctb;
+    if (!s || !sps || !vps || !lc || !blf || !ilr || !ref0 || !fb || !fe)
+        return -1;
+    up_fill(u, &w, &s->up_filter_inf);
+    sps->log2_ctb_size = log2_ctb; sps->width = el_w; sps->height = el_h;
+    sps->ctb_width = (el_w + ctb - 1) >> log2_ctb; sps->ctb_height = (el_h + ctb - 1) >> log2_ctb;
+    sps->log2_min_pu_size = 2;
+    sps->scaled_ref_layer_window[0] = w;
+    s->sps = sps; s->vps = vps; s->nuh_layer_id = 1;            /* m_refLayerId[1][0] == 0 */
+    s->HEVClc = lc; s->HEVClcList[0] = lc;
+    s->sh.slice_type = P_SLICE;
+    for (int c = 0; c < 3; c++) {
+        fb->data[c] = bl[c]; fb->linesize[c] = bl_stride[c];
+        fe->data[c] = el[c]; fe->linesize[c] = el_stride[c];
+    }
+    fb->coded_width = bl_w; fb->coded_height = bl_h; fe->coded_width = el_w; fe->coded_height = el_h;
+    blf->frame = fb; ref0->frame = fe;
+    blf->tab_mvf = calloc((size_t)(bl_w >> 2) * (bl_h >> 2) + 64, sizeof(MvField));
+    ilr->tab_mvf = calloc((size_t)(el_w >> 2) * (el_h >> 2) + 64, sizeof(MvField));
+    s->BL_frame = blf; s->inter_layer_ref = ilr;
+    s->is_upsampled = calloc((size_t)sps->ctb_width * sps->ctb_height, 1);
+    ff_hevc_dsp_init(&s->hevcdsp, 8);
+    ff_videodsp_init(&s->vdsp, 8);
+    for (int y0 = 0; y0 < el_h; y0 += ctb)
+        for (int x0 = 0; x0 < el_w; x0 += ctb)
+            ff_upsample_block(s, ref0, x0, y0, ctb, ctb);
+    int missing = 0;
+    for (int i = 0; i < sps->ctb_width * sps->ctb_height; i++) missing += !s->is_upsampled[i];
+    free(s->is_upsampled); free(blf->tab_mvf); free(ilr->tab_mvf);
+    free(fb); free(fe); free(blf); free(ilr); free(ref0); free(lc); free(vps); free(sps); free(s);
+    return missing;
+}

@@ -94,6 +94,7 @@ _REF_SIGS = {
     "ref_up_block_v": [I, I, I, U8, P, I16, P, I, I, I, I, I, I, I, V],
     "ref_up_frame": [V, V, I, I, V, V, I, I, V],
     "ref_frame": [V, V, V, V, I, V, V],
+    "ref_up_blocks": [V, V, I, I, V, V, I, I, V, I],
 }
 
 
@@ -101,7 +102,7 @@ def _declare(lib, sigs):
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int if ("pass_" in name or name.endswith("_frame") or name.endswith("_picture")) and name != "ref_up_frame" else None
+        fn.restype = C.c_int if ("pass_" in name or name.endswith("_frame") or name.endswith("_picture") or name == "ref_up_blocks") and name != "ref_up_frame" else None
     return lib
 
 

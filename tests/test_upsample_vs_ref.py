@@ -96,3 +96,52 @@ def test_frame_slot(name, bl_size, el_size, win, pa):
     _, _, want, got = run_frame_both(bl_size, el_size, win, 77, pa)
     for c in range(3):
         assert np.array_equal(want.visible(c), got.visible(c)), (name, c)
+
+
+def edge_padded(p, hp, pad=32):
+    """planes with an edge-replicated border, like the reference's frames (its block path writes into the border)"""
+    arrs, ptrs, ls = [], [], []
+    for c, pl in enumerate(hp.planes):
+        w, h = F.plane_dims(p, c)
+        a = np.ascontiguousarray(np.pad(pl[:h, :w], pad, mode="edge"))
+        arrs.append(a)
+        ls.append(a.strides[0])
+        ptrs.append(a.ctypes.data + pad * a.strides[0] + pad * a.itemsize)
+    return arrs, ptrs, ls
+
+
+def run_block_path(u, bl, bl_size, el_size, log2_ctb):
+    pb, pe = F.pic_params(*bl_size), F.pic_params(*el_size)
+    keep, ptrs, ls = edge_padded(pb, bl)
+    el = F.HostPic(pe, fill=0)
+    el_p = (C.c_void_p * 3)(*[pl.ctypes.data for pl in el.planes])
+    el_s = (C.c_int * 3)(*[pl.strides[0] for pl in el.planes])
+    bl_p, bl_s = (C.c_void_p * 3)(*ptrs), (C.c_int * 3)(*ls)
+    assert ref().ref_up_blocks(el_p, el_s, el_size[0], el_size[1], bl_p, bl_s, bl_size[0], bl_size[1], C.byref(u), log2_ctb) == 0
+    return el
+
+
+@pytest.mark.parametrize("name,bl_size,el_size,lc", [
+    ("x2_ctb64", (208, 120), (416, 240), 6), ("x2_ctb16", (208, 120), (416, 240), 4), ("x1_5", (176, 96), (264, 144), 5),
+    ("snr", (264, 144), (264, 144), 6), ("ratio_1_64", (200, 112), (328, 200), 5), ("x2_1080p", (960, 544), (1920, 1088), 6)])
+def test_pu_driven_block_path_equals_whole_picture_slot(name, bl_size, el_size, lc):
+    """The reference's default build up-samples CTB by CTB on demand (ACTIVE_PU_UPSAMPLING: ff_upsample_block,
+    hevc_filter.c:1370-1426, with emulated_edge_up_h/v and the block slots); the GPU pass mirrors the whole-picture slot.
+    For zero scaled-reference-layer offsets and phase_align 0 — every ratio — the two reference paths give the same picture,
+    so the GPU pass is a drop-in for either."""
+    u, bl, want, got = run_frame_both(bl_size, el_size, (0, 0, 0, 0), 91)
+    el = run_block_path(u, bl, bl_size, el_size, lc)
+    for c in range(3):
+        assert np.array_equal(want.visible(c), el.visible(c)), (name, c)
+        assert np.array_equal(got.visible(c), el.visible(c)), (name, c)
+
+
+def test_reference_paths_disagree_with_offsets_or_phase_alignment():
+    """Recorded fact, not a requirement: with scaled-reference-layer offsets or m_phaseAlignFlag the reference's own two
+    paths produce different pictures (the x2 / x1.5 block slots ignore the phase, the block driver positions by
+    pic_conf_win).  The GPU pass and the oracle follow the whole-picture slot there."""
+    for win, pa in (((8, 8, 8, 8), 0), ((0, 0, 0, 0), 1)):
+        bl_size = (200, 112) if win[0] else (208, 120)
+        u, bl, want, _ = run_frame_both(bl_size, (416, 240), win, 92, pa)
+        el = run_block_path(u, bl, bl_size, (416, 240), 6)
+        assert not np.array_equal(want.visible(0), el.visible(0))

@@ -34,7 +34,8 @@ enum { OH_MCF_FROM_L1 = 1 };      /* uni-prediction whose only list is list 1 (s
  * the host from the level's CTUs (OhIntraLaunch). */
 #define OH_CTU_MAX 64
 #define OH_MAX_CTU_BLOCKS 768                      /* 64x64 4:4:4 all 4x4 */
-#define OH_INTRA_WAVE_LDS 528                      /* per-wave edge arrays: 132 ints (kernels.hip: IntraLds) */
+#define OH_INTRA_WAVE_LDS 576                      /* per-wave edge arrays: 132 ints for one block or 4 x 36 ints for four
+                                                      <=8x8 blocks in 16-lane slots (kernels.hip: IntraLds) */
 struct OhCtuAreas { uint32_t main[3], top[3], total; };
 static __host__ __device__ inline OhCtuAreas oh_ctu_areas(int log2_ctb, int chroma_format_idc)
 {
@@ -56,7 +57,7 @@ static __host__ __device__ inline OhCtuAreas oh_ctu_areas(int log2_ctb, int chro
 }
 struct OhIntraLaunch {                             /* one wavefront level of a batch of pictures = one launch */
     uint32_t level;                                /* index into DevFrame.lvl_start                           */
-    uint32_t off_items, off_sub, off_res, off_wave, lds_bytes;   /* byte offsets into the dynamic LDS block */
+    uint32_t off_items, off_sub, off_small, off_res, off_wave, lds_bytes;   /* byte offsets into the dynamic LDS block */
     uint32_t waves;                                /* waves per workgroup (CTU)                               */
     uint32_t staged;                               /* 1: every CTU of the launch has its residual span contiguous: staged in LDS */
 };
@@ -109,6 +110,7 @@ struct DevFrame {
     const DevIntra  *intra;
     const DevIntraCtu *ictu;          /* CTUs with intra blocks in wavefront order             */
     const uint32_t  *sub_start;       /* sub-level ranges into intra[]                         */
+    const uint32_t  *sub_small;       /* per sub-level: its first sub_small[] blocks are <= 8x8 (slot path)      */
     const uint32_t  *lvl_start;       /* wavefront level ranges into ictu[]                    */
     const uint8_t   *vbs, *hbs;
     const int8_t    *qp;

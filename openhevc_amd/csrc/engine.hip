@@ -733,6 +733,14 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         for (uint32_t b = f->sub_start[dictu[k].sub_first]; b < f->sub_start[dictu[k].sub_first + dictu[k].n_sub]; b++)
             if (dintra[b].res_off != OH_NO_COEFF && dictu[k].res_cnt)
                 dintra[b].res_lds = dintra[b].res_off - dictu[k].res_lo;
+    /* inside a sub-level the blocks are independent: put the <=8x8 ones first — the kernel runs four of them per wave
+     * (16-lane slots) — and note how many there are (none for constrained intra pred, which needs the one-block path) */
+    std::vector<uint32_t> sub_small(f->n_intra ? f->n_sub : 0, 0);
+    for (size_t j = 0; j < sub_small.size(); j++) {
+        auto b0 = dintra.begin() + f->sub_start[j], b1 = dintra.begin() + f->sub_start[j + 1];
+        auto mid = std::stable_partition(b0, b1, [](const DevIntra &d) { return d.log2_size <= 3; });
+        sub_small[j] = p.constrained_intra_pred ? 0u : (uint32_t)(mid - b0);
+    }
     std::vector<OhDevFrame::Level> levels(f->n_intra ? f->n_levels : 0);
     for (size_t l = 0; l < levels.size(); l++) {
         OhDevFrame::Level &L = levels[l];
@@ -748,12 +756,15 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             L.max_items = std::max(L.max_items, std::min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
             L.max_sub = std::max(L.max_sub, std::min((uint32_t)dictu[k].n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
             L.max_res = std::max(L.max_res, dictu[k].res_cnt);
-            L.sum_items += b1 - b0; L.sum_sub += dictu[k].n_sub;
+            for (uint32_t j = dictu[k].sub_first; j < dictu[k].sub_first + dictu[k].n_sub; j++)      /* wave passes: slot groups + big blocks */
+                L.sum_items += (sub_small[j] + 3) / 4 + (f->sub_start[j + 1] - f->sub_start[j] - sub_small[j]);
+            L.sum_sub += dictu[k].n_sub;
         }
     }
     int s_ictu = add(dictu.data(), dictu.size() * sizeof(DevIntraCtu));
     int s_lvl = add(levels.empty() ? nullptr : f->level_start, levels.empty() ? 0 : (levels.size() + 1) * sizeof(uint32_t));
     int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
+    int s_small = add(sub_small.data(), sub_small.size() * sizeof(uint32_t));
     int s_vbs = add(has_db ? f->vertical_bs : nullptr, has_db ? f->bs_size : 0);
     int s_hbs = add(has_db ? f->horizontal_bs : nullptr, has_db ? f->bs_size : 0);
     int s_qp = add(has_db ? f->qp_y_tab : nullptr, has_db ? oh_qp_tab_size(&p) : 0);
@@ -789,6 +800,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.intra = (const DevIntra *)(base + seg[s_intra].off);
     hd.ictu = (const DevIntraCtu *)(base + seg[s_ictu].off);
     hd.sub_start = (const uint32_t *)(base + seg[s_sub].off);
+    hd.sub_small = (const uint32_t *)(base + seg[s_small].off);
     hd.lvl_start = (const uint32_t *)(base + seg[s_lvl].off);
     hd.vbs = (const uint8_t *)(base + seg[s_vbs].off);
     hd.hbs = (const uint8_t *)(base + seg[s_hbs].off);
@@ -914,7 +926,8 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             if (IL.waves < 1 || IL.waves > 8) IL.waves = 8;
             size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
             IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
-            IL.off_sub = (uint32_t)off;   off = align_up(off + ((size_t)max_sub + 1) * sizeof(uint32_t), 16);
+            IL.off_sub = (uint32_t)off;   off += ((size_t)max_sub + 1) * sizeof(uint32_t);
+            IL.off_small = (uint32_t)off; off = align_up(off + (size_t)max_sub * sizeof(uint32_t), 16);
             IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)max_res * sizeof(int16_t), 16);
             IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
             IL.lds_bytes = (uint32_t)off;

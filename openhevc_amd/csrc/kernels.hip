@@ -891,6 +891,150 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     ACC(2, ta, tb); ACC(3, tb, tc); ACC(4, tc, td);
 }
 
+/* Four blocks of <= 8x8 samples per wave, one per 16-lane slot (DPP row).  Same arithmetic as intra_block with the
+ * block descriptor held per lane instead of in scalar registers: slot-local lane reads are ds_bpermute, the smoothing
+ * shifts are DPP row shifts (they stop at the slot boundary by construction), the DC sum is an xor-butterfly inside the
+ * slot.  Blocks of a sub-level are independent, so the four of a pass need no ordering.  edges: 4 x 36 ints,
+ * per slot [0] = left[-1], [1..16] = left[0..15], [17] = top[-1], [18..33] = top[0..15]. */
+static __device__ __forceinline__ int row_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); }
+static __device__ __forceinline__ int row_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false); }
+
+template <typename PX>
+static __device__ __forceinline__ void intra_slots(const int bd, const PlaneRegs &pr, const DevIntra *__restrict__ items, const uint32_t first,
+                                                   const int count, int *__restrict__ edges, uint16_t *__restrict__ M,
+                                                   const int16_t *__restrict__ res_lds_base, const int lane)
+{
+    const int slot = lane >> 4, sl = lane & 15, base = lane & 48;
+    const bool act = slot < count;
+    const uint4v *__restrict__ item = (const uint4v *)&items[first + (act ? slot : 0)];
+    const uint4v q0 = item[0], q1 = item[1];
+    const uint32_t w0 = q0[0], w1 = q0[1], res_off = q0[2], w3 = q0[3], w4 = q1[0], w5 = q1[1], res_lds = q1[2];
+    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
+    const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
+    const int n = 1 << log2, cls = (flags >> 4) & 7, ngroups = (n * n) >> 2;
+    const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
+    const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
+    const int i = sl;                                                  /* edge element this lane owns (2n <= 16) */
+    const bool work = act && sl < ngroups;                             /* group this lane predicts */
+
+    short4v rv = short4v{ 0, 0, 0, 0 };
+    if (work && res_off != OH_NO_COEFF) rv = *(const short4v *)(res_lds_base + res_lds + 4 * sl);
+
+    int tv = 0, lv = 0, cv = 0;
+    {
+        const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
+        const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
+        const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
+        if (t_ok) tv = M[top_off + ti];
+        if (l_ok) lv = M[cm_off - 1 + __mul24(li, rs)];
+        if (a_ul) cv = M[top_off - 1];
+    }
+    const int l_0 = __shfl(lv, base), l_n1 = __shfl(lv, base + n - 1), l_n = __shfl(lv, base + (n & 15));
+    const int t_0 = __shfl(tv, base), t_n1 = __shfl(tv, base + n - 1), t_n = __shfl(tv, base + (n & 15));
+    int corner, left_i, top_i;
+    if (a_bl || a_l) {
+        left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
+        corner = a_ul ? cv : (a_l ? l_0 : l_n);
+    } else {
+        corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : (1 << (bd - 1))));
+        left_i = corner;
+    }
+    top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
+
+    if (__builtin_amdgcn_ballot_w64(act && (flags & OH_IF_FILTER)) != 0) {
+        /* smoothing (:288-326); never the strong filter here (32x32 only).  All lanes run the shifts, the flag selects. */
+        const int lp = row_shr1(left_i, corner), ln = row_shl1(left_i, 0);
+        const int tp = row_shr1(top_i, corner), tn = row_shl1(top_i, 0);
+        const int l0v = __shfl(left_i, base), t0v = __shfl(top_i, base);
+        if (flags & OH_IF_FILTER) {
+            if (i < 2 * n - 1) {
+                left_i = (ln + 2 * left_i + lp + 2) >> 2;
+                top_i  = (tn + 2 * top_i + tp + 2) >> 2;
+            }
+            corner = (l0v + 2 * corner + t0v + 2) >> 2;
+        }
+    }
+    int *E = edges + slot * 36;
+    const int LB = 1, TB = 18;                               /* left[k] = E[LB + k], top[k] = E[TB + k] */
+    if (act) {
+        E[LB + i] = left_i; E[TB + i] = top_i;               /* entries >= 2n are written too and never read */
+        if (sl == 0) { E[0] = corner; E[17] = corner; }
+    }
+    WSYNC();
+
+    const int g = sl, y = (4 * g) >> log2, x0 = (4 * g) & (n - 1);
+    const bool edge = flags & OH_IF_EDGE;
+    int v[4] = { 0, 0, 0, 0 };
+    /* the DC sum needs every lane of the slot: outside the per-group predicate (and skipped when no slot is DC) */
+    int dc = 0;
+    if (__builtin_amdgcn_ballot_w64(act && cls == OH_IC_DC) != 0) {
+        int part = i < n ? left_i + top_i : 0;
+        part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+        dc = (__shfl(part, base) + n) >> (log2 + 1);
+    }
+    if (work) {
+        if (cls == OH_IC_PLANAR) {
+            const int tn_ = E[TB + n], ln_ = E[LB + n], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                v[j] = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - y) * E[TB + x] + (y + 1) * ln_ + n) >> (log2 + 1);
+            }
+        } else if (cls == OH_IC_DC) {
+            const int l0_ = E[LB], t0_ = E[TB], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                int pv = dc;
+                if (edge) {
+                    if (x == 0 && y == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
+                    else if (y == 0)      pv = (E[TB + x] + 3 * dc + 2) >> 2;
+                    else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
+                }
+                v[j] = pv;
+            }
+        } else if (cls == OH_IC_PURE_V) {
+            const int t0_ = E[TB], lm1 = E[LB - 1], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = E[TB + x0 + j];
+            if (edge && x0 == 0) v[0] = clip_px(t0_ + ((ly_ - lm1) >> 1), bd);
+        } else if (cls == OH_IC_PURE_H) {
+            const int l0_ = E[LB], tm1 = E[TB - 1], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (edge && y == 0) ? clip_px(l0_ + ((E[TB + x0 + j] - tm1) >> 1), bd) : ly_;
+        } else if (cls == OH_IC_ANG_V) {
+            const int id = ((y + 1) * angle) >> 5, fact = ((y + 1) * angle) & 31;
+            int r[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int kk = x0 + j + id + 1;
+                r[j] = E[kk >= 0 ? TB + kk - 1 : LB - 1 + ((kk * inv_a + 128) >> 8)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = fact ? ((32 - fact) * r[j] + fact * r[j + 1] + 16) >> 5 : r[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const int id = ((x + 1) * angle) >> 5, fact = ((x + 1) * angle) & 31;
+                const int k0 = y + id + 1, k1 = k0 + 1;
+                const int r0 = E[k0 >= 0 ? LB + k0 - 1 : TB - 1 + ((k0 * inv_a + 128) >> 8)];
+                const int r1 = E[k1 >= 0 ? LB + k1 - 1 : TB - 1 + ((k1 * inv_a + 128) >> 8)];
+                v[j] = fact ? ((32 - fact) * r0 + fact * r1 + 16) >> 5 : r0;
+            }
+        }
+        if (res_off != OH_NO_COEFF) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[j], bd);
+        }
+        const int gstride = c ? pr.stride[1] : pr.stride[0];
+        GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) + (size_t)(by + y) * gstride + bx + x0;
+        put4<PX>(M + cm_off + y * rs + x0, dst, v[0], v[1], v[2], v[3]);
+    }
+    WSYNC();                                                 /* the wave's edge arrays are reused by its next pass */
+}
+
 template <typename PX, bool CIP, bool STAGED>
 __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
 {
@@ -902,6 +1046,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
     uint16_t *__restrict__ M = (uint16_t *)smem;                                  /* sample area, oh_ctu_areas() */
     DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
     uint32_t *__restrict__ sub = (uint32_t *)(smem + L.off_sub);
+    uint32_t *__restrict__ small = (uint32_t *)(smem + L.off_small);              /* per sub-level: leading blocks that go four per wave */
     int16_t *__restrict__ res_l = (int16_t *)(smem + L.off_res);                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     IntraLds &edges = *(IntraLds *)(smem + L.off_wave + wave * OH_INTRA_WAVE_LDS);
@@ -924,6 +1069,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
         uint4v *dst = (uint4v *)items;
         for (uint32_t e = tid; e < n_items * 2; e += nthr) dst[e] = src[e];
         for (int e = tid; e <= n_sub; e += nthr) sub[e] = ss[e] - item0;
+        for (int e = tid; e < n_sub; e += nthr) small[e] = G_CONST(uint32_t, f->sub_small)[ctu.sub_first + e];
         /* the CTU's residual blocks: one coalesced sweep instead of a dependent load per block */
         const GLOBAL short4v *__restrict__ rsrc = (const GLOBAL short4v *)(f->res + ctu.res_lo);
         if (STAGED)
@@ -965,9 +1111,16 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
 
     for (int s = 0; s < n_sub; s++) {
         STAMP(t0);
-        const uint32_t b1 = sub[s + 1];
-        for (uint32_t b = sub[s] + wave; b < b1; b += nwaves)
-            intra_block<PX, CIP, STAGED>(f, bd, pr, (const uint4v *)&items[b], edges, M, res_l, lane, acc);
+        /* units of the sub-level: groups of up to four <=8x8 blocks (one 16-lane slot each), then the bigger blocks one
+         * per wave; the slot path needs the residual staged in LDS and has no constrained-intra variant */
+        const uint32_t b0 = sub[s], b1 = sub[s + 1], ns = (STAGED && !CIP) ? min(small[s], b1 - b0) : 0u;
+        const uint32_t ngrp = (ns + 3) >> 2, nunits = ngrp + (b1 - b0 - ns);
+        for (uint32_t u = wave; u < nunits; u += nwaves) {
+            if (u < ngrp)
+                intra_slots<PX>(bd, pr, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), edges.E, M, res_l, lane);
+            else
+                intra_block<PX, CIP, STAGED>(f, bd, pr, (const uint4v *)&items[b0 + ns + (u - ngrp)], edges, M, res_l, lane, acc);
+        }
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
         STAMP(t2);

@@ -81,8 +81,24 @@ enum OhTuFlags {
     OH_TUF_ADD_NOW   = 1,  /* prediction already complete after pass 1 (inter CU): add in pass 2  */
     OH_TUF_RDPCM     = 2,  /* hevcdsp.transform_rdpcm after skip / on bypass                      */
     OH_TUF_RDPCM_VER = 4,  /* rdpcm mode 1 (vertical)                                             */
-    OH_TUF_ROTATE    = 8   /* transform_skip_rotation (4x4): coefficients reversed before skip    */
+    OH_TUF_ROTATE    = 8,  /* transform_skip_rotation (4x4): coefficients reversed before skip    */
+    OH_TUF_SPARSE    = 16  /* coefficients come as quantised (position, level) pairs, see OhFrame.sparse */
 };
+
+/* Sparse residual hand-off (the step upstream of the inverse transform): instead of a dense
+ * de-quantised N x N block the host passes what residual_coding parsed — the non-zero LEVELS — and de-quantisation
+ * (hevc_cabac.c:1478-1494, 1818-1841) runs on the GPU.  Record of one block in OhFrame.sparse (uint32 words):
+ *   word 0      n | qp << 16 | matrix_id << 24      n = number of pairs (<= N*N); qp = the block's final QP incl.
+ *                                                   qp_bd_offset (0..75); matrix_id 0..5 = 3*(!intra) + c_idx into
+ *                                                   OhFrame.scaling, OH_FLAT_MATRIX = flat 16 (also for
+ *                                                   transform-skipped blocks > 4x4, hevc_cabac.c:1485)
+ *   word 1..n   pos | (uint16_t)level << 16         pos = y*N + x
+ * Kinds: IDCT, DST4, SKIP (bypass and PCM blocks carry no quantised levels and stay dense). */
+#define OH_FLAT_MATRIX 0xffu
+typedef struct OhScalingList {    /* hevc.h:722-727 */
+    uint8_t sl[4][6][64];
+    uint8_t sl_dc[2][6];
+} OhScalingList;
 typedef struct OhTu {
     uint16_t x, y;                /* position in samples of plane c_idx                             */
     uint8_t  c_idx;               /* 0 Y, 1 Cb, 2 Cr                                                */
@@ -160,6 +176,10 @@ typedef struct OhFrame {
     const OhSaoCtb     *sao;          /* ctb_width x ctb_height, may be NULL when !sao_enabled    */
     const uint8_t      *is_intra;     /* min_pu_width x min_pu_height: 1 where the covering CU is intra (tab_mvf[].pred_flag ==
                                          PF_INTRA, incl. PCM CUs); required when constrained_intra_pred, else may be NULL */
+    /* sparse residual hand-off (OH_TUF_SPARSE blocks): all NULL / 0 when every block is dense */
+    uint32_t n_sparse;  const uint32_t *sparse;      /* records, uint32 words                                     */
+    const uint32_t     *tu_sparse;    /* per OhTu: word offset of its record in sparse[], OH_NO_COEFF for dense blocks */
+    const OhScalingList *scaling;     /* scaling lists in use (sps/pps), NULL when every block uses the flat matrix */
 } OhFrame;
 
 /* ---- derived geometry helpers (all integer, shared by every consumer) ---- */

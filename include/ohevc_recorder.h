@@ -43,6 +43,13 @@ int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int
 uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
                    const int16_t *coeffs);
 
+/* same block handed over as quantised levels (OH_TUF_SPARSE, ohevc_frame.h): pairs[i] = pos | (uint16_t)level << 16.
+ * The dense pool keeps a slot for the block (the residual lands there), its content is not read. */
+uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+                          int qp, int matrix_id, int n, const uint32_t *pairs);
+/* scaling lists of the picture (zeroed by oh_rec_create; only read when a block names a matrix) */
+OhScalingList *oh_rec_scaling_list(OhRecorder *r);
+
 /* intra block; tu = index returned by oh_rec_tu for the same block or OH_NO_COEFF.
  * Computes the block's dependency level from the levels of the neighbours it reads. */
 int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu);

@@ -36,7 +36,9 @@ typedef struct OhSynthParams {
     int32_t  pcm_pct;           /* % of CUs coded PCM (needs pcm_loop_filter_disable to matter)*/
     int32_t  bypass_pct;        /* % of CUs with cu_transquant_bypass (if enabled in params)   */
     int32_t  vary_deblock_offsets; /* 1: per-CTB beta/tc offsets differ (multi-slice quirks)   */
-    int32_t  reserved[8];
+    int32_t  sparse_pct;        /* % of transform blocks handed over as quantised levels (OH_TUF_SPARSE) */
+    int32_t  scaling_list;      /* 1: random scaling lists, blocks name their matrix            */
+    int32_t  reserved[6];
 } OhSynthParams;
 
 /* sensible defaults for a mid-QP picture of the given slice type */

@@ -94,6 +94,9 @@ struct DevIntraCtu {
                                      CTU reads (its row above and column to the left, up to 2n): what gets staged */
 };
 
+/* transform block as uploaded: OhTu plus the word offset of its sparse record (OH_TUF_SPARSE) */
+struct DevTu { OhTu t; uint32_t sparse_off; };     /* 16 bytes */
+
 struct DevFrame {
     OhPicParams pp;
     DevPlanes   cur;              /* reconstruction / deblock buffer of the current picture   */
@@ -103,9 +106,11 @@ struct DevFrame {
     const OhPu      *pu;
     const DevMcJob  *mc_luma, *mc_chroma;
     const OhWeights *wp;
-    const OhTu      *tu;              /* sorted by size: blocks of log2 size 2+k are tu[tu_first[k] .. +tu_cnt[k]) */
+    const DevTu     *tu;              /* sorted by size: blocks of log2 size 2+k are tu[tu_first[k] .. +tu_cnt[k]) */
     uint32_t        tu_first[4], tu_cnt[4];
     const int16_t   *coeffs;
+    const uint32_t  *sparse;          /* records of the OH_TUF_SPARSE blocks (ohevc_frame.h), may be null            */
+    const OhScalingList *scaling;     /* may be null: flat matrices only                                            */
     int16_t         *res;             /* residual pool (deferred adds of intra blocks)        */
     const DevIntra  *intra;
     const DevIntraCtu *ictu;          /* CTUs with intra blocks in wavefront order             */

@@ -510,6 +510,19 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
             FAIL(e, OH_E_ARG, "TU %u: position / coefficient offset not a multiple of 4", i);
         if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
             FAIL(e, OH_E_ARG, "TU %u: rotation is 4x4 only", i);
+        if (t.flags & OH_TUF_SPARSE) {
+            if (!f->sparse || !f->tu_sparse || t.kind == OH_TU_BYPASS || t.kind == OH_TU_PCM)
+                FAIL(e, OH_E_ARG, "TU %u: sparse block without records / of a kind that carries no levels", i);
+            const uint64_t so = f->tu_sparse[i];
+            if (so >= f->n_sparse)
+                FAIL(e, OH_E_ARG, "TU %u: sparse record outside the pool", i);
+            const uint32_t w0 = f->sparse[so], cnt = w0 & 0xffff, qp = (w0 >> 16) & 0xff, mid = w0 >> 24;
+            if (cnt > (uint32_t)(n * n) || so + 1 + cnt > f->n_sparse || qp > 75 || (mid != OH_FLAT_MATRIX && (mid > 5 || !f->scaling)))
+                FAIL(e, OH_E_ARG, "TU %u: bad sparse record (count / QP / matrix)", i);
+            for (uint32_t k = 0; k < cnt; k++)
+                if ((f->sparse[so + 1 + k] & 0xffff) >= (uint32_t)(n * n))
+                    FAIL(e, OH_E_ARG, "TU %u: sparse coefficient outside the block", i);
+        }
     }
     if (f->n_intra && p.constrained_intra_pred && !f->is_intra)
         FAIL(e, OH_E_ARG, "constrained_intra_pred without the is_intra map");
@@ -590,7 +603,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
 
     /* arena layout: [DevFrame][pu][mc jobs][wp][tu][intra][vbs][hbs][qp][is_pcm][db][sao][coeffs] | [res] */
     struct Seg { const void *src; size_t bytes, off; };
-    Seg seg[20];
+    Seg seg[24];
     int ns = 0;
     size_t total = 0;
     auto add = [&](const void *src, size_t bytes) {
@@ -606,15 +619,23 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_mcc = add(mc_chroma.data(), mc_chroma.size() * sizeof(DevMcJob));
     int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
     /* transform blocks sorted by size (stable): the residual pass runs one launch per size */
-    std::vector<OhTu> tu_sorted(f->n_tu);
+    std::vector<DevTu> tu_sorted(f->n_tu);
+    bool any_dense = false;
     uint32_t tu_first[4] = { 0, 0, 0, 0 }, tu_cnt[4] = { 0, 0, 0, 0 };
     for (uint32_t i = 0; i < f->n_tu; i++) tu_cnt[f->tu[i].log2_size - 2]++;
     for (int k = 1; k < 4; k++) tu_first[k] = tu_first[k - 1] + tu_cnt[k - 1];
     {
         uint32_t cur_[4] = { tu_first[0], tu_first[1], tu_first[2], tu_first[3] };
-        for (uint32_t i = 0; i < f->n_tu; i++) tu_sorted[cur_[f->tu[i].log2_size - 2]++] = f->tu[i];
+        for (uint32_t i = 0; i < f->n_tu; i++) {
+            DevTu &d = tu_sorted[cur_[f->tu[i].log2_size - 2]++];
+            d.t = f->tu[i];
+            d.sparse_off = (f->tu[i].flags & OH_TUF_SPARSE) ? f->tu_sparse[i] : OH_NO_COEFF;
+            any_dense = any_dense || !(f->tu[i].flags & OH_TUF_SPARSE);
+        }
     }
-    int s_tu = add(tu_sorted.data(), tu_sorted.size() * sizeof(OhTu));
+    int s_tu = add(tu_sorted.data(), tu_sorted.size() * sizeof(DevTu));
+    int s_sparse = add(f->sparse, (size_t)(f->sparse ? f->n_sparse : 0) * sizeof(uint32_t));
+    int s_scaling = add(f->scaling, f->scaling ? sizeof(OhScalingList) : 0);
     /* intra block descriptors: everything that depends only on geometry and mode is resolved here */
     static const int8_t k_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
                                         -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };      /* hevcpred_template.c:430-433 */
@@ -772,7 +793,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_db = add(has_db ? f->deblock : nullptr, has_db ? n_ctb * sizeof(OhDeblockCtb) : 0);
     int s_sao = add(has_sao ? f->sao : nullptr, has_sao ? n_ctb * sizeof(OhSaoCtb) : 0);
     int s_coef = add(f->coeffs, (size_t)f->n_coeff * sizeof(int16_t));
-    const size_t copy_bytes = total;
+    /* the dense pool is the last uploaded segment: when every block came as levels nothing of it crosses PCIe */
+    const size_t copy_bytes = any_dense || !f->n_tu ? total : seg[s_coef].off;
     const size_t res_off = total;
     total += align_up((size_t)(f->n_coeff ? f->n_coeff : 1) * sizeof(int16_t), 256);
 
@@ -794,7 +816,9 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.mc_luma = (const DevMcJob *)(base + seg[s_mcl].off);
     hd.mc_chroma = (const DevMcJob *)(base + seg[s_mcc].off);
     hd.wp = (const OhWeights *)(base + seg[s_wp].off);
-    hd.tu = (const OhTu *)(base + seg[s_tu].off);
+    hd.tu = (const DevTu *)(base + seg[s_tu].off);
+    hd.sparse = f->sparse ? (const uint32_t *)(base + seg[s_sparse].off) : nullptr;
+    hd.scaling = f->scaling ? (const OhScalingList *)(base + seg[s_scaling].off) : nullptr;
     hd.coeffs = (const int16_t *)(base + seg[s_coef].off);
     hd.res = (int16_t *)(base + res_off);
     hd.intra = (const DevIntra *)(base + seg[s_intra].off);
@@ -820,7 +844,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
     }
     for (int i = 0; i < ns; i++)
-        if (seg[i].bytes && seg[i].src)
+        if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
             memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
     hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, e->stream);
     if (hrc == hipSuccess)

@@ -20,6 +20,7 @@
 
 /* ---- constant tables (H.265 facts; same numbers as hevcdsp.c:879-944,1028-1042, hevcpred_template.c:430-437,
  *      hevc_filter.c:50-60); the interpolation taps live in ohk_init(), which packs them for mc_kernel ---- */
+__constant__ uint8_t c_level_scale[6] = { 40, 45, 51, 57, 64, 72 };        /* hevc_cabac.c:1417 */
 __constant__ int8_t  c_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
                                      -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
 __constant__ int16_t c_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
@@ -367,7 +368,9 @@ __global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
         return;
     const int lane = threadIdx.x, slot = lane / LPS, sl = lane % LPS;
     const bool live = t0 + slot < cnt;                            /* a dead slot repeats the wave's first block and stores nothing */
-    const OhTu tu = gload(f->tu + f->tu_first[LOG2 - 2] + t0 + (live ? slot : 0));
+    const DevTu dtu = gload(f->tu + f->tu_first[LOG2 - 2] + t0 + (live ? slot : 0));
+    const OhTu tu = dtu.t;
+    const bool sparse = tu.flags & OH_TUF_SPARSE;
     const int bd = f->pp.bit_depth;
     const bool is_tr = tu.kind == OH_TU_IDCT || tu.kind == OH_TU_DST4;
     const bool to_pic = tu.kind == OH_TU_PCM || (tu.flags & OH_TUF_ADD_NOW);
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int g = sl + 64 * k;
-        cv[k] = cin[g];
+        cv[k] = sparse ? short4v{ 0, 0, 0, 0 } : cin[g];
         if (add) load4<PX>(dst + (size_t)((4 * g) >> LOG2) * ds + ((4 * g) & (N - 1)), pv[k]);
     }
     {
@@ -396,18 +399,48 @@ __global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
     }
     /* LDS: coefficients; for the big sizes the bounding box of the non-zero coefficients (zero rows /
      * columns contribute nothing: what the reference's col_limit exploits, hevc_cabac.c:1927-1934) */
-    int my_r = 0, my_c = 0;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int g = sl + 64 * k;
-        *(short4v *)(a[slot] + 4 * g) = cv[k];
-        if (LOG2 >= 4) {
+    for (int k = 0; k < K; k++)
+        *(short4v *)(a[slot] + 4 * (sl + 64 * k)) = cv[k];
+    __syncthreads();
+    /* sparse hand-off (ohevc_frame.h): the block arrived as quantised levels; de-quantise (hevc_cabac.c:1478-1494,
+     * 1818-1841: level * scale * scale_m + add >> shift, clipped to int16) and scatter them into the zeroed block */
+    if (__builtin_amdgcn_ballot_w64(sparse) != 0) {
+        if (sparse) {
+            const GLOBAL uint32_t *__restrict__ rec = G_CONST(uint32_t, f->sparse) + dtu.sparse_off;
+            const uint32_t w0 = rec[0], cnt = w0 & 0xffff, qp = (w0 >> 16) & 0xff, mid = w0 >> 24;
+            const int shift = bd + LOG2 - 5;
+            const long long radd = 1ll << (shift - 1), scale = (long long)c_level_scale[qp % 6] << (qp / 6);
+            const bool flat = mid == OH_FLAT_MATRIX;
+            const GLOBAL uint8_t *__restrict__ mtx = flat ? nullptr : G_CONST(uint8_t, f->scaling->sl[LOG2 - 2][flat ? 0 : mid]);
+            const int dc_scale = !flat && LOG2 >= 4 ? G_CONST(uint8_t, f->scaling->sl_dc[LOG2 >= 4 ? LOG2 - 4 : 0])[mid] : 16;
+            for (uint32_t k = sl; k < cnt; k += LPS) {
+                const uint32_t w = rec[1 + k], pos = w & 0xffff;
+                const int x = pos & (N - 1), y = pos >> LOG2;
+                int scale_m = 16;
+                if (!flat)
+                    scale_m = (x || y || LOG2 < 4) ? mtx[LOG2 == 3 ? (y << 3) + x : LOG2 == 4 ? ((y >> 1) << 3) + (x >> 1) : LOG2 == 5 ? ((y >> 2) << 3) + (x >> 2) : (y << 2) + x]
+                                                    : dc_scale;
+                long long v = ((long long)(int16_t)(w >> 16) * scale * scale_m + radd) >> shift;
+                a[slot][pos] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+            }
+        }
+        __syncthreads();
+        if (sparse) {
+#pragma unroll
+            for (int k = 0; k < K; k++) cv[k] = *(const short4v *)(a[slot] + 4 * (sl + 64 * k));
+        }
+    }
+    int my_r = 0, my_c = 0;
+    if (LOG2 >= 4) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int g = sl + 64 * k;
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (cv[k][j]) { my_r = max(my_r, (4 * g) >> LOG2); my_c = max(my_c, ((4 * g) & (N - 1)) + j); }
         }
     }
-    __syncthreads();
     int nr = N, nc = N;
     if (LOG2 >= 4) {
         if (my_r) atomicMax(&bbox[0], my_r);

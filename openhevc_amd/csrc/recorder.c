@@ -39,6 +39,8 @@ struct OhRecorder {
     uint32_t  *level_start;
     /* side arrays */
     uint8_t *vbs, *hbs, *is_pcm, *is_intra;
+    uint32_t *sparse, *tu_sparse; uint64_t cap_sparse, cap_tu_sparse; int any_sparse, any_matrix;
+    OhScalingList scaling;
     int8_t  *qp;
     OhDeblockCtb *deblock;
     OhSaoCtb *sao;
@@ -103,7 +105,7 @@ void oh_rec_destroy(OhRecorder *r)
     free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->it_ctu); free(r->it_sub);
     free(r->sorted); free(r->ctu_dep); free(r->ctu_nsub); free(r->ctu_level); free(r->ctu_entry); free(r->ictu);
     free(r->sub_start); free(r->level_start);
-    free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->qp); free(r->deblock); free(r->sao);
+    free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->sparse); free(r->tu_sparse); free(r->qp); free(r->deblock); free(r->sao);
     for (int c = 0; c < 3; c++)
         free(r->lvl[c]);
     free(r->decoded);
@@ -117,6 +119,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     for (int i = 0; i < OH_MAX_REFS; i++)
         r->f.ref_pics[i] = i < n_ref_pics ? ref_pics[i] : -1;
     r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = r->f.n_ictu = r->f.n_sub = 0;
+    r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0;
     r->f.n_coeff = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
@@ -169,8 +172,35 @@ uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int ki
     it->coeff_off = (uint32_t)r->f.n_coeff;
     memcpy(r->coeffs + r->f.n_coeff, coeffs, n2 * sizeof(int16_t));
     r->f.n_coeff += n2;
+    r->tu_sparse = (uint32_t *)grow(r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
+    r->tu_sparse[r->f.n_tu] = OH_NO_COEFF;
     return r->f.n_tu++;
 }
+
+uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+                          int qp, int matrix_id, int n, const uint32_t *pairs)
+{
+    uint32_t n2 = 1u << (2 * log2_size);
+    GROW32(r->tu, r->cap_tu, (uint64_t)r->f.n_tu + 1);
+    r->coeffs = (int16_t *)grow(r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
+    r->tu_sparse = (uint32_t *)grow(r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
+    r->sparse = (uint32_t *)grow(r->sparse, sizeof(uint32_t), &r->cap_sparse, (uint64_t)r->f.n_sparse + 1 + (uint64_t)n);
+    OhTu *it = &r->tu[r->f.n_tu];
+    it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
+    it->kind = (uint8_t)kind; it->flags = (uint8_t)(flags | OH_TUF_SPARSE);
+    it->coeff_off = (uint32_t)r->f.n_coeff;
+    memset(r->coeffs + r->f.n_coeff, 0, n2 * sizeof(int16_t));
+    r->f.n_coeff += n2;
+    r->tu_sparse[r->f.n_tu] = r->f.n_sparse;
+    r->sparse[r->f.n_sparse] = (uint32_t)n | ((uint32_t)(qp & 0xff) << 16) | ((uint32_t)(matrix_id & 0xff) << 24);
+    memcpy(r->sparse + r->f.n_sparse + 1, pairs, sizeof(uint32_t) * (size_t)n);
+    r->f.n_sparse += 1 + (uint32_t)n;
+    r->any_sparse = 1;
+    if ((matrix_id & 0xff) != OH_FLAT_MATRIX) r->any_matrix = 1;
+    return r->f.n_tu++;
+}
+
+OhScalingList *oh_rec_scaling_list(OhRecorder *r) { return &r->scaling; }
 
 /* one neighbour cell (plane c, sample position x,y) read by a block of CTU (cx,cy) */
 static inline void visit(OhRecorder *r, int c, int x, int y, int cx, int cy, unsigned *sub, unsigned *dep)
@@ -325,6 +355,9 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     f->vertical_bs = r->vbs; f->horizontal_bs = r->hbs; f->qp_y_tab = r->qp;
     f->is_pcm = (f->p.pcm_loop_filter_disable || f->p.transquant_bypass_enable) ? r->is_pcm : NULL;
     f->is_intra = f->p.constrained_intra_pred ? r->is_intra : NULL;
+    f->sparse = r->any_sparse ? r->sparse : NULL;
+    f->tu_sparse = r->any_sparse ? r->tu_sparse : NULL;
+    f->scaling = r->any_matrix ? &r->scaling : NULL;
     f->deblock = r->deblock;
     f->sao = f->p.sao_enabled ? r->sao : NULL;
     return f;

@@ -165,8 +165,30 @@ static void emit_tb(Gen *g, const CuInfo *cu, int c_idx, int xl, int yl, int log
     if (cbf) {
         int kind = pick_kind(g, cu, c_idx, log2);
         int flags = pick_flags(g, cu, kind);
-        gen_coeffs(g, log2, kind);
-        tu = oh_rec_tu(g->rec, c_idx, x, y, log2, kind, flags, g->blk);
+        if (kind != OH_TU_BYPASS && kind != OH_TU_PCM && g->sp->sparse_pct > 0 && pct(g, g->sp->sparse_pct)) {   /* no draw when off: the
+                                                                   dense streams of the golden fixtures stay what they were */
+            /* what residual_coding parses: a few non-zero levels, the block's QP, its scaling matrix (hevc_cabac.c:1478-1494) */
+            uint32_t pairs[1024];
+            int n = 1 << log2, shape = rnd(g, 10), cnt = 0;
+            int nz = shape < 3 ? 1 : 1 + rnd(g, shape < 8 ? (n * n / 8 > 1 ? n * n / 8 : 2) : n * n / 2);
+            int lim = shape < 8 ? (n > 8 ? n / 2 : n) : n;
+            memset(g->blk, 0, sizeof(int16_t) * (size_t)(n * n));        /* marks the positions already taken */
+            for (int i = 0; i < nz; i++) {
+                int px = shape < 3 ? 0 : rnd(g, lim), py = shape < 3 ? 0 : rnd(g, lim);
+                int lvl = clipi(laplace(g, px + py == 0 ? 60 : 12), -32768, 32767);
+                if (!lvl) lvl = 1;
+                if (rnd(g, 60) == 0) lvl = rnd(g, 2) ? 32767 : -32768;                  /* rare saturating level */
+                if (g->blk[py * n + px]) continue;
+                g->blk[py * n + px] = 1;
+                pairs[cnt++] = (uint32_t)(py * n + px) | ((uint32_t)(uint16_t)(int16_t)lvl << 16);
+            }
+            int qp = clipi(g->sp->qp_base + rnd_range(g, -g->sp->qp_var, g->sp->qp_var), 0, 51) + 6 * (g->p.bit_depth - 8);
+            int matrix = (g->sp->scaling_list && !(kind == OH_TU_SKIP && log2 > 2)) ? 3 * !cu->intra + c_idx : (int)OH_FLAT_MATRIX;
+            tu = oh_rec_tu_sparse(g->rec, c_idx, x, y, log2, kind, flags, qp, matrix, cnt, pairs);
+        } else {
+            gen_coeffs(g, log2, kind);
+            tu = oh_rec_tu(g->rec, c_idx, x, y, log2, kind, flags, g->blk);
+        }
     }
     if (cu->intra)
         oh_rec_intra(g->rec, c_idx, x, y, log2, mode, avail, tu);
@@ -453,6 +475,11 @@ const OhFrame *oh_synth_picture(OhRecorder *rec, const OhSynthParams *sp, int cu
     g.qp = oh_rec_qp_y_tab(rec);
     g.is_pcm = oh_rec_is_pcm(rec);
     g.is_intra = oh_rec_is_intra(rec);
+    if (sp->scaling_list) {                              /* any legal list: entries 1..255 */
+        OhScalingList *sl = oh_rec_scaling_list(rec);
+        for (size_t i = 0; i < sizeof(sl->sl); i++) ((uint8_t *)sl->sl)[i] = (uint8_t)(1 + rnd(&g, 64 + (int)(i & 63)));
+        for (size_t i = 0; i < sizeof(sl->sl_dc); i++) ((uint8_t *)sl->sl_dc)[i] = (uint8_t)(1 + rnd(&g, 200));
+    }
     memset(g.qp, sp->qp_base, oh_qp_tab_size(&g.p));
 
     int ctb = 1 << g.p.log2_ctb_size;

@@ -352,6 +352,34 @@ int oh_or_pass_inter(const OhFrame *f, OhHostPic *pics)
 }
 
 /* ---- pass 2: residual (hevc_cabac.c:1868-1949) ---- */
+/* ---- sparse hand-off: de-quantisation of the parsed levels into the dense block, hevc_cabac.c:1478-1494 (scale, shift,
+ * matrix choice) and :1818-1841 (per coefficient).  PARITY UNPINNED for this function: the reference statements sit
+ * inside ff_hevc_hls_residual_coding between CABAC reads and cannot be called on their own; restated from the text. ---- */
+static void tu_dequant(const OhFrame *f, const OhTu *tu, const uint32_t *rec, int16_t *c)
+{
+    static const uint8_t level_scale[6] = { 40, 45, 51, 57, 64, 72 };
+    const int log2 = tu->log2_size, n = 1 << log2, cnt = (int)(rec[0] & 0xffff), qp = (int)((rec[0] >> 16) & 0xff);
+    const unsigned matrix = rec[0] >> 24;
+    const int shift = f->p.bit_depth + log2 - 5;            /* + 10 - log2_transform_range, the range being 15 (:1416) */
+    const int64_t add = (int64_t)1 << (shift - 1), scale = (int64_t)level_scale[qp % 6] << (qp / 6);
+    const uint8_t *m = matrix != OH_FLAT_MATRIX && f->scaling ? f->scaling->sl[log2 - 2][matrix] : NULL;
+    const int dc_scale = m && log2 >= 4 ? f->scaling->sl_dc[log2 - 4][matrix] : (m ? -1 : 16);
+    memset(c, 0, sizeof(int16_t) * (size_t)(n * n));
+    for (int i = 0; i < cnt; i++) {
+        const int pos = (int)(rec[1 + i] & 0xffff), x = pos & (n - 1), y = pos >> log2;
+        int64_t v = (int16_t)(rec[1 + i] >> 16);
+        int scale_m = 16;
+        if (m) {
+            if (x || y || log2 < 4)
+                scale_m = m[log2 == 3 ? (y << 3) + x : log2 == 4 ? ((y >> 1) << 3) + (x >> 1) : log2 == 5 ? ((y >> 2) << 3) + (x >> 2) : (y << 2) + x];
+            else
+                scale_m = dc_scale;
+        }
+        v = (v * scale * scale_m + add) >> shift;
+        c[pos] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+    }
+}
+
 static void tu_inverse(int bd, const OhTu *tu, int16_t *c)
 {
     int log2 = tu->log2_size;
@@ -394,6 +422,8 @@ int oh_or_pass_residual(const OhFrame *f, OhHostPic *pics, int16_t *coeffs)
     for (uint32_t i = 0; i < f->n_tu; i++) {
         const OhTu *tu = &f->tu[i];
         int16_t *c = coeffs + tu->coeff_off;
+        if ((tu->flags & OH_TUF_SPARSE) && f->tu_sparse && f->tu_sparse[i] != OH_NO_COEFF)
+            tu_dequant(f, tu, f->sparse + f->tu_sparse[i], c);
         tu_inverse(f->p.bit_depth, tu, c);
         if (tu->flags & OH_TUF_ADD_NOW)
             tu_store(f, cur, tu, c);

@@ -77,6 +77,10 @@ CASES = [
     ("b10_cip_pcm", 200, 136, 10, 1, 5, 2, {"intra_pct": 60, "pcm_pct": 10, "split_pct": 70}),
     ("b8_444_cip", 136, 88, 8, 3, 5, 2, {"intra_pct": 40}),
     ("b10_422_cip", 200, 136, 10, 2, 6, 2, {"intra_pct": 50}),
+    # sparse residual hand-off: quantised levels + QP (+ scaling lists), de-quantised on the GPU (hevc_cabac.c:1478-1494, 1818-1841)
+    ("b8_sparse", 416, 240, 8, 1, 6, 2, {"sparse_pct": 70}),
+    ("b10_sparse_lists", 264, 200, 10, 1, 5, 2, {"sparse_pct": 100, "scaling_list": 1, "tskip_pct": 25, "intra_pct": 30}),
+    ("i12_444_sparse_lists", 136, 88, 12, 3, 5, 0, {"sparse_pct": 100, "scaling_list": 1}),
 ]
 
 
@@ -201,6 +205,24 @@ def test_malformed_work_lists_fail_on_the_host(eng):
     with pytest.raises(EngineError):
         eng.frame_submit(bad)
     eng.frame_submit(good)
+    eng.sync()
+    # sparse records: a position outside the block, a matrix without scaling lists, a record running out of the pool
+    fs = rec.synth(F.synth_params(2, 4, sparse_pct=100), 2, [0, 1])
+    words = np.ctypeslib.as_array(fs.sparse, shape=(int(fs.n_sparse),)).copy()
+    first = int(fs.tu_sparse[0])
+    for mutate in ("position", "matrix", "count"):
+        w = words.copy()
+        if mutate == "position":
+            w[first + 1] = (w[first + 1] & 0xffff0000) | 0x7fff
+        elif mutate == "matrix":
+            w[first] = (w[first] & 0x00ffffff) | (2 << 24)
+        else:
+            w[first] = (w[first] & 0xffff0000) | 0xffff
+        bad = remap_frame(fs, ids)
+        bad.sparse = w.ctypes.data_as(C.POINTER(C.c_uint32))
+        with pytest.raises(EngineError):
+            eng.frame_submit(bad)
+    eng.frame_submit(remap_frame(fs, ids))
     eng.sync()
     for v in ids.values():
         eng.pic_free(v)
@@ -337,7 +359,8 @@ def test_random_configurations(eng):
                      cbf_pct=int(rng.integers(10, 100)), weighted_pct=int(rng.choice([0, 0, 30, 100])),
                      split_pct=int(rng.integers(10, 90)), tskip_pct=int(rng.choice([0, 0, 30])),
                      pcm_pct=int(rng.choice([0, 15])) if pcm else 0, bypass_pct=int(rng.choice([0, 15])) if byp else 0,
-                     sao_pct=int(rng.integers(0, 101)), vary_deblock_offsets=int(rng.integers(0, 2)))
+                     sao_pct=int(rng.integers(0, 101)), vary_deblock_offsets=int(rng.integers(0, 2)),
+                     sparse_pct=int(rng.choice([0, 0, 50, 100])), scaling_list=int(rng.integers(0, 2)))
         rec = F.Recorder(p)
         f = rec.synth(F.synth_params(st, 555000 + it, **knobs), 2, [0, 1] if st else [])
         prng = np.random.default_rng(it)

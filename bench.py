@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
+    ap.add_argument("--sparse-pct", type=int, default=0, help="%% of transform blocks handed over as quantised levels (de-quantised on the GPU) instead of dense coefficients")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
     args = ap.parse_args()
@@ -120,7 +121,7 @@ def main():
             g.append((stream, Engine(local_rank, stream=stream.cuda_stream), dist.new_group() if world > 1 else None))
         stream, engine, group = g[0]
         with torch.cuda.stream(stream):
-            be_k = P.EngineBackend(torch, local_rank, params, plan_k, engine=engine)
+            be_k = P.EngineBackend(torch, local_rank, params, plan_k, knobs=dict(sparse_pct=args.sparse_pct), engine=engine)
         g.append((plan_k, be_k, group))
         chains.append((plan_k, be_k, stream, group))
     engines = [g[0][1] for g in groups]
@@ -215,7 +216,7 @@ def main():
                             algorithmic_bytes_per_launch=round(abytes[dom] * steps_timed / n_launch_total, 1),
                             pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
                             pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms})
-        knobs = P.default_synth_knobs()
+        knobs = dict(P.default_synth_knobs(), sparse_pct=args.sparse_pct)
         out = {
             "metric": "decoded Mpixels/s (luma), synthetic stream, bit-exact vs reference-pinned oracle",
             "value": round(value, 2), "unit": "Mpixels/s", "fps": round(total_pics / dt, 2),

@@ -18,20 +18,15 @@
 #include "dev_frame.h"
 #include "kernels.h"
 
-/* ---- constant tables (H.265 facts; same numbers as hevcdsp.c:879-944,1028-1042, hevcpred_template.c:430-437,
- *      hevc_filter.c:50-60); the interpolation taps live in ohk_init(), which packs them for mc_kernel ---- */
+/* ---- constant tables (H.265 facts; same numbers as hevc_filter.c:50-60, hevc_cabac.c:1417).  The interpolation taps and
+ *      the transform bases are packed by ohk_init() (g_mctab, g_basis); the intra angles are resolved per block on the
+ *      host (engine.hip, DevIntra) ---- */
 __constant__ uint8_t c_level_scale[6] = { 40, 45, 51, 57, 64, 72 };        /* hevc_cabac.c:1417 */
-__constant__ int8_t  c_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
-                                     -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
-__constant__ int16_t c_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
 __constant__ uint8_t c_tc[54] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
                                   5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
 __constant__ uint8_t c_beta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
                                     26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
 __constant__ uint8_t c_qpc[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
-__constant__ int8_t  c_dst7[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
-/* 32-point inverse DCT basis, filled by ohk_init() from the folded cosine table */
-__device__ int8_t g_dct[32][32];
 
 /* Pointers read out of DevFrame are generic to the compiler, which then emits flat_* accesses;
  * those count on lgkmcnt as well as vmcnt, so every LDS wait would also wait for stores in flight.
@@ -1613,7 +1608,7 @@ extern "C" int ohk_init(void)
     for (const void *k : intra_kernels)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
             return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_dct), m, sizeof(m)) == hipSuccess ? 0 : -1;
+    return 0;
 }
 
 /* =========================================================================================

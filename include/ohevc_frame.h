@@ -82,7 +82,10 @@ enum OhTuFlags {
     OH_TUF_RDPCM     = 2,  /* hevcdsp.transform_rdpcm after skip / on bypass                      */
     OH_TUF_RDPCM_VER = 4,  /* rdpcm mode 1 (vertical)                                             */
     OH_TUF_ROTATE    = 8,  /* transform_skip_rotation (4x4): coefficients reversed before skip    */
-    OH_TUF_SPARSE    = 16  /* coefficients come as quantised (position, level) pairs, see OhFrame.sparse */
+    OH_TUF_SPARSE    = 16, /* coefficients come as quantised (position, level) pairs, see OhFrame.sparse */
+    OH_TUF_CROSS     = 32, /* chroma block with cross-component prediction (4:4:4 range extension, hevc.c:1319-1365,
+                              hevc_cabac.c:1942-1947): residual += (res_scale_val * luma residual) >> 3, see OhFrame.tu_cross */
+    OH_TUF_KEEP_RES  = 64  /* luma block whose residual a OH_TUF_CROSS block reads: kept in the residual pool even when added at once */
 };
 
 /* Sparse residual hand-off (the step upstream of the inverse transform): instead of a dense
@@ -180,6 +183,9 @@ typedef struct OhFrame {
     uint32_t n_sparse;  const uint32_t *sparse;      /* records, uint32 words                                     */
     const uint32_t     *tu_sparse;    /* per OhTu: word offset of its record in sparse[], OH_NO_COEFF for dense blocks */
     const OhScalingList *scaling;     /* scaling lists in use (sps/pps), NULL when every block uses the flat matrix */
+    /* cross-component prediction: per OhTu, for OH_TUF_CROSS blocks `luma TU index | (res_scale_val & 0xff) << 24`
+     * (res_scale_val = +-1, 2, 4, 8 as a signed byte), OH_NO_COEFF otherwise; NULL when the picture has none */
+    const uint32_t     *tu_cross;
 } OhFrame;
 
 /* ---- derived geometry helpers (all integer, shared by every consumer) ---- */

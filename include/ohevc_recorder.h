@@ -47,6 +47,9 @@ uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int ki
  * The dense pool keeps a slot for the block (the residual lands there), its content is not read. */
 uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
                           int qp, int matrix_id, int n, const uint32_t *pairs);
+/* cross-component prediction (hevc.c:1319-1365): chroma block tu_c (index from oh_rec_tu*, recorded with its own coefficients
+ * or, when cbf is 0, as an OH_TU_BYPASS block of zeros) takes (res_scale_val * residual of luma block tu_y) >> 3 on top */
+int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val);
 /* scaling lists of the picture (zeroed by oh_rec_create; only read when a block names a matrix) */
 OhScalingList *oh_rec_scaling_list(OhRecorder *r);
 

@@ -38,7 +38,8 @@ typedef struct OhSynthParams {
     int32_t  vary_deblock_offsets; /* 1: per-CTB beta/tc offsets differ (multi-slice quirks)   */
     int32_t  sparse_pct;        /* % of transform blocks handed over as quantised levels (OH_TUF_SPARSE) */
     int32_t  scaling_list;      /* 1: random scaling lists, blocks name their matrix            */
-    int32_t  reserved[6];
+    int32_t  ccp_pct;           /* 4:4:4 only: % of transform units with cross-component prediction */
+    int32_t  reserved[5];
 } OhSynthParams;
 
 /* sensible defaults for a mid-QP picture of the given slice type */

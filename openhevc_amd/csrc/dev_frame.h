@@ -97,6 +97,9 @@ struct DevIntraCtu {
 /* transform block as uploaded: OhTu plus the word offset of its sparse record (OH_TUF_SPARSE) */
 struct DevTu { OhTu t; uint32_t sparse_off; };     /* 16 bytes */
 
+/* cross-component prediction of one chroma block (OH_TUF_CROSS): residual_c += (scale * residual_y) >> 3 */
+struct DevCross { uint16_t x, y; uint8_t c_idx, log2_size, flags; int8_t scale; uint32_t res_c, res_y; };    /* 16 bytes */
+
 struct DevFrame {
     OhPicParams pp;
     DevPlanes   cur;              /* reconstruction / deblock buffer of the current picture   */
@@ -110,6 +113,8 @@ struct DevFrame {
     uint32_t        tu_first[4], tu_cnt[4];
     const int16_t   *coeffs;
     const uint32_t  *sparse;          /* records of the OH_TUF_SPARSE blocks (ohevc_frame.h), may be null            */
+    const DevCross  *cross;           /* cross-component prediction blocks, n_cross of them                          */
+    uint32_t        n_cross;
     const OhScalingList *scaling;     /* may be null: flat matrices only                                            */
     int16_t         *res;             /* residual pool (deferred adds of intra blocks)        */
     const DevIntra  *intra;

@@ -38,6 +38,7 @@ struct OhDevFrame {
     OhPicParams p{};
     uint32_t   n_mc_luma = 0, n_mc_chroma = 0, n_tu = 0, n_intra = 0;
     uint32_t   tu_cnt[4] = { 0, 0, 0, 0 };
+    uint32_t   n_cross = 0;
     bool       has_sao = false;
     int        cur_pic = -1;      /* engine id of the picture the list reconstructs */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
@@ -510,6 +511,12 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
             FAIL(e, OH_E_ARG, "TU %u: position / coefficient offset not a multiple of 4", i);
         if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
             FAIL(e, OH_E_ARG, "TU %u: rotation is 4x4 only", i);
+        if (t.flags & OH_TUF_CROSS) {
+            const uint32_t cw = f->tu_cross ? f->tu_cross[i] : OH_NO_COEFF, ty = cw & 0xffffff;
+            if (cw == OH_NO_COEFF || p.chroma_format_idc != 3 || t.c_idx == 0 || ty >= f->n_tu || f->tu[ty].c_idx != 0 ||
+                f->tu[ty].log2_size != t.log2_size || t.kind == OH_TU_PCM)
+                FAIL(e, OH_E_ARG, "TU %u: bad cross-component prediction link", i);
+        }
         if (t.flags & OH_TUF_SPARSE) {
             if (!f->sparse || !f->tu_sparse || t.kind == OH_TU_BYPASS || t.kind == OH_TU_PCM)
                 FAIL(e, OH_E_ARG, "TU %u: sparse block without records / of a kind that carries no levels", i);
@@ -603,7 +610,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
 
     /* arena layout: [DevFrame][pu][mc jobs][wp][tu][intra][vbs][hbs][qp][is_pcm][db][sao][coeffs] | [res] */
     struct Seg { const void *src; size_t bytes, off; };
-    Seg seg[24];
+    Seg seg[26];
     int ns = 0;
     size_t total = 0;
     auto add = [&](const void *src, size_t bytes) {
@@ -621,6 +628,10 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     /* transform blocks sorted by size (stable): the residual pass runs one launch per size */
     std::vector<DevTu> tu_sorted(f->n_tu);
     bool any_dense = false;
+    std::vector<uint8_t> keep_res(f->tu_cross ? f->n_tu : 0, 0);      /* luma blocks a cross-component block reads */
+    for (uint32_t i = 0; i < f->n_tu && f->tu_cross; i++)
+        if (f->tu[i].flags & OH_TUF_CROSS)
+            keep_res[f->tu_cross[i] & 0xffffff] = 1;
     uint32_t tu_first[4] = { 0, 0, 0, 0 }, tu_cnt[4] = { 0, 0, 0, 0 };
     for (uint32_t i = 0; i < f->n_tu; i++) tu_cnt[f->tu[i].log2_size - 2]++;
     for (int k = 1; k < 4; k++) tu_first[k] = tu_first[k - 1] + tu_cnt[k - 1];
@@ -629,11 +640,25 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         for (uint32_t i = 0; i < f->n_tu; i++) {
             DevTu &d = tu_sorted[cur_[f->tu[i].log2_size - 2]++];
             d.t = f->tu[i];
+            if (!keep_res.empty() && keep_res[i]) d.t.flags |= OH_TUF_KEEP_RES;
             d.sparse_off = (f->tu[i].flags & OH_TUF_SPARSE) ? f->tu_sparse[i] : OH_NO_COEFF;
             any_dense = any_dense || !(f->tu[i].flags & OH_TUF_SPARSE);
         }
     }
+    /* cross-component prediction: the luma blocks it reads keep their residual, the chroma blocks are finished by a
+     * second launch (ohk_cross) once every inverse transform of the picture is done */
+    std::vector<DevCross> cross;
+    if (f->tu_cross)
+        for (uint32_t i = 0; i < f->n_tu; i++)
+            if (f->tu[i].flags & OH_TUF_CROSS) {
+                const OhTu &t = f->tu[i], &ty = f->tu[f->tu_cross[i] & 0xffffff];
+                DevCross d;
+                d.x = t.x; d.y = t.y; d.c_idx = t.c_idx; d.log2_size = t.log2_size; d.flags = t.flags;
+                d.scale = (int8_t)(f->tu_cross[i] >> 24); d.res_c = t.coeff_off; d.res_y = ty.coeff_off;
+                cross.push_back(d);
+            }
     int s_tu = add(tu_sorted.data(), tu_sorted.size() * sizeof(DevTu));
+    int s_cross = add(cross.data(), cross.size() * sizeof(DevCross));
     int s_sparse = add(f->sparse, (size_t)(f->sparse ? f->n_sparse : 0) * sizeof(uint32_t));
     int s_scaling = add(f->scaling, f->scaling ? sizeof(OhScalingList) : 0);
     /* intra block descriptors: everything that depends only on geometry and mode is resolved here */
@@ -818,6 +843,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.wp = (const OhWeights *)(base + seg[s_wp].off);
     hd.tu = (const DevTu *)(base + seg[s_tu].off);
     hd.sparse = f->sparse ? (const uint32_t *)(base + seg[s_sparse].off) : nullptr;
+    hd.cross = (const DevCross *)(base + seg[s_cross].off); hd.n_cross = (uint32_t)cross.size();
     hd.scaling = f->scaling ? (const OhScalingList *)(base + seg[s_scaling].off) : nullptr;
     hd.coeffs = (const int16_t *)(base + seg[s_coef].off);
     hd.res = (int16_t *)(base + res_off);
@@ -858,6 +884,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     df->p = p;
     df->n_mc_luma = hd.n_mc_luma; df->n_mc_chroma = hd.n_mc_chroma; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
     for (int k = 0; k < 4; k++) df->tu_cnt[k] = tu_cnt[k];
+    df->n_cross = hd.n_cross;
     df->has_sao = has_sao;
     if (f->n_intra) {
         df->levels = levels;
@@ -919,6 +946,11 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
         ohk_inter(&all, nb, p, max_luma, max_chroma, st);
         MARK(OH_PASS_INTER);
         ohk_residual(&all, nb, p, max_tu, st);
+        {
+            uint32_t max_cross = 0;
+            for (int i = 0; i < nb; i++) max_cross = std::max(max_cross, fr[i]->n_cross);
+            ohk_cross(&all, nb, p, max_cross, st);
+        }
         MARK(OH_PASS_RESIDUAL);
         const OhCtuAreas areas = oh_ctu_areas(p->log2_ctb_size, p->chroma_format_idc);
         for (size_t l = 0; l < max_levels; l++) {

@@ -9,6 +9,7 @@ extern "C" {
 int  ohk_init(void);
 void ohk_inter(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_luma, uint32_t max_chroma, hipStream_t st);
 void ohk_residual(const OhBatch *B, int n, const OhPicParams *p, const uint32_t max_cnt[4], hipStream_t st);
+void ohk_cross(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_cross, hipStream_t st);
 void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st);
 void ohk_deblock(const OhBatch *B, int n, const OhPicParams *p, int horiz, hipStream_t st);
 void ohk_upsample_plane(const OhUpPlane *a, int taps, hipStream_t st);

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
     const bool sparse = tu.flags & OH_TUF_SPARSE;
     const int bd = f->pp.bit_depth;
     const bool is_tr = tu.kind == OH_TU_IDCT || tu.kind == OH_TU_DST4;
-    const bool to_pic = tu.kind == OH_TU_PCM || (tu.flags & OH_TUF_ADD_NOW);
+    /* a cross-component block is finished by cross_kernel once the luma residual of the picture is complete */
+    const bool to_pic = (tu.kind == OH_TU_PCM || (tu.flags & OH_TUF_ADD_NOW)) && !(tu.flags & OH_TUF_CROSS);
     const bool add = to_pic && tu.kind != OH_TU_PCM;
     const GLOBAL short4v *__restrict__ cin = (const GLOBAL short4v *)(f->coeffs + tu.coeff_off);
     const uint64_t p0 = (uint64_t)f->cur.p[0], p1 = (uint64_t)f->cur.p[1], p2 = (uint64_t)f->cur.p[2];
@@ -554,11 +555,43 @@ __global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
 #pragma unroll
             for (int j = 0; j < 4; j++) o[j] = add ? clip_px(pv[k][j] + res[k][j], bd) : (res[k][j] & (sizeof(PX) == 1 ? 0xff : 0xffff));
             store4<PX>(dst + (size_t)((4 * g) >> LOG2) * ds + ((4 * g) & (N - 1)), o[0], o[1], o[2], o[3]);
-        } else {
+        }
+        if (!to_pic || (tu.flags & OH_TUF_KEEP_RES)) {
             short4v o;
 #pragma unroll
             for (int j = 0; j < 4; j++) o[j] = (short)res[k][j];
             *((GLOBAL short4v *)(f->res + tu.coeff_off) + g) = o;
+        }
+    }
+}
+
+/* cross-component prediction (4:4:4 range extension; hevc_cabac.c:1942-1947 for coded chroma blocks, hevc.c:1319-1331 /
+ * 1352-1364 for cbf 0): chroma residual += (res_scale_val * luma residual) >> 3 in int16 storage, then the block is added
+ * to the prediction (inter) or left in the pool for the intra pass.  Runs after every inverse transform of the picture. */
+template <typename PX>
+__global__ __launch_bounds__(64) void cross_kernel(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    if (blockIdx.x >= f->n_cross)
+        return;
+    const DevCross c = gload(f->cross + blockIdx.x);
+    const int lane = threadIdx.x, bd = f->pp.bit_depth, log2 = c.log2_size, n = 1 << log2, ng = (n * n) >> 2;
+    const int ds = f->cur.stride[c.c_idx];
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, f->cur.p[c.c_idx]) + (size_t)c.y * ds + c.x;
+    GLOBAL short4v *__restrict__ rc = (GLOBAL short4v *)(f->res + c.res_c);
+    const GLOBAL short4v *__restrict__ ry = (const GLOBAL short4v *)(f->res + c.res_y);
+    for (int g = lane; g < ng; g += 64) {
+        const short4v a = rc[g], y = ry[g];
+        short4v r;
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = (short)(a[j] + ((c.scale * y[j]) >> 3));
+        if (c.flags & OH_TUF_ADD_NOW) {
+            int pv[4];
+            GLOBAL PX *__restrict__ d = dst + (size_t)((4 * g) >> log2) * ds + ((4 * g) & (n - 1));
+            load4<PX>(d, pv);
+            store4<PX>(d, clip_px(pv[0] + r[0], bd), clip_px(pv[1] + r[1], bd), clip_px(pv[2] + r[2], bd), clip_px(pv[3] + r[3], bd));
+        } else {
+            rc[g] = r;
         }
     }
 }
@@ -1699,6 +1732,13 @@ extern "C" void ohk_residual(const OhBatch *B, int n, const OhPicParams *p, cons
     } while (0)
     if (p->bit_depth == 8) RES_LAUNCH(uint8_t); else RES_LAUNCH(uint16_t);
 #undef RES_LAUNCH
+}
+
+extern "C" void ohk_cross(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_cross, hipStream_t st)
+{
+    if (!max_cross) return;
+    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_kernel<uint8_t>), dim3(max_cross, n), dim3(64), 0, st, *B);
+    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_kernel<uint16_t>), dim3(max_cross, n), dim3(64), 0, st, *B);
 }
 
 extern "C" void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st)

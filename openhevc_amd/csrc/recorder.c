@@ -39,7 +39,7 @@ struct OhRecorder {
     uint32_t  *level_start;
     /* side arrays */
     uint8_t *vbs, *hbs, *is_pcm, *is_intra;
-    uint32_t *sparse, *tu_sparse; uint64_t cap_sparse, cap_tu_sparse; int any_sparse, any_matrix;
+    uint32_t *sparse, *tu_sparse, *tu_cross; uint64_t cap_sparse, cap_tu_sparse, cap_tu_cross; int any_sparse, any_matrix, any_cross;
     OhScalingList scaling;
     int8_t  *qp;
     OhDeblockCtb *deblock;
@@ -105,7 +105,7 @@ void oh_rec_destroy(OhRecorder *r)
     free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->it_ctu); free(r->it_sub);
     free(r->sorted); free(r->ctu_dep); free(r->ctu_nsub); free(r->ctu_level); free(r->ctu_entry); free(r->ictu);
     free(r->sub_start); free(r->level_start);
-    free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->sparse); free(r->tu_sparse); free(r->qp); free(r->deblock); free(r->sao);
+    free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->sparse); free(r->tu_sparse); free(r->tu_cross); free(r->qp); free(r->deblock); free(r->sao);
     for (int c = 0; c < 3; c++)
         free(r->lvl[c]);
     free(r->decoded);
@@ -119,7 +119,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     for (int i = 0; i < OH_MAX_REFS; i++)
         r->f.ref_pics[i] = i < n_ref_pics ? ref_pics[i] : -1;
     r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = r->f.n_ictu = r->f.n_sub = 0;
-    r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0;
+    r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0; r->any_cross = 0;
     r->f.n_coeff = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
@@ -174,6 +174,7 @@ uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int ki
     r->f.n_coeff += n2;
     r->tu_sparse = (uint32_t *)grow(r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
     r->tu_sparse[r->f.n_tu] = OH_NO_COEFF;
+    if (r->any_cross) { r->tu_cross = (uint32_t *)grow(r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1); r->tu_cross[r->f.n_tu] = OH_NO_COEFF; }
     return r->f.n_tu++;
 }
 
@@ -197,10 +198,27 @@ uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size,
     r->f.n_sparse += 1 + (uint32_t)n;
     r->any_sparse = 1;
     if ((matrix_id & 0xff) != OH_FLAT_MATRIX) r->any_matrix = 1;
+    if (r->any_cross) { r->tu_cross = (uint32_t *)grow(r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1); r->tu_cross[r->f.n_tu] = OH_NO_COEFF; }
     return r->f.n_tu++;
 }
 
 OhScalingList *oh_rec_scaling_list(OhRecorder *r) { return &r->scaling; }
+
+int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
+{
+    if (tu_c >= r->f.n_tu || tu_y >= r->f.n_tu || tu_y >= (1u << 24) || r->tu[tu_y].c_idx != 0 || r->tu[tu_c].c_idx == 0 ||
+        r->tu[tu_y].log2_size != r->tu[tu_c].log2_size)
+        return -1;
+    if (!r->any_cross) {                                  /* first one of the picture: start from "none" */
+        r->tu_cross = (uint32_t *)grow(r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
+        for (uint32_t i = 0; i < r->f.n_tu; i++) r->tu_cross[i] = OH_NO_COEFF;
+        r->any_cross = 1;
+    }
+    r->tu_cross[tu_c] = tu_y | ((uint32_t)(res_scale_val & 0xff) << 24);
+    r->tu[tu_c].flags |= OH_TUF_CROSS;
+    r->tu[tu_y].flags |= OH_TUF_KEEP_RES;
+    return 0;
+}
 
 /* one neighbour cell (plane c, sample position x,y) read by a block of CTU (cx,cy) */
 static inline void visit(OhRecorder *r, int c, int x, int y, int cx, int cy, unsigned *sub, unsigned *dep)
@@ -358,6 +376,7 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     f->sparse = r->any_sparse ? r->sparse : NULL;
     f->tu_sparse = r->any_sparse ? r->tu_sparse : NULL;
     f->scaling = r->any_matrix ? &r->scaling : NULL;
+    f->tu_cross = r->any_cross ? r->tu_cross : NULL;
     f->deblock = r->deblock;
     f->sao = f->p.sao_enabled ? r->sao : NULL;
     return f;

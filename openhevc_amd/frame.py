@@ -75,7 +75,7 @@ class OhFrame(C.Structure):
         ("qp_y_tab", C.POINTER(C.c_int8)), ("is_pcm", C.POINTER(C.c_uint8)),
         ("deblock", C.POINTER(OhDeblockCtb)), ("sao", C.POINTER(OhSaoCtb)), ("is_intra", C.POINTER(C.c_uint8)),
         ("n_sparse", C.c_uint32), ("sparse", C.POINTER(C.c_uint32)), ("tu_sparse", C.POINTER(C.c_uint32)),
-        ("scaling", C.c_void_p),
+        ("scaling", C.c_void_p), ("tu_cross", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -83,7 +83,7 @@ class OhSynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in (
         "slice_type", "n_refs", "intra_pct", "skip_pct", "bi_pct", "frac_mv_pct", "mv_range", "cbf_pct",
         "weighted_pct", "split_pct", "qp_base", "qp_var", "sao_pct", "tskip_pct", "pcm_pct", "bypass_pct",
-        "vary_deblock_offsets", "sparse_pct", "scaling_list")] + [("reserved", C.c_int32 * 6)]
+        "vary_deblock_offsets", "sparse_pct", "scaling_list", "ccp_pct")] + [("reserved", C.c_int32 * 5)]
 
 
 assert C.sizeof(OhPu) == 20 and C.sizeof(OhWeights) == 28 and C.sizeof(OhTu) == 12
@@ -191,6 +191,7 @@ def host():
         lib.oh_rec_tu_sparse.restype = C.c_uint32
         lib.oh_rec_scaling_list.argtypes = [V]
         lib.oh_rec_scaling_list.restype = C.c_void_p
+        lib.oh_rec_tu_cross.argtypes = [V, C.c_uint32, C.c_uint32, I]
         lib.oh_rec_intra.argtypes = [V, I, I, I, I, I, I, C.c_uint32]
         lib.oh_rec_finish.argtypes = [V]
         lib.oh_rec_finish.restype = C.POINTER(OhFrame)

@@ -157,11 +157,16 @@ static int pick_flags(Gen *g, const CuInfo *cu, int kind)
 }
 
 /* one transform block of one plane: optional residual item, and the intra item for intra CUs */
-static void emit_tb(Gen *g, const CuInfo *cu, int c_idx, int xl, int yl, int log2, int mode, int avail, int cbf)
+/* returns the index of the recorded transform block, OH_NO_COEFF when cbf == 0 */
+static uint32_t emit_tb(Gen *g, const CuInfo *cu, int c_idx, int xl, int yl, int log2, int mode, int avail, int cbf, int zero_block)
 {
     int hs = oh_hshift(&g->p, c_idx), vs = oh_vshift(&g->p, c_idx);
     int x = xl >> hs, y = yl >> vs;
     uint32_t tu = OH_NO_COEFF;
+    if (!cbf && zero_block) {                          /* cross-component prediction with cbf 0: a block of zeros carries it, hevc.c:1315-1331 */
+        memset(g->blk, 0, sizeof(int16_t) << (2 * log2));
+        tu = oh_rec_tu(g->rec, c_idx, x, y, log2, OH_TU_BYPASS, cu->intra ? 0 : OH_TUF_ADD_NOW, g->blk);
+    }
     if (cbf) {
         int kind = pick_kind(g, cu, c_idx, log2);
         int flags = pick_flags(g, cu, kind);
@@ -192,6 +197,7 @@ static void emit_tb(Gen *g, const CuInfo *cu, int c_idx, int xl, int yl, int log
     }
     if (cu->intra)
         oh_rec_intra(g->rec, c_idx, x, y, log2, mode, avail, tu);
+    return tu;
 }
 
 static void gen_tu(Gen *g, const CuInfo *cu, int x, int y, int log2, int blk_idx, int xb, int yb)
@@ -201,7 +207,9 @@ static void gen_tu(Gen *g, const CuInfo *cu, int x, int y, int log2, int blk_idx
     int avail = cu->intra ? oh_rec_avail(g->rec, x, y, 1 << log2, 1 << log2) : 0;
     int cbf_y = pct(g, g->sp->cbf_pct) || cu->bypass;
     mark_edges(g, x, y, 1 << log2, 1 << log2, 1, 0);
-    emit_tb(g, cu, 0, x, y, log2, cu->mode[pu], avail, cbf_y);
+    uint32_t tu_y = emit_tb(g, cu, 0, x, y, log2, cu->mode[pu], avail, cbf_y, 0);
+    /* cross_pf is only parsed when the luma block is coded (hevc.c:1286-1290); 4:4:4 only */
+    int cross = nch == 3 && cbf_y && !cu->bypass && g->sp->ccp_pct > 0 && pct(g, g->sp->ccp_pct);
     if (cbf_y) set_cbf(g, x, y, 1 << log2);
     /* the luma block is reconstructed before its chroma blocks: from here on it counts as decoded
      * (the second chroma block of a 4:2:2 pair has the first one above it, hevc.c:1297-1345) */
@@ -212,7 +220,9 @@ static void gen_tu(Gen *g, const CuInfo *cu, int x, int y, int log2, int blk_idx
             for (int i = 0; i < nblk; i++) {
                 int yy = y + (i << lc);               /* 4:2:2: two square blocks stacked vertically */
                 int av = nch == 2 ? (cu->intra ? oh_rec_avail(g->rec, x, yy, 2 << lc, 1 << lc) : 0) : avail;
-                emit_tb(g, cu, c, x, yy, lc, cu->mode_c[pu], av, pct(g, g->sp->cbf_pct / 2) || cu->bypass);
+                int scale = cross ? (rnd(g, 2) ? 1 : -1) * (1 << rnd(g, 4)) : 0;          /* log2_res_scale_abs_plus1 - 1 in 0..3, sign */
+                uint32_t tu_c = emit_tb(g, cu, c, x, yy, lc, cu->mode_c[pu], av, pct(g, g->sp->cbf_pct / 2) || cu->bypass, cross && scale);
+                if (cross && scale && tu_c != OH_NO_COEFF) oh_rec_tu_cross(g->rec, tu_c, tu_y, scale);
             }
     } else if (nch && blk_idx == 3) {               /* chroma of four 4x4 luma blocks, hevc.c:1395-1420 */
         int nblk = nch == 2 ? 2 : 1;
@@ -220,7 +230,7 @@ static void gen_tu(Gen *g, const CuInfo *cu, int x, int y, int log2, int blk_idx
             for (int i = 0; i < nblk; i++) {
                 int yy = yb + 4 * i;
                 int av = cu->intra ? oh_rec_avail(g->rec, xb, yy, 8, nch == 2 ? 4 : 8) : 0;
-                emit_tb(g, cu, c, xb, yy, 2, cu->mode_c[0], av, pct(g, g->sp->cbf_pct / 2) || cu->bypass);
+                emit_tb(g, cu, c, xb, yy, 2, cu->mode_c[0], av, pct(g, g->sp->cbf_pct / 2) || cu->bypass, 0);
             }
     }
 }

@@ -425,6 +425,16 @@ int oh_or_pass_residual(const OhFrame *f, OhHostPic *pics, int16_t *coeffs)
         if ((tu->flags & OH_TUF_SPARSE) && f->tu_sparse && f->tu_sparse[i] != OH_NO_COEFF)
             tu_dequant(f, tu, f->sparse + f->tu_sparse[i], c);
         tu_inverse(f->p.bit_depth, tu, c);
+        /* cross-component prediction, hevc_cabac.c:1942-1947 (coded chroma block) and hevc.c:1319-1331, 1352-1364 (cbf 0):
+         * the luma block of the transform unit precedes its chroma blocks in the list, its residual is already in the
+         * pool.  PARITY UNPINNED for this statement: it is host code of hevc.c / hevc_cabac.c, outside the files that
+         * can be compiled here; restated from the text (int16 storage, arithmetic shift). */
+        if ((tu->flags & OH_TUF_CROSS) && f->tu_cross && f->tu_cross[i] != OH_NO_COEFF) {
+            const OhTu *ty = &f->tu[f->tu_cross[i] & 0xffffff];
+            const int scale = (int8_t)(f->tu_cross[i] >> 24), n2 = 1 << (2 * tu->log2_size);
+            const int16_t *cy = coeffs + ty->coeff_off;
+            for (int k = 0; k < n2; k++) c[k] = (int16_t)(c[k] + ((scale * cy[k]) >> 3));
+        }
         if (tu->flags & OH_TUF_ADD_NOW)
             tu_store(f, cur, tu, c);
     }

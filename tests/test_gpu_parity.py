@@ -81,6 +81,9 @@ CASES = [
     ("b8_sparse", 416, 240, 8, 1, 6, 2, {"sparse_pct": 70}),
     ("b10_sparse_lists", 264, 200, 10, 1, 5, 2, {"sparse_pct": 100, "scaling_list": 1, "tskip_pct": 25, "intra_pct": 30}),
     ("i12_444_sparse_lists", 136, 88, 12, 3, 5, 0, {"sparse_pct": 100, "scaling_list": 1}),
+    # cross-component prediction (4:4:4 range extension, hevc.c:1319-1365): chroma residual += (scale * luma residual) >> 3
+    ("b8_444_ccp", 200, 136, 8, 3, 5, 2, {"ccp_pct": 60, "intra_pct": 30}),
+    ("i10_444_ccp_sparse", 136, 88, 10, 3, 6, 0, {"ccp_pct": 80, "sparse_pct": 60, "tskip_pct": 20}),
 ]
 
 
@@ -360,7 +363,8 @@ def test_random_configurations(eng):
                      split_pct=int(rng.integers(10, 90)), tskip_pct=int(rng.choice([0, 0, 30])),
                      pcm_pct=int(rng.choice([0, 15])) if pcm else 0, bypass_pct=int(rng.choice([0, 15])) if byp else 0,
                      sao_pct=int(rng.integers(0, 101)), vary_deblock_offsets=int(rng.integers(0, 2)),
-                     sparse_pct=int(rng.choice([0, 0, 50, 100])), scaling_list=int(rng.integers(0, 2)))
+                     sparse_pct=int(rng.choice([0, 0, 50, 100])), scaling_list=int(rng.integers(0, 2)),
+                     ccp_pct=int(rng.choice([0, 50])) if chroma == 3 else 0)
         rec = F.Recorder(p)
         f = rec.synth(F.synth_params(st, 555000 + it, **knobs), 2, [0, 1] if st else [])
         prng = np.random.default_rng(it)

@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
     ap.add_argument("--sparse-pct", type=int, default=0, help="%% of transform blocks handed over as quantised levels (de-quantised on the GPU) instead of dense coefficients")
+    ap.add_argument("--exchange", default="readers", choices=["readers", "allgather"],
+                    help="N>1: send finished reference pictures to the ranks that reference them (point-to-point batches), or replicate them everywhere (one all-gather per chain and wave)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
     args = ap.parse_args()
@@ -134,12 +136,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange = P.exchange_map(world, rank, args.waves, args.tail) if world > 1 and args.exchange == "readers" else None
+
     def run(n_steps):
         """one step = every chain in flight advances by one GOP: each stream runs its chains as lockstep batches"""
         for _ in range(n_steps):
             for g in groups:
                 with torch.cuda.stream(g[0][0]):
-                    P.run_steps_batched(g[1:], dist if world > 1 else None)
+                    P.run_steps_batched(g[1:], dist if world > 1 else None, exchange)
 
     run(max(args.warmup, 1))
     barrier()
@@ -230,7 +234,9 @@ def main():
                                f"non-reference B pictures): {n_chains} GOPs per GPU and step",
                        "chains_in_flight_per_gpu": n_chains, "streams_per_gpu": n_streams,
                        "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
-                       "exchange": "one RCCL all-gather of the finished reference pictures per wave" if world > 1 else "none (1 GPU)",
+                       "exchange": ("none (1 GPU)" if world == 1 else
+                                    "finished reference pictures sent point-to-point (RCCL) to the ranks that reference them, one batch per wave and stream"
+                                    if exchange is not None else "one RCCL all-gather of the finished reference pictures per chain and wave"),
                        "generator": dict(knobs, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
             "roofline": roofline,
         }

@@ -98,15 +98,34 @@ def run_step(plan: StepPlan, backend: Backend, dist=None, group=None):
         backend.execute(pic.name)
 
 
-def run_steps_batched(chains, dist=None):
+def exchange_map(world, rank, n_waves, n_tail):
+    """Who references whose reference pictures: per wave (send_to, recv_from) of this rank.  A decoder knows its reference
+    picture sets ahead of time, so a finished picture only has to reach the GPUs that will read it — the general case is the
+    all-gather (everybody), this is the same exchange restricted to the readers."""
+    need = {}
+    for r in range(world):
+        for pic in make_step_plan(world, r, n_waves=n_waves, n_tail=n_tail).pictures():
+            for ref in pic.refs:
+                if ref[2] != r:
+                    need.setdefault((ref[1], ref[2]), set()).add(r)
+    out = []
+    for w in range(n_waves):
+        send_to = sorted(need.get((w, rank), ()))
+        recv_from = sorted(src for (ww, src), dsts in need.items() if ww == w and rank in dsts)
+        out.append((send_to, recv_from))
+    return out
+
+
+def run_steps_batched(chains, dist=None, exchange=None):
     """Enqueue one step of EVERY chain in lockstep.  chains: list of (plan, backend, process group); the
     chains are independent GOPs with the same schedule, so wave w of all of them is one batch of
     mutually independent pictures (Backend.execute_batch: one launch per pass over the whole batch), and
-    so is the union of their tails.  The exchange after a wave stays one all-gather per chain."""
+    so is the union of their tails.  The exchange after a wave is one all-gather per chain, or — with exchange =
+    exchange_map(...) — one batch of point-to-point transfers to the ranks that reference the pictures."""
     plan0, be0 = chains[0][0], chains[0][1]
     for w in range(len(plan0.waves)):
         be0.execute_batch([(be, pl.waves[w].name) for pl, be, _ in chains])
-        if plan0.world > 1:
+        if plan0.world > 1 and exchange is None:          # everybody gets everything: one all-gather per chain
             for pl, be, group in chains:
                 half = be.final_half(pl.waves[w].name)
                 buf = be.wave_tensor(w)[half]
@@ -114,6 +133,22 @@ def run_steps_batched(chains, dist=None):
                 for r in range(pl.world):
                     if r != pl.rank:
                         be.set_final_half(("ref", w, r), half)
+        elif plan0.world > 1:                             # only to the ranks that reference the picture: one P2P batch per wave
+            send_to, recv_from = exchange[w]
+            by_group, done = {}, []                        # a batch must stay inside one communicator
+            for pl, be, group in chains:
+                half = be.final_half(pl.waves[w].name)
+                buf = be.wave_tensor(w)[half]
+                ops = by_group.setdefault(id(group), [])
+                ops += [dist.P2POp(dist.isend, buf[pl.rank], dst, group) for dst in send_to]
+                ops += [dist.P2POp(dist.irecv, buf[src], src, group) for src in recv_from]
+                done += [(be, ("ref", w, src), half) for src in recv_from]
+            for ops in by_group.values():
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+            for be, name, half in done:
+                be.set_final_half(name, half)
     tail = [(be, pic.name) for pl, be, _ in chains for pic in pl.tail]
     if tail:
         be0.execute_batch(tail)

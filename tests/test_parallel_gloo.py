@@ -30,7 +30,7 @@ def _digest(planes):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, w, h, out_path, batched=False):
+def _worker(rank, world, port, w, h, out_path, batched=False, p2p=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     from openhevc_amd import frame as F
@@ -48,7 +48,7 @@ def _worker(rank, world, port, w, h, out_path, batched=False):
         chains = [(plan, be, None), (plan2, be2, dist.new_group())]
     for _ in range(2):                                 # two steps: buffers are reused across steps
         if batched:
-            P.run_steps_batched(chains, dist)
+            P.run_steps_batched(chains, dist, P.exchange_map(world, rank, 3, 2) if p2p else None)
         else:
             P.run_step(plan, be, dist)
     res = {str(n): _digest(be.picture(n)) for n in be.store.names()}
@@ -97,6 +97,26 @@ def test_two_ranks_gloo_match_single_process(tmp_path, batched):
     for k in a:
         if k.startswith("('ref'"):
             assert a[k] == b[k]
+
+
+@pytest.mark.timeout(900)
+def test_four_ranks_point_to_point_exchange(tmp_path):
+    """lockstep batches with the reference pictures sent only to the ranks that reference them (exchange_map): every picture a
+    rank DECODES must equal the single-process decode; pictures it never references may be missing in its DPB"""
+    world, w, h = 4, 128, 72
+    out = str(tmp_path / "res")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out, True, True), nprocs=world, join=True)
+    want = _single_process_expectation(world, w, h)
+    from openhevc_amd import parallel as P
+    for r in range(world):
+        got = torch.load(f"{out}.{r}")
+        plan = P.make_step_plan(world, r, n_waves=3, n_tail=2, seed=5)
+        mine = {str(pic.name) for pic in plan.pictures()} | {str(ref) for pic in plan.pictures() for ref in pic.refs}
+        for k in mine:
+            assert got[k] == want[r][k], f"rank {r}: picture {k} differs from the single-process decode"
+        ex = P.exchange_map(world, r, 3, 2)
+        assert all(r not in s and r not in t for s, t in ex)
+        assert sum(len(s) for s, _ in ex) < 3 * (world - 1)        # fewer transfers than replicating everything
 
 
 def test_plan_is_balanced_and_cross_rank():

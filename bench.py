@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--sparse-pct", type=int, default=0, help="%% of transform blocks handed over as quantised levels (de-quantised on the GPU) instead of dense coefficients")
     ap.add_argument("--exchange", default="readers", choices=["readers", "allgather"],
                     help="N>1: send finished reference pictures to the ranks that reference them (point-to-point batches), or replicate them everywhere (one all-gather per chain and wave)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: REHEARSAL of the N>1 control flow with several ranks on one GPU (transfers staged through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
     args = ap.parse_args()
@@ -102,10 +104,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()            # rehearsal: the ranks share the GPUs that are there
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     params = F.pic_params(**WORKLOADS[args.workload])
     n_chains = max(1, args.chains)
@@ -160,7 +167,7 @@ def main():
     for eng in engines:
         eng.profile(0)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

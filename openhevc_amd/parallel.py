@@ -116,6 +116,12 @@ def exchange_map(world, rank, n_waves, n_tail):
     return out
 
 
+def _staged(dist, group, tensor):
+    """rehearsal only: the gloo backend cannot move device memory, so the transfer goes through a host copy (lets the
+    N > 1 control flow run with several ranks on ONE GPU; RCCL moves the device buffers themselves)"""
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def run_steps_batched(chains, dist=None, exchange=None):
     """Enqueue one step of EVERY chain in lockstep.  chains: list of (plan, backend, process group); the
     chains are independent GOPs with the same schedule, so wave w of all of them is one batch of
@@ -129,24 +135,37 @@ def run_steps_batched(chains, dist=None, exchange=None):
             for pl, be, group in chains:
                 half = be.final_half(pl.waves[w].name)
                 buf = be.wave_tensor(w)[half]
-                dist.all_gather_into_tensor(buf.view(-1), buf[pl.rank], group=group)
+                if _staged(dist, group, buf):
+                    host = buf.cpu()
+                    dist.all_gather_into_tensor(host.view(-1), host[pl.rank].clone(), group=group)
+                    buf.copy_(host)
+                else:
+                    dist.all_gather_into_tensor(buf.view(-1), buf[pl.rank], group=group)
                 for r in range(pl.world):
                     if r != pl.rank:
                         be.set_final_half(("ref", w, r), half)
         elif plan0.world > 1:                             # only to the ranks that reference the picture: one P2P batch per wave
             send_to, recv_from = exchange[w]
-            by_group, done = {}, []                        # a batch must stay inside one communicator
+            by_group, done, landed = {}, [], []            # a batch must stay inside one communicator
             for pl, be, group in chains:
                 half = be.final_half(pl.waves[w].name)
                 buf = be.wave_tensor(w)[half]
                 ops = by_group.setdefault(id(group), [])
-                ops += [dist.P2POp(dist.isend, buf[pl.rank], dst, group) for dst in send_to]
-                ops += [dist.P2POp(dist.irecv, buf[src], src, group) for src in recv_from]
+                stage = _staged(dist, group, buf)
+                mine = buf[pl.rank].cpu() if stage and send_to else buf[pl.rank]
+                ops += [dist.P2POp(dist.isend, mine, dst, group) for dst in send_to]
+                for src in recv_from:
+                    into = buf[src].cpu() if stage else buf[src]
+                    ops.append(dist.P2POp(dist.irecv, into, src, group))
+                    if stage:
+                        landed.append((buf[src], into))
                 done += [(be, ("ref", w, src), half) for src in recv_from]
             for ops in by_group.values():
                 if ops:
                     for req in dist.batch_isend_irecv(ops):
                         req.wait()
+            for dev, host in landed:
+                dev.copy_(host)
             for be, name, half in done:
                 be.set_final_half(name, half)
     tail = [(be, pic.name) for pl, be, _ in chains for pic in pl.tail]

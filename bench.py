@@ -85,7 +85,7 @@ def main():
 
     # One HIP stream per chain only overlaps if the runtime maps them to distinct hardware queues
     # (ROCm default: 4).  Must be set before the HIP runtime starts.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(args.streams + 2, 24))))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, min(2 * args.streams + 4, 24))))   # engine streams + the collectives' own
 
     import torch
     import torch.distributed as dist

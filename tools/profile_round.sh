@@ -7,9 +7,9 @@ R=$PWD
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp
-python3 $R/bench.py --steps 8 > $O/bench.json
+python3 $R/bench.py > $O/bench.json
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 4 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py > $O/bench_under_rocprof.json 2> $O/rocprof_stats.log
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --steps 1 --no-cpu-baseline --no-profile > $O/bench_under_pmc_fetch.json 2> $O/rocprof_fetch.log
 echo "fetch done"

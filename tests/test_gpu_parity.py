@@ -185,6 +185,27 @@ def test_1080p_b_and_i_pictures(eng):
     rec.close()
 
 
+@pytest.mark.parametrize("name,w,h,bd,chroma,seeds", [
+    ("2160p_main10", 3840, 2160, 10, 1, ((0, 21), (2, 22))),            # BASELINE configs[2]/[3] geometry, the bench workload
+    ("4320p_444_10bit", 7680, 4320, 10, 3, ((2, 23),)),                  # BASELINE configs[4] geometry (range extension 4:4:4)
+])
+def test_full_size_pictures(eng, name, w, h, bd, chroma, seeds):
+    """BASELINE.json's full sizes, bit-exact against the oracle (a 4K picture costs the oracle ~0.3 s, the 8K 4:4:4 one a
+    few seconds): the benchmark stream's own generator knobs"""
+    from openhevc_amd import parallel as P
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma)
+    rec = F.Recorder(p)
+    rng = np.random.default_rng(31)
+    refs = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng)}
+    for st, seed in seeds:
+        f = rec.synth(F.synth_params(st, seed, **P.default_synth_knobs()), 2, [0, 1])
+        pics = dict(refs)
+        pics[2] = F.HostPic(p)
+        want, got = run_both(eng, p, f, pics)
+        assert_same(want, got, f"{name} slice_type {st}")
+    rec.close()
+
+
 def test_malformed_work_lists_fail_on_the_host(eng):
     from openhevc_amd.engine import EngineError, remap_frame
     p = F.pic_params(128, 72)

@@ -31,6 +31,9 @@ WORKLOADS = {
     "1080p_main8": dict(width=1920, height=1080, bit_depth=8, chroma_format_idc=1),
     "2160p_main8": dict(width=3840, height=2160, bit_depth=8, chroma_format_idc=1),
     "480p_main8": dict(width=832, height=480, bit_depth=8, chroma_format_idc=1),
+    # north-star target geometry (8K60 = 1990 Mpixels/s) and configs[4] (range extension 4:4:4); use --chains 16: a picture is 100 / 200 MB
+    "4320p_main10": dict(width=7680, height=4320, bit_depth=10, chroma_format_idc=1),
+    "4320p_444_main10": dict(width=7680, height=4320, bit_depth=10, chroma_format_idc=3),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 # kernel that implements each pass (name as rocprofv3 reports it, without template arguments)

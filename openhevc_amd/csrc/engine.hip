@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,7 @@ struct EventSet { hipEvent_t ev[OH_N_PASSES + 1]; int n_frames = 1; };
 
 struct OhDevFrame {
     void      *arena = nullptr;
+    size_t     arena_bytes = 0;
     DevFrame  *d = nullptr;
     OhPicParams p{};
     uint32_t   n_mc_luma = 0, n_mc_chroma = 0, n_tu = 0, n_intra = 0;
@@ -63,6 +65,12 @@ struct OhEngine {
     double      pass_ms[OH_N_PASSES] = {};
     uint64_t    executes = 0;
     std::vector<OhDevFrame *> deferred;
+    /* upload path: pinned staging buffers and device arenas are recycled (hipHostMalloc / hipMalloc cost milliseconds);
+     * a staging buffer is busy until the H2D copy that reads it has passed `done` */
+    struct Stage { void *p; size_t bytes; hipEvent_t done; bool busy; };
+    std::vector<Stage> stages;
+    struct Arena { void *p; size_t bytes; };
+    std::vector<Arena> arenas;               /* free device arenas */
     int16_t    *up_tmp = nullptr;        /* intermediate rows of oh_pic_upsample */
     size_t      up_tmp_elems = 0;
     uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
@@ -144,12 +152,18 @@ extern "C" int oh_engine_create_on_stream(OhEngine **out, int device, void *hip_
 extern "C" const char *oh_engine_last_error(const OhEngine *e) { return e ? e->err.c_str() : "no engine"; }
 extern "C" void *oh_engine_stream(OhEngine *e) { return e ? (void *)e->stream : nullptr; }
 
-static void free_dev_frame(OhDevFrame *df)
+/* arenas go back to the engine's pool: the next upload that reuses one is ordered behind everything enqueued on the
+ * engine stream, so kernels that still read the old contents are not disturbed */
+static void free_dev_frame(OhEngine *e, OhDevFrame *df)
 {
     if (!df)
         return;
-    if (df->arena)
-        (void)hipFree(df->arena);
+    if (df->arena) {
+        if (e && e->arenas.size() < 256)
+            e->arenas.push_back({ df->arena, df->arena_bytes });
+        else
+            (void)hipFree(df->arena);
+    }
     delete df;
 }
 
@@ -160,7 +174,7 @@ extern "C" int oh_engine_sync(OhEngine *e)
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (OhDevFrame *df : e->deferred)
-        free_dev_frame(df);
+        free_dev_frame(e, df);
     e->deferred.clear();
     return OH_OK;
 }
@@ -172,7 +186,7 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (OhDevFrame *df : e->deferred)
-        free_dev_frame(df);
+        free_dev_frame(e, df);
     for (Pic &p : e->pics)
         if (p.used && p.base && p.owned)
             (void)hipFree(p.base);
@@ -182,6 +196,8 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &ev : e->lev_pending) (void)hipEventDestroy(ev);
     for (auto &s : e->ev_pending)
         for (auto &ev : s.ev) (void)hipEventDestroy(ev);
+    for (auto &c : e->stages) { (void)hipEventDestroy(c.done); (void)hipHostFree(c.p); }
+    for (auto &a : e->arenas) (void)hipFree(a.p);
     if (e->up_tmp)
         (void)hipFree(e->up_tmp);
     if (e->own_stream)
@@ -594,12 +610,16 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     Pic *cur = get_pic(e, f->cur_pic);
     if (!cur || !same_geometry(cur->p, f->p))
         FAIL(e, OH_E_ARG, "cur_pic %d is not an allocated picture of this geometry", f->cur_pic);
+    static const bool timing = getenv("OHEVC_UPLOAD_TIMING") != nullptr;      /* diagnostic: where the host time of an upload goes */
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t_begin = tnow();
     std::vector<DevMcJob> mc_luma, mc_chroma;
     mc_luma.reserve((size_t)f->n_pu * 4);
     mc_chroma.reserve((size_t)f->n_pu * 4);
     rc = validate(e, f, cur, mc_luma, mc_chroma);
     if (rc)
         return rc;
+    auto t_valid = tnow();
     HIPCHK(e, hipSetDevice(e->device));
 
     const OhPicParams &p = f->p;
@@ -823,10 +843,29 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     const size_t res_off = total;
     total += align_up((size_t)(f->n_coeff ? f->n_coeff : 1) * sizeof(int16_t), 256);
 
+    auto t_lists = tnow();
     OhDevFrame *df = new OhDevFrame();
-    if (hipMalloc(&df->arena, total) != hipSuccess) {
-        delete df;
-        FAIL(e, OH_E_NOMEM, "hipMalloc(%zu) for the work list failed", total);
+    {   /* smallest pooled arena that fits (within 2x), else a new one rounded up to 1 MiB */
+        int best = -1;
+        for (size_t i = 0; i < e->arenas.size(); i++)
+            if (e->arenas[i].bytes >= total && e->arenas[i].bytes <= 2 * total + (1u << 20) &&
+                (best < 0 || e->arenas[i].bytes < e->arenas[best].bytes))
+                best = (int)i;
+        if (best >= 0) {
+            df->arena = e->arenas[best].p; df->arena_bytes = e->arenas[best].bytes;
+            e->arenas.erase(e->arenas.begin() + best);
+        } else {
+            df->arena_bytes = align_up(total, (size_t)1 << 20);
+            if (hipMalloc(&df->arena, df->arena_bytes) != hipSuccess) {
+                for (auto &a : e->arenas) (void)hipFree(a.p);          /* the pool may be what is in the way */
+                e->arenas.clear();
+                if (hipMalloc(&df->arena, df->arena_bytes) != hipSuccess) {
+                    df->arena = nullptr;
+                    delete df;
+                    FAIL(e, OH_E_NOMEM, "hipMalloc(%zu) for the work list failed", total);
+                }
+            }
+        }
     }
     char *base = (char *)df->arena;
     hd.pp = p;
@@ -864,21 +903,43 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     (void)s_hdr;
 
     /* stage everything in one host buffer -> one H2D copy */
-    void *stage = nullptr;
-    if (hipHostMalloc(&stage, copy_bytes, hipHostMallocDefault) != hipSuccess) {
-        free_dev_frame(df);
-        FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
+    auto t_alloc = tnow();
+    OhEngine::Stage *sg = nullptr;
+    for (auto &c : e->stages) {                          /* a pinned buffer whose previous copy has completed */
+        if (c.busy && hipEventQuery(c.done) == hipSuccess)
+            c.busy = false;
+        if (!c.busy && c.bytes >= copy_bytes && (!sg || c.bytes < sg->bytes))
+            sg = &c;
     }
+    if (!sg) {
+        OhEngine::Stage c;
+        c.bytes = align_up(copy_bytes, (size_t)4 << 20); c.busy = false; c.p = nullptr; c.done = nullptr;
+        if (hipHostMalloc(&c.p, c.bytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess) {
+            if (c.p) (void)hipHostFree(c.p);
+            free_dev_frame(e, df);
+            FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
+        }
+        e->stages.push_back(c);
+        sg = &e->stages.back();
+    }
+    void *stage = sg->p;
     for (int i = 0; i < ns; i++)
         if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
             memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
+    /* asynchronous: the caller's arrays are already copied out; the pinned buffer stays busy until `done` */
     hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, e->stream);
     if (hrc == hipSuccess)
-        hrc = hipStreamSynchronize(e->stream);
-    (void)hipHostFree(stage);
+        hrc = hipEventRecord(sg->done, e->stream);
+    sg->busy = hrc == hipSuccess;
     if (hrc != hipSuccess) {
-        free_dev_frame(df);
+        free_dev_frame(e, df);
         FAIL(e, OH_E_HIP, "work-list upload failed: %s", hipGetErrorString(hrc));
+    }
+    if (timing) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        auto t_end = tnow();
+        fprintf(stderr, "oh_frame_upload: validate + MC jobs %.2f ms, descriptors / levels %.2f ms, arena %.2f ms, staging copy + enqueue %.2f ms (%zu bytes)\n",
+                ms(t_begin, t_valid), ms(t_valid, t_lists), ms(t_lists, t_alloc), ms(t_alloc, t_end), copy_bytes);
     }
     df->d = (DevFrame *)base;
     df->p = p;
@@ -1039,7 +1100,7 @@ extern "C" int oh_frame_free(OhEngine *e, OhDevFrame *df)
         return OH_E_ARG;
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    free_dev_frame(df);
+    free_dev_frame(e, df);
     return OH_OK;
 }
 

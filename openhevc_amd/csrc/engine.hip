@@ -802,10 +802,17 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     /* inside a sub-level the blocks are independent: put the <=8x8 ones first — the kernel runs four of them per wave
      * (16-lane slots) — and note how many there are (none for constrained intra pred, which needs the one-block path) */
     std::vector<uint32_t> sub_small(f->n_intra ? f->n_sub : 0, 0);
+    std::vector<DevIntra> big;                              /* scratch of the stable partition (ranges are a handful of blocks) */
     for (size_t j = 0; j < sub_small.size(); j++) {
-        auto b0 = dintra.begin() + f->sub_start[j], b1 = dintra.begin() + f->sub_start[j + 1];
-        auto mid = std::stable_partition(b0, b1, [](const DevIntra &d) { return d.log2_size <= 3; });
-        sub_small[j] = p.constrained_intra_pred ? 0u : (uint32_t)(mid - b0);
+        const uint32_t b0 = f->sub_start[j], b1 = f->sub_start[j + 1];
+        uint32_t w = b0;
+        big.clear();
+        for (uint32_t b = b0; b < b1; b++) {
+            if (dintra[b].log2_size <= 3) { if (w != b) dintra[w] = dintra[b]; w++; }
+            else big.push_back(dintra[b]);
+        }
+        for (size_t k = 0; k < big.size(); k++) dintra[w + k] = big[k];
+        sub_small[j] = p.constrained_intra_pred ? 0u : w - b0;
     }
     std::vector<OhDevFrame::Level> levels(f->n_intra ? f->n_levels : 0);
     for (size_t l = 0; l < levels.size(); l++) {

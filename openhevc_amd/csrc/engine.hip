@@ -979,7 +979,8 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
     }
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
-    const bool prof = e->profile > 0, prof_launch = e->profile > 1;
+    /* per-launch events are a sample, not a log: stop bracketing once 100 k launches are pending collection */
+    const bool prof = e->profile > 0, prof_launch = e->profile > 1 && e->lev_pending.size() < 200000;
     static const char *wenv = getenv("OHEVC_INTRA_WAVES");            /* experiments: force the waves per CTU */
     for (int c0 = 0; c0 < n; c0 += OH_MAX_BATCH) {
         const int nb = n - c0 < OH_MAX_BATCH ? n - c0 : OH_MAX_BATCH;

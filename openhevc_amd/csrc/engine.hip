@@ -43,6 +43,7 @@ struct OhDevFrame {
     uint32_t   n_cross = 0;
     bool       has_sao = false;
     int        cur_pic = -1;      /* engine id of the picture the list reconstructs */
+    const struct OhEngine *owner = nullptr;   /* picture ids and arenas belong to one engine */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
         bool     staged;                  /* every CTU has its residual span contiguous (stageable in LDS) */
@@ -959,6 +960,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     }
     cur->final_b = has_sao;
     df->cur_pic = f->cur_pic;
+    df->owner = e;
     *out = df;
     return OH_OK;
 }
@@ -973,6 +975,8 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
     for (int i = 0; i < n; i++) {
         if (!dfs[i])
             return OH_E_ARG;
+        if (dfs[i]->owner != e)
+            FAIL(e, OH_E_ARG, "batch: picture %d was uploaded to another engine", i);
         const OhPicParams &a = dfs[0]->p, &b = dfs[i]->p;
         if (memcmp(&a, &b, sizeof(a)) != 0)
             FAIL(e, OH_E_ARG, "batch: picture %d has other parameters than picture 0", i);

@@ -248,6 +248,14 @@ def test_malformed_work_lists_fail_on_the_host(eng):
             eng.frame_submit(bad)
     eng.frame_submit(remap_frame(fs, ids))
     eng.sync()
+    # a work list uploaded to one engine cannot be executed by another (picture ids are per engine)
+    from openhevc_amd.engine import Engine
+    other = Engine(0)
+    df = eng.frame_upload(remap_frame(f, ids))
+    with pytest.raises(EngineError):
+        other.frames_execute([df])
+    eng.frame_free(df)
+    other.close()
     for v in ids.values():
         eng.pic_free(v)
     rec.close()

@@ -35,7 +35,7 @@ enum { OH_MCF_FROM_L1 = 1 };      /* uni-prediction whose only list is list 1 (s
 #define OH_CTU_MAX 64
 #define OH_MAX_CTU_BLOCKS 768                      /* 64x64 4:4:4 all 4x4 */
 #define OH_INTRA_WAVE_LDS 576                      /* per-wave edge arrays: 132 ints for one block or 4 x 36 ints for four
-                                                      <=8x8 blocks in 16-lane slots (kernels.hip: IntraLds) */
+                                                      <=8x8 blocks in 16-lane slots (intra.hip: IntraLds) */
 struct OhCtuAreas { uint32_t main[3], top[3], total; };
 static __host__ __device__ inline OhCtuAreas oh_ctu_areas(int log2_ctb, int chroma_format_idc)
 {

@@ -131,7 +131,7 @@ static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_e
     return OH_OK;
 }
 
-/* diagnostics: copies the in-kernel stamp records (see kernels.hip, OH_STAMPS) and clears them */
+/* diagnostics: copies the in-kernel stamp records (see intra.hip, OH_STAMPS) and clears them */
 extern "C" int oh_debug_read(OhEngine *e, uint64_t *out, size_t n_u64)
 {
     if (!e || !e->dbg || !out)

@@ -1,0 +1,645 @@
+/*
+ * intra.hip — pass 3: intra prediction as a CTU wavefront (planar / DC / angular, constrained intra pred) + deferred residual add
+ * (gfx950; overview of the passes: kernels.hip; bit-exactness: tests/test_gpu_parity.py)
+ */
+#include "kernels_common.h"
+
+/* =========================================================================================
+ * pass 3: intra prediction as a CTU wavefront — hevcpred_template.c:30-538
+ * (constrained_intra_pred_flag == 0), each block followed by its residual (transform_add).
+ *
+ * One workgroup reconstructs one CTU.  The CTU's samples (with the one-sample border above and
+ * to the left that intra_pred() gathers from, :164-183), the CTU's block descriptors and residual
+ * blocks are staged in LDS once; the waves then take the blocks of the current SUB-LEVEL (blocks
+ * of one sub-level never read each other).  Per block a wave
+ *   - reads its 32-byte descriptor (everything that depends only on the block's geometry and mode
+ *     was resolved on the host at upload: LDS offsets, edge sizes, filter / class flags, angles),
+ *   - gathers left[]/top[] from the staged CTU, one element per lane, and substitutes missing
+ *     samples with wave-uniform lane reads (v_readlane) instead of the reference's serial fills,
+ *   - smooths with whole-wave DPP shifts, publishes left[]/top[] in LDS once,
+ *   - predicts 4 consecutive samples per lane in a mode-class specific loop, adds the residual and
+ *     writes LDS (for the next sub-level) and HBM (dword stores, never waited for).
+ * Sub-levels are separated by an LDS-only workgroup barrier, so the dependent chain inside a CTU
+ * costs a handful of LDS round trips per block inside one CU — no kernel launch, no HBM round
+ * trip.  CTUs of one launch are mutually independent (same wavefront level, recorder.c).
+ * ======================================================================================= */
+#define INTRA_MAX_WAVES 8
+/* diagnostic build (-DOH_STAMPS, tools/intra_stamps.py): in-kernel cycle accounting of workgroup 0 */
+#ifdef OH_STAMPS
+#define STAMP(var) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; } while (0)
+#define ACC(slot, t0, t1) (acc[slot] += (t1) - (t0))
+#else
+#define STAMP(var) do { } while (0)
+#define ACC(slot, t0, t1) do { } while (0)
+#endif
+struct IntraLds { int E[OH_INTRA_WAVE_LDS / 4]; };                   /* E[0..65] = left[-1..64), E[66..131] = top[-1..64), per wave */
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+/* workgroup barrier that waits for LDS traffic only (global stores of finished samples stay in flight) */
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+/* lane i <- lane i-1 (lane 0 keeps `fill`) / lane i <- lane i+1 (lane 63 keeps `fill`): GFX9 whole-wave DPP shifts */
+static __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+static __device__ __forceinline__ int wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+struct PlaneRegs { uint64_t base[3]; int stride[2]; };               /* wave-uniform (SGPRs): [0] luma, [1] chroma */
+
+template <typename PX>
+static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, GLOBAL PX *__restrict__ g, int v0, int v1, int v2, int v3)
+{
+    const uint2v pk16 = { (unsigned)(v0 | (v1 << 16)), (unsigned)(v2 | (v3 << 16)) };
+    *(uint2v *)lds = pk16;                                           /* 8-byte aligned by construction */
+    if (sizeof(PX) == 1) *(GLOBAL uint32_t *)g = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+    else                 *(GLOBAL uint2v *)g = pk16;
+}
+
+/* constrained_intra_pred (hevcpred_template.c:185-286) for one block, run by ONE lane over the wave's edge arrays
+ * left[k] = E[1 + k], top[k] = E[67 + k] (k = -1..63) after the gather with the re-derived candidate flags.
+ * lm / tm: bit g = the 4-sample group g of the left column / top row lies in an intra CU; corner likewise. */
+typedef __attribute__((address_space(3))) int lds_int;     /* keeps the accesses ds_* (a generic pointer would make them flat_*,
+                                                              which are not ordered against ds_* of the same wave) */
+static __device__ __forceinline__ void cip_patch(lds_int *E, const int n, const int avail, const unsigned lm, const unsigned tm, const bool corner_intra,
+                                              const int size_max_x, const int size_max_y, const int bl_size,
+                                              const bool x_nz, const bool y_nz, const int bd)
+{
+    lds_int *left = E + 1, *top = E + 67;
+    bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT, a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
+    auto isl = [&](int j) { return j < 0 ? corner_intra : ((lm >> (j >> 2)) & 1) != 0; };
+    auto ist = [&](int j) { return j < 0 ? corner_intra : ((tm >> (j >> 2)) & 1) != 0; };
+    if (a_bl || a_l || a_ul || a_u || a_ur) {
+        int j = n + bl_size - 1;
+        if (a_bl || a_l || a_ul) {
+            while (j > -1 && !isl(j)) j--;
+            if (!isl(j)) {
+                j = 0;
+                while (j < size_max_x && !ist(j)) j++;
+                for (int i = j; i > -1; i--)
+                    if (!ist(i - 1)) top[i - 1] = top[i];
+                left[-1] = top[-1];
+            }
+        } else {
+            j = 0;
+            while (j < size_max_x && !ist(j)) j++;
+            if (j > 0) {
+                for (int i = j; i > (x_nz ? -1 : 0); i--)
+                    if (!ist(i - 1)) top[i - 1] = top[i];
+                if (!x_nz) top[-1] = top[0];
+            }
+        }
+        left[-1] = top[-1];
+        if (a_bl || a_l) {
+            int a = left[-1];
+            for (int i = 0; i < size_max_y; i += 4) {
+                if (!isl(i)) { left[i] = a; left[i + 1] = a; left[i + 2] = a; left[i + 3] = a; }
+                else a = left[i + 3];
+            }
+        }
+        if (!a_l)  for (int i = 0; i < n; i++) left[i] = left[-1];
+        if (!a_bl) { const int v = left[n - 1]; for (int i = 0; i < n; i++) left[n + i] = v; }
+        if (!x_nz) {
+            for (int i = 0; i < size_max_y; i++) left[i] = 0;
+        } else {
+            int a = left[size_max_y - 1];
+            for (int i = size_max_y - 1; i > -1; i -= 4) {
+                if (!isl(i - 3)) { left[i - 3] = a; left[i - 2] = a; left[i - 1] = a; left[i] = a; }
+                else a = left[i - 3];
+            }
+            if (y_nz && !corner_intra) left[-1] = left[0];
+        }
+        top[-1] = left[-1];
+        if (y_nz) {
+            int a = left[-1];
+            for (int i = 0; i < size_max_x; i += 4) {
+                if (!ist(i)) { top[i] = a; top[i + 1] = a; top[i + 2] = a; top[i + 3] = a; }
+                else a = top[i + 3];
+            }
+        }
+    }
+    /* missing samples, :251-286 */
+    if (!a_bl) {
+        if (a_l) {
+            const int v = left[n - 1];
+            for (int i = 0; i < n; i++) left[n + i] = v;
+        } else if (a_ul) {
+            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            a_l = true;
+        } else if (a_u) {
+            left[-1] = top[0];
+            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            a_ul = a_l = true;
+        } else if (a_ur) {
+            for (int i = 0; i < n; i++) top[i] = top[n];
+            left[-1] = top[n];
+            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            a_u = a_ul = a_l = true;
+        } else {
+            left[-1] = 1 << (bd - 1);
+            for (int i = 0; i < 2 * n; i++) { top[i] = left[-1]; left[i] = left[-1]; }
+        }
+    }
+    if (!a_l)  { const int v = left[n]; for (int i = 0; i < n; i++) left[i] = v; }
+    if (!a_ul) left[-1] = left[0];
+    if (!a_u)  for (int i = 0; i < n; i++) top[i] = left[-1];
+    if (!a_ur) { const int v = top[n - 1]; for (int i = 0; i < n; i++) top[n + i] = v; }
+    top[-1] = left[-1];
+}
+
+template <typename PX, bool CIP, bool STAGED>
+static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
+                                                   const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
+                                                   const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
+{
+    unsigned long long ta = 0, tb = 0, tc = 0, td = 0; (void)ta; (void)tb; (void)tc; (void)td; (void)acc;
+    STAMP(ta);
+    /* the descriptor is the same for every lane: keep it in scalar registers */
+    const uint4v q0 = item[0], q1 = item[1];
+    const uint32_t w0 = __builtin_amdgcn_readfirstlane(q0[0]), w1 = __builtin_amdgcn_readfirstlane(q0[1]);
+    const uint32_t res_off = __builtin_amdgcn_readfirstlane(q0[2]), w3 = __builtin_amdgcn_readfirstlane(q0[3]);
+    const uint32_t w4 = __builtin_amdgcn_readfirstlane(q1[0]), w5 = __builtin_amdgcn_readfirstlane(q1[1]);
+    const uint32_t res_lds = __builtin_amdgcn_readfirstlane(q1[2]);
+    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
+    const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
+    const int n = 1 << log2, cls = (flags >> 4) & 7;
+    const uint32_t w7 = __builtin_amdgcn_readfirstlane(q1[3]);           /* cip_left | cip_top << 16 */
+    const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
+    const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
+    const int i = lane;                                                /* element this lane owns */
+    const bool has_res = res_off != OH_NO_COEFF;
+    const int ngroups = (n * n) >> 2;
+
+    /* residual: requested now, consumed at the very end */
+    short4v rv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        rv[k] = short4v{ 0, 0, 0, 0 };
+        const int g = lane + 64 * k;
+        if (has_res && g < ngroups) {
+            if (STAGED) rv[k] = *(const short4v *)(res_lds_base + res_lds + 4 * g);
+            else        rv[k] = *((const GLOBAL short4v *)(f->res + res_off) + g);       /* slow path: dependent HBM load */
+        }
+    }
+
+    /* gather (:164-183) from the staged CTU: lane i owns top[i] and left[i]; branch-free addresses */
+    int tv = 0, lv = 0, cv = 0;
+    const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
+    {
+        const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
+        const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
+        if (t_ok) tv = M[top_off + ti];
+        if (l_ok) lv = M[cm_off - 1 + li * rs];
+        if (a_ul) cv = M[top_off - 1];
+    }
+    /* substitution (:251-286) in closed form: the reference's cascaded fills only ever copy one of
+     * these wave-uniform values */
+    const int l_0 = __builtin_amdgcn_readlane(lv, 0), l_n1 = __builtin_amdgcn_readlane(lv, n - 1), l_n = __builtin_amdgcn_readlane(lv, n & 63);
+    const int t_0 = __builtin_amdgcn_readlane(tv, 0), t_n1 = __builtin_amdgcn_readlane(tv, n - 1), t_n = __builtin_amdgcn_readlane(tv, n & 63);
+    int corner, left_i, top_i;
+    if (CIP && (flags & OH_IF_CIP)) {
+        /* constrained intra prediction (own kernel instantiation, so the common one carries none of this): rare, so one lane replays the reference's sweeps over the published edges
+         * (cip_patch) instead of a lane-parallel closed form */
+        const int fill = sizeof(PX) == 1 ? 128 : 0x8080;                   /* memset(.., 128, ..) over 16-bit samples, :158-160 */
+        int *E = s.E;
+        E[1 + i] = l_ok ? lv : fill;
+        E[67 + i] = t_ok ? tv : fill;
+        if (lane == 0) { E[0] = a_ul ? cv : 0; E[66] = a_ul ? cv : 128; }
+        WSYNC();
+        if (lane == 0)
+            cip_patch((lds_int *)E, n, avail, w7 & 0xffff, w7 >> 16, (flags & OH_IF_CIP_CORNER) != 0, a_ur ? n + tr_size : n, a_bl ? n + bl_size : n,
+                      a_bl ? bl_size : 0, bx != 0, by != 0, bd);
+        WSYNC();
+        left_i = E[1 + i]; top_i = E[67 + i]; corner = E[0];
+    } else if (a_bl || a_l) {
+        left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
+        corner = a_ul ? cv : (a_l ? l_0 : l_n);
+    } else {
+        corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : (1 << (bd - 1))));
+        left_i = corner;
+    }
+    if (!(CIP && (flags & OH_IF_CIP)))
+        top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
+
+    /* smoothing (:288-326) with whole-wave DPP shifts; the mode/size test was done on the host */
+    if (flags & OH_IF_FILTER) {
+        bool strong = false;
+        int t63 = 0, l63 = 0;
+        if (flags & OH_IF_STRONG_CAND) {
+            t63 = __builtin_amdgcn_readlane(top_i, 63); l63 = __builtin_amdgcn_readlane(left_i, 63);
+            const int t31 = __builtin_amdgcn_readlane(top_i, 31), l31 = __builtin_amdgcn_readlane(left_i, 31);
+            const int lim = 1 << (bd - 5);
+            strong = abs(corner + t63 - 2 * t31) < lim && abs(corner + l63 - 2 * l31) < lim;
+        }
+        if (strong) {
+            if (i < 63) {
+                top_i  = ((63 - i) * corner + (i + 1) * t63 + 32) >> 6;
+                left_i = ((63 - i) * corner + (i + 1) * l63 + 32) >> 6;
+            }
+        } else {
+            const int lp = wave_shr1(left_i, corner), ln = wave_shl1(left_i, 0);
+            const int tp = wave_shr1(top_i, corner), tn = wave_shl1(top_i, 0);
+            const int l0v = __builtin_amdgcn_readlane(left_i, 0), t0v = __builtin_amdgcn_readlane(top_i, 0);
+            if (i < 2 * n - 1) {
+                left_i = (ln + 2 * left_i + lp + 2) >> 2;
+                top_i  = (tn + 2 * top_i + tp + 2) >> 2;
+            }
+            corner = (l0v + 2 * corner + t0v + 2) >> 2;
+        }
+    }
+    /* publish the edges once */
+    int *E = s.E;
+    const int LB = 1, TB = 67;                            /* left[k] = E[LB + k], top[k] = E[TB + k] */
+    if (i < 2 * n) { E[LB + i] = left_i; E[TB + i] = top_i; }
+    if (lane == 0) { E[0] = corner; E[66] = corner; }
+    STAMP(tb);
+    WSYNC();
+    STAMP(tc);
+
+    /* prediction (:359-538): lane group g = lane + 64k owns samples 4g..4g+3 of the block (one row).
+     * One straight-line loop per mode class; all LDS reads of a group are issued before use. */
+    const bool edge = flags & OH_IF_EDGE;
+    GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) +
+                                  (size_t)by * (c ? pr.stride[1] : pr.stride[0]) + bx;
+    const int gstride = c ? pr.stride[1] : pr.stride[0];
+    uint16_t *__restrict__ cm = M + cm_off;
+#define GROUP_LOOP_BEGIN                                                                  \
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {                                       \
+        const int g = lane + 64 * k;                                                      \
+        if (g >= ngroups) break;                                                          \
+        const int y = (4 * g) >> log2, x0 = (4 * g) & (n - 1);                            \
+        int v[4];
+#define GROUP_LOOP_END                                                                    \
+        if (has_res) { _Pragma("unroll") for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[k][j], bd); } \
+        put4<PX>(cm + y * rs + x0 + 4 - 4, dst + (size_t)y * gstride + x0, v[0], v[1], v[2], v[3]);         \
+    }
+    /* note: cm already points at the block's sample (0,0) which sits at column index +4 of its row */
+    if (cls == OH_IC_PLANAR) {
+        const int tn_ = E[TB + n], ln_ = E[LB + n];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + x0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                v[j] = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - y) * tx[j] + (y + 1) * ln_ + n) >> (log2 + 1);
+            }
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_DC) {
+        int part = i < n ? left_i + top_i : 0;
+        for (int m = 1; m < n; m <<= 1) part += __shfl_xor(part, m);
+        const int dc = (__builtin_amdgcn_readlane(part, 0) + n) >> (log2 + 1);
+        const int l0_ = E[LB], t0_ = E[TB];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + x0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                int pv = dc;
+                if (edge) {                               /* :410-416 */
+                    if (x == 0 && y == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
+                    else if (y == 0)      pv = (tx[j] + 3 * dc + 2) >> 2;
+                    else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
+                }
+                v[j] = pv;
+            }
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_PURE_V) {                     /* mode 26: copy of the row above, :474-477 */
+        const int t0_ = E[TB], lm1 = E[LB - 1];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = E[TB + x0 + j];
+            if (edge && x0 == 0) v[0] = clip_px(t0_ + ((ly_ - lm1) >> 1), bd);
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_PURE_H) {                     /* mode 10: copy of the left column, :501-508 */
+        const int l0_ = E[LB], tm1 = E[TB - 1];
+        GROUP_LOOP_BEGIN
+            const int ly_ = E[LB + y];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + x0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (edge && y == 0) ? clip_px(l0_ + ((tx[j] - tm1) >> 1), bd) : ly_;
+        GROUP_LOOP_END
+    } else if (cls == OH_IC_ANG_V) {                      /* modes 18..34 except 26: one (idx, fact) per row */
+        GROUP_LOOP_BEGIN
+            const int id = ((y + 1) * angle) >> 5, fact = ((y + 1) * angle) & 31;
+            int r[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                /* ref[k] == top[k-1] for k >= 0, the projected left sample for k < 0 (:447-453) */
+                const int kk = x0 + j + id + 1;
+                r[j] = E[kk >= 0 ? TB + kk - 1 : LB - 1 + ((kk * inv_a + 128) >> 8)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = fact ? ((32 - fact) * r[j] + fact * r[j + 1] + 16) >> 5 : r[j];
+        GROUP_LOOP_END
+    } else {                                              /* modes 2..17 except 10: one (idx, fact) per column */
+        GROUP_LOOP_BEGIN
+            int r0[4], r1[4], fact[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const int id = ((x + 1) * angle) >> 5;
+                fact[j] = ((x + 1) * angle) & 31;
+                const int k0 = y + id + 1, k1 = k0 + 1;   /* ref[k] == left[k-1], projected top sample for k < 0 (:480-486) */
+                r0[j] = E[k0 >= 0 ? LB + k0 - 1 : TB - 1 + ((k0 * inv_a + 128) >> 8)];
+                r1[j] = E[k1 >= 0 ? LB + k1 - 1 : TB - 1 + ((k1 * inv_a + 128) >> 8)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = fact[j] ? ((32 - fact[j]) * r0[j] + fact[j] * r1[j] + 16) >> 5 : r0[j];
+        GROUP_LOOP_END
+    }
+#undef GROUP_LOOP_BEGIN
+#undef GROUP_LOOP_END
+    WSYNC();                                              /* this wave's edge arrays are reused by its next block */
+    STAMP(td);
+    ACC(2, ta, tb); ACC(3, tb, tc); ACC(4, tc, td);
+}
+
+/* Four blocks of <= 8x8 samples per wave, one per 16-lane slot (DPP row).  Same arithmetic as intra_block with the
+ * block descriptor held per lane instead of in scalar registers: slot-local lane reads are ds_bpermute, the smoothing
+ * shifts are DPP row shifts (they stop at the slot boundary by construction), the DC sum is an xor-butterfly inside the
+ * slot.  Blocks of a sub-level are independent, so the four of a pass need no ordering.  edges: 4 x 36 ints,
+ * per slot [0] = left[-1], [1..16] = left[0..15], [17] = top[-1], [18..33] = top[0..15]. */
+static __device__ __forceinline__ int row_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); }
+static __device__ __forceinline__ int row_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false); }
+
+template <typename PX>
+static __device__ __forceinline__ void intra_slots(const int bd, const PlaneRegs &pr, const DevIntra *__restrict__ items, const uint32_t first,
+                                                   const int count, int *__restrict__ edges, uint16_t *__restrict__ M,
+                                                   const int16_t *__restrict__ res_lds_base, const int lane)
+{
+    const int slot = lane >> 4, sl = lane & 15, base = lane & 48;
+    const bool act = slot < count;
+    const uint4v *__restrict__ item = (const uint4v *)&items[first + (act ? slot : 0)];
+    const uint4v q0 = item[0], q1 = item[1];
+    const uint32_t w0 = q0[0], w1 = q0[1], res_off = q0[2], w3 = q0[3], w4 = q1[0], w5 = q1[1], res_lds = q1[2];
+    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
+    const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
+    const int n = 1 << log2, cls = (flags >> 4) & 7, ngroups = (n * n) >> 2;
+    const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
+    const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
+    const int i = sl;                                                  /* edge element this lane owns (2n <= 16) */
+    const bool work = act && sl < ngroups;                             /* group this lane predicts */
+
+    short4v rv = short4v{ 0, 0, 0, 0 };
+    if (work && res_off != OH_NO_COEFF) rv = *(const short4v *)(res_lds_base + res_lds + 4 * sl);
+
+    int tv = 0, lv = 0, cv = 0;
+    {
+        const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
+        const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
+        const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
+        if (t_ok) tv = M[top_off + ti];
+        if (l_ok) lv = M[cm_off - 1 + __mul24(li, rs)];
+        if (a_ul) cv = M[top_off - 1];
+    }
+    const int l_0 = __shfl(lv, base), l_n1 = __shfl(lv, base + n - 1), l_n = __shfl(lv, base + (n & 15));
+    const int t_0 = __shfl(tv, base), t_n1 = __shfl(tv, base + n - 1), t_n = __shfl(tv, base + (n & 15));
+    int corner, left_i, top_i;
+    if (a_bl || a_l) {
+        left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
+        corner = a_ul ? cv : (a_l ? l_0 : l_n);
+    } else {
+        corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : (1 << (bd - 1))));
+        left_i = corner;
+    }
+    top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
+
+    if (__builtin_amdgcn_ballot_w64(act && (flags & OH_IF_FILTER)) != 0) {
+        /* smoothing (:288-326); never the strong filter here (32x32 only).  All lanes run the shifts, the flag selects. */
+        const int lp = row_shr1(left_i, corner), ln = row_shl1(left_i, 0);
+        const int tp = row_shr1(top_i, corner), tn = row_shl1(top_i, 0);
+        const int l0v = __shfl(left_i, base), t0v = __shfl(top_i, base);
+        if (flags & OH_IF_FILTER) {
+            if (i < 2 * n - 1) {
+                left_i = (ln + 2 * left_i + lp + 2) >> 2;
+                top_i  = (tn + 2 * top_i + tp + 2) >> 2;
+            }
+            corner = (l0v + 2 * corner + t0v + 2) >> 2;
+        }
+    }
+    int *E = edges + slot * 36;
+    const int LB = 1, TB = 18;                               /* left[k] = E[LB + k], top[k] = E[TB + k] */
+    if (act) {
+        E[LB + i] = left_i; E[TB + i] = top_i;               /* entries >= 2n are written too and never read */
+        if (sl == 0) { E[0] = corner; E[17] = corner; }
+    }
+    WSYNC();
+
+    const int g = sl, y = (4 * g) >> log2, x0 = (4 * g) & (n - 1);
+    const bool edge = flags & OH_IF_EDGE;
+    int v[4] = { 0, 0, 0, 0 };
+    /* the DC sum needs every lane of the slot: outside the per-group predicate (and skipped when no slot is DC) */
+    int dc = 0;
+    if (__builtin_amdgcn_ballot_w64(act && cls == OH_IC_DC) != 0) {
+        int part = i < n ? left_i + top_i : 0;
+        part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+        dc = (__shfl(part, base) + n) >> (log2 + 1);
+    }
+    if (work) {
+        if (cls == OH_IC_PLANAR) {
+            const int tn_ = E[TB + n], ln_ = E[LB + n], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                v[j] = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - y) * E[TB + x] + (y + 1) * ln_ + n) >> (log2 + 1);
+            }
+        } else if (cls == OH_IC_DC) {
+            const int l0_ = E[LB], t0_ = E[TB], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                int pv = dc;
+                if (edge) {
+                    if (x == 0 && y == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
+                    else if (y == 0)      pv = (E[TB + x] + 3 * dc + 2) >> 2;
+                    else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
+                }
+                v[j] = pv;
+            }
+        } else if (cls == OH_IC_PURE_V) {
+            const int t0_ = E[TB], lm1 = E[LB - 1], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = E[TB + x0 + j];
+            if (edge && x0 == 0) v[0] = clip_px(t0_ + ((ly_ - lm1) >> 1), bd);
+        } else if (cls == OH_IC_PURE_H) {
+            const int l0_ = E[LB], tm1 = E[TB - 1], ly_ = E[LB + y];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (edge && y == 0) ? clip_px(l0_ + ((E[TB + x0 + j] - tm1) >> 1), bd) : ly_;
+        } else if (cls == OH_IC_ANG_V) {
+            const int id = ((y + 1) * angle) >> 5, fact = ((y + 1) * angle) & 31;
+            int r[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int kk = x0 + j + id + 1;
+                r[j] = E[kk >= 0 ? TB + kk - 1 : LB - 1 + ((kk * inv_a + 128) >> 8)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = fact ? ((32 - fact) * r[j] + fact * r[j + 1] + 16) >> 5 : r[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const int id = ((x + 1) * angle) >> 5, fact = ((x + 1) * angle) & 31;
+                const int k0 = y + id + 1, k1 = k0 + 1;
+                const int r0 = E[k0 >= 0 ? LB + k0 - 1 : TB - 1 + ((k0 * inv_a + 128) >> 8)];
+                const int r1 = E[k1 >= 0 ? LB + k1 - 1 : TB - 1 + ((k1 * inv_a + 128) >> 8)];
+                v[j] = fact ? ((32 - fact) * r0 + fact * r1 + 16) >> 5 : r0;
+            }
+        }
+        if (res_off != OH_NO_COEFF) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[j], bd);
+        }
+        const int gstride = c ? pr.stride[1] : pr.stride[0];
+        GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) + (size_t)(by + y) * gstride + bx + x0;
+        put4<PX>(M + cm_off + y * rs + x0, dst, v[0], v[1], v[2], v[3]);
+    }
+    WSYNC();                                                 /* the wave's edge arrays are reused by its next pass */
+}
+
+template <typename PX, bool CIP, bool STAGED>
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t first_ctu = f->lvl_start[L.level];
+    if (blockIdx.x >= f->lvl_start[L.level + 1] - first_ctu)
+        return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *__restrict__ M = (uint16_t *)smem;                                  /* sample area, oh_ctu_areas() */
+    DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
+    uint32_t *__restrict__ sub = (uint32_t *)(smem + L.off_sub);
+    uint32_t *__restrict__ small = (uint32_t *)(smem + L.off_small);              /* per sub-level: leading blocks that go four per wave */
+    int16_t *__restrict__ res_l = (int16_t *)(smem + L.off_res);                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
+    IntraLds &edges = *(IntraLds *)(smem + L.off_wave + wave * OH_INTRA_WAVE_LDS);
+    const DevIntraCtu ctu = gload(f->ictu + first_ctu + blockIdx.x);
+    const GLOBAL uint32_t *__restrict__ ss = G_CONST(uint32_t, f->sub_start) + ctu.sub_first;
+    const OhPicParams &pp = f->pp;
+    const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc;
+    const int cx0 = (ctu.ctu % ctbw) << lc, cy0 = (ctu.ctu / ctbw) << lc;      /* luma origin of the CTU */
+    const int n_sub = min((int)ctu.n_sub, OH_MAX_CTU_BLOCKS);
+    const int bd = pp.bit_depth;
+    const OhCtuAreas ar = oh_ctu_areas(lc, pp.chroma_format_idc);
+    PlaneRegs pr;
+    pr.base[0] = (uint64_t)f->cur.p[0]; pr.base[1] = (uint64_t)f->cur.p[1]; pr.base[2] = (uint64_t)f->cur.p[2];
+    pr.stride[0] = f->cur.stride[0]; pr.stride[1] = f->cur.stride[1];
+
+    /* stage: block descriptors, sub-level table, residual blocks */
+    const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items, (uint32_t)OH_MAX_CTU_BLOCKS);
+    {
+        const GLOBAL uint4v *__restrict__ src = (const GLOBAL uint4v *)(f->intra + item0);
+        uint4v *dst = (uint4v *)items;
+        for (uint32_t e = tid; e < n_items * 2; e += nthr) dst[e] = src[e];
+        for (int e = tid; e <= n_sub; e += nthr) sub[e] = ss[e] - item0;
+        for (int e = tid; e < n_sub; e += nthr) small[e] = G_CONST(uint32_t, f->sub_small)[ctu.sub_first + e];
+        /* the CTU's residual blocks: one coalesced sweep instead of a dependent load per block */
+        const GLOBAL short4v *__restrict__ rsrc = (const GLOBAL short4v *)(f->res + ctu.res_lo);
+        if (STAGED)
+            for (uint32_t e = tid; e < ctu.res_cnt / 4; e += nthr) ((short4v *)res_l)[e] = rsrc[e];
+    }
+    /* stage the part of the CTU its blocks read (DevIntraCtu.bx0..by1): samples reconstructed by passes
+     * 1-2 (inter), the column left of the CTU and the row above it (up to 2*wc samples: the up-right CTU) —
+     * all final by the wavefront order.  Rows go as 4-sample vectors, 16 per row and step. */
+    const int nplanes = pp.chroma_format_idc ? 3 : 1;
+    for (int c = 0; c < nplanes; c++) {
+        const int hs = hsh(pp, c), vs = vsh(pp, c);
+        const int wc = (1 << lc) >> hs, hc = (1 << lc) >> vs, rs = wc + 4;
+        const int x0 = cx0 >> hs, y0 = cy0 >> vs, pw = f->cur.w[c], ph = f->cur.h[c], stride = f->cur.stride[c];
+        const int px0 = ctu.bx0 >> hs, px1 = (ctu.bx1 + (1 << hs) - 1) >> hs, py0 = ctu.by0 >> vs, py1 = (ctu.by1 + (1 << vs) - 1) >> vs;
+        const GLOBAL PX *__restrict__ g = G_CONST(PX, f->cur.p[c]);
+        uint16_t *__restrict__ Mm = M + (c == 0 ? ar.main[0] : c == 1 ? ar.main[1] : ar.main[2]);      /* selects: no indexed struct on the stack */
+        uint16_t *__restrict__ Mt = M + (c == 0 ? ar.top[0] : c == 1 ? ar.top[1] : ar.top[2]);
+        const int r0 = max(py0, 0), r1 = min(min(py1, hc), ph - y0);
+        const int cs = max(px0, 0) & ~3, ce = min(min((px1 + 3) & ~3, wc), pw - x0);
+        const int seg = tid & 15;
+        if (cs + 4 * seg < ce)
+            for (int row = r0 + (tid >> 4); row < r1; row += nthr >> 4)
+                *(uint2v *)&Mm[row * rs + cs + 4 * seg + 4] = load4_pairs(g + (size_t)(y0 + row) * stride + x0 + cs + 4 * seg);
+        if (px0 < 0 && x0 > 0)
+            for (int row = r0 + tid; row < r1; row += nthr)
+                Mm[row * rs + 3] = g[(size_t)(y0 + row) * stride + x0 - 1];
+        if (py0 < 0 && y0 > 0) {
+            const int t0 = max(px0, x0 > 0 ? -1 : 0), t1 = min(min(px1, 2 * wc), pw - x0);
+            for (int xx = t0 + tid; xx < t1; xx += nthr)
+                Mt[xx + 4] = g[(size_t)(y0 - 1) * stride + x0 + xx];
+        }
+    }
+    __syncthreads();
+    unsigned long long acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t0 = 0, t1 = 0, t2 = 0, tk = 0, rt1 = 0; (void)acc; (void)t0; (void)t1; (void)t2; (void)tk; (void)rt1;
+#ifdef OH_STAMPS
+    STAMP(tk);
+    rt1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    for (int s = 0; s < n_sub; s++) {
+        STAMP(t0);
+        /* units of the sub-level: groups of up to four <=8x8 blocks (one 16-lane slot each), then the bigger blocks one
+         * per wave; the slot path needs the residual staged in LDS and has no constrained-intra variant */
+        const uint32_t b0 = sub[s], b1 = sub[s + 1], ns = (STAGED && !CIP) ? min(small[s], b1 - b0) : 0u;
+        const uint32_t ngrp = (ns + 3) >> 2, nunits = ngrp + (b1 - b0 - ns);
+        for (uint32_t u = wave; u < nunits; u += nwaves) {
+            if (u < ngrp)
+                intra_slots<PX>(bd, pr, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), edges.E, M, res_l, lane);
+            else
+                intra_block<PX, CIP, STAGED>(f, bd, pr, (const uint4v *)&items[b0 + ns + (u - ngrp)], edges, M, res_l, lane, acc);
+        }
+        STAMP(t1);
+        LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
+        STAMP(t2);
+        ACC(0, t0, t1); ACC(1, t1, t2);
+    }
+#ifdef OH_STAMPS
+    if (f->dbg && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0) {
+        unsigned long long te; STAMP(te);
+        unsigned long long rt2 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long slot = atomicAdd((unsigned long long *)f->dbg, 1ull);
+        if (slot < 4000) {
+            unsigned long long *o = (unsigned long long *)f->dbg + 16 + slot * 16;
+            o[0] = n_sub; o[1] = te - tk; o[2] = rt2 - rt1; o[3] = acc[0]; o[4] = acc[1]; o[5] = acc[2]; o[6] = acc[3]; o[7] = acc[4];
+            o[8] = gridDim.x; o[9] = n_items; o[10] = tk;
+        }
+    }
+#endif
+}
+
+/* =========================================================================================
+ * launcher
+ * ======================================================================================= */
+int ohk_init_intra(void)
+{
+    /* the intra kernel's LDS block is sized per launch and exceeds 64 KiB for 4:4:4 CTUs full of 4x4 blocks */
+    const int max_lds = 128 * 1024;
+    const void *intra_kernels[8] = {
+        (const void *)intra_ctu_kernel<uint8_t, false, false>, (const void *)intra_ctu_kernel<uint8_t, false, true>,
+        (const void *)intra_ctu_kernel<uint8_t, true, false>, (const void *)intra_ctu_kernel<uint8_t, true, true>,
+        (const void *)intra_ctu_kernel<uint16_t, false, false>, (const void *)intra_ctu_kernel<uint16_t, false, true>,
+        (const void *)intra_ctu_kernel<uint16_t, true, false>, (const void *)intra_ctu_kernel<uint16_t, true, true> };
+    for (const void *k : intra_kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+            return -1;
+    return 0;
+}
+
+extern "C" void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st)
+{
+    if (!max_ctu) return;
+    dim3 g(max_ctu, n), b(64 * l->waves);
+    /* instantiations: constrained intra pred carries a slow path the common one must not pay for; STAGED = every CTU of the
+     * launch has its residual span in LDS (otherwise the blocks read it from HBM) */
+#define INTRA_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_ctu_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l)
+#define INTRA_BY_FLAGS(PX)                                                                     \
+    do {                                                                                       \
+        if (p->constrained_intra_pred) { if (l->staged) INTRA_LAUNCH(PX, true, true); else INTRA_LAUNCH(PX, true, false); }   \
+        else                           { if (l->staged) INTRA_LAUNCH(PX, false, true); else INTRA_LAUNCH(PX, false, false); } \
+    } while (0)
+    if (p->bit_depth == 8) INTRA_BY_FLAGS(uint8_t); else INTRA_BY_FLAGS(uint16_t);
+#undef INTRA_BY_FLAGS
+#undef INTRA_LAUNCH
+}

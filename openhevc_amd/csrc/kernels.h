@@ -1,4 +1,4 @@
-/* kernels.h — launchers of kernels.hip (internal to libohevc_hip.so) */
+/* kernels.h — launchers of the per-pass kernel files (mc / residual / intra / deblock / sao / upsample .hip) (internal to libohevc_hip.so) */
 #ifndef OHEVC_KERNELS_H
 #define OHEVC_KERNELS_H
 

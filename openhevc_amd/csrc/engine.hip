@@ -712,7 +712,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
                 if (p.strong_intra_smoothing && c == 0 && log2 == 5) flags |= OH_IF_STRONG_CAND;
             }
         }
-        if (c == 0 && n < 32) flags |= OH_IF_EDGE;
+        if (c == 0 && n < 32 && (mode == 1 || mode == 10 || mode == 26)) flags |= OH_IF_EDGE;     /* :410-416, :474-477, :501-508 */
         if (mode == 0) cls = OH_IC_PLANAR;
         else if (mode == 1) cls = OH_IC_DC;
         else if (mode == 26) cls = OH_IC_PURE_V;
@@ -813,7 +813,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             else big.push_back(dintra[b]);
         }
         for (size_t k = 0; k < big.size(); k++) dintra[w + k] = big[k];
-        sub_small[j] = p.constrained_intra_pred ? 0u : w - b0;
+        static const char *smin = getenv("OHEVC_INTRA_SLOT_MIN");      /* experiments: sub-levels of up to this many blocks go one block per wave */
+        sub_small[j] = p.constrained_intra_pred || (smin && b1 - b0 <= (uint32_t)atoi(smin)) ? 0u : w - b0;
     }
     std::vector<OhDevFrame::Level> levels(f->n_intra ? f->n_levels : 0);
     for (size_t l = 0; l < levels.size(); l++) {

@@ -18,7 +18,7 @@
  *     samples with wave-uniform lane reads (v_readlane) instead of the reference's serial fills,
  *   - smooths with whole-wave DPP shifts, publishes left[]/top[] in LDS once,
  *   - predicts 4 consecutive samples per lane in a mode-class specific loop, adds the residual and
- *     writes LDS (for the next sub-level) and HBM (dword stores, never waited for).
+ *     writes the staged CTU in LDS (for the next sub-level); the finished CTU goes to HBM in one coalesced sweep.
  * Sub-levels are separated by an LDS-only workgroup barrier, so the dependent chain inside a CTU
  * costs a handful of LDS round trips per block inside one CU — no kernel launch, no HBM round
  * trip.  CTUs of one launch are mutually independent (same wavefront level, recorder.c).
@@ -41,15 +41,11 @@ struct IntraLds { int E[OH_INTRA_WAVE_LDS / 4]; };                   /* E[0..65]
 static __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 static __device__ __forceinline__ int wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
 
-struct PlaneRegs { uint64_t base[3]; int stride[2]; };               /* wave-uniform (SGPRs): [0] luma, [1] chroma */
-
-template <typename PX>
-static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, GLOBAL PX *__restrict__ g, int v0, int v1, int v2, int v3)
+/* four finished samples of one row -> the staged CTU (8-byte aligned by construction); the CTU goes to HBM in one
+ * coalesced sweep when its last sub-level is done (intra_ctu_kernel) */
+static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, int v0, int v1, int v2, int v3)
 {
-    const uint2v pk16 = { (unsigned)(v0 | (v1 << 16)), (unsigned)(v2 | (v3 << 16)) };
-    *(uint2v *)lds = pk16;                                           /* 8-byte aligned by construction */
-    if (sizeof(PX) == 1) *(GLOBAL uint32_t *)g = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-    else                 *(GLOBAL uint2v *)g = pk16;
+    *(uint2v *)lds = uint2v{ (unsigned)(v0 | (v1 << 16)), (unsigned)(v2 | (v3 << 16)) };
 }
 
 /* constrained_intra_pred (hevcpred_template.c:185-286) for one block, run by ONE lane over the wave's edge arrays
@@ -144,7 +140,7 @@ static __device__ __forceinline__ void cip_patch(lds_int *E, const int n, const 
 }
 
 template <typename PX, bool CIP, bool STAGED>
-static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd, const PlaneRegs &pr,
+static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd,
                                                    const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
                                                    const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
 {
@@ -156,7 +152,7 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const uint32_t res_off = __builtin_amdgcn_readfirstlane(q0[2]), w3 = __builtin_amdgcn_readfirstlane(q0[3]);
     const uint32_t w4 = __builtin_amdgcn_readfirstlane(q1[0]), w5 = __builtin_amdgcn_readfirstlane(q1[1]);
     const uint32_t res_lds = __builtin_amdgcn_readfirstlane(q1[2]);
-    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
+    const int bx = w0 & 0xffff, by = w0 >> 16, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
     const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
     const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
     const int n = 1 << log2, cls = (flags >> 4) & 7;
@@ -180,15 +176,12 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     }
 
     /* gather (:164-183) from the staged CTU: lane i owns top[i] and left[i]; branch-free addresses */
-    int tv = 0, lv = 0, cv = 0;
+    /* the three loads are unconditional (one wait instead of three): a value fetched for an unavailable neighbour is
+     * never selected below, and every address stays inside the workgroup's LDS block (lanes >= 2n read row 0) */
     const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
-    {
-        const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
-        const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
-        if (t_ok) tv = M[top_off + ti];
-        if (l_ok) lv = M[cm_off - 1 + li * rs];
-        if (a_ul) cv = M[top_off - 1];
-    }
+    const int ti = i < n ? i : (i < 2 * n ? (i - n < tr_size ? i : n + tr_size - 1) : 0);
+    const int li = i < n ? i : (i < 2 * n ? (i - n < bl_size ? i : n + bl_size - 1) : 0);
+    const int tv = M[top_off + ti], lv = M[cm_off - 1 + li * rs], cv = M[top_off - 1];
     /* substitution (:251-286) in closed form: the reference's cascaded fills only ever copy one of
      * these wave-uniform values */
     const int l_0 = __builtin_amdgcn_readlane(lv, 0), l_n1 = __builtin_amdgcn_readlane(lv, n - 1), l_n = __builtin_amdgcn_readlane(lv, n & 63);
@@ -256,9 +249,6 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     /* prediction (:359-538): lane group g = lane + 64k owns samples 4g..4g+3 of the block (one row).
      * One straight-line loop per mode class; all LDS reads of a group are issued before use. */
     const bool edge = flags & OH_IF_EDGE;
-    GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) +
-                                  (size_t)by * (c ? pr.stride[1] : pr.stride[0]) + bx;
-    const int gstride = c ? pr.stride[1] : pr.stride[0];
     uint16_t *__restrict__ cm = M + cm_off;
 #define GROUP_LOOP_BEGIN                                                                  \
     _Pragma("unroll") for (int k = 0; k < 4; k++) {                                       \
@@ -268,9 +258,8 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
         int v[4];
 #define GROUP_LOOP_END                                                                    \
         if (has_res) { _Pragma("unroll") for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[k][j], bd); } \
-        put4<PX>(cm + y * rs + x0 + 4 - 4, dst + (size_t)y * gstride + x0, v[0], v[1], v[2], v[3]);         \
+        put4(cm + y * rs + x0, v[0], v[1], v[2], v[3]);                                                    \
     }
-    /* note: cm already points at the block's sample (0,0) which sits at column index +4 of its row */
     if (cls == OH_IC_PLANAR) {
         const int tn_ = E[TB + n], ln_ = E[LB + n];
         GROUP_LOOP_BEGIN
@@ -369,16 +358,18 @@ static __device__ __forceinline__ int row_shr1(int v, int fill) { return __built
 static __device__ __forceinline__ int row_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false); }
 
 template <typename PX>
-static __device__ __forceinline__ void intra_slots(const int bd, const PlaneRegs &pr, const DevIntra *__restrict__ items, const uint32_t first,
+static __device__ __forceinline__ void intra_slots(const int bd, const DevIntra *__restrict__ items, const uint32_t first,
                                                    const int count, int *__restrict__ edges, uint16_t *__restrict__ M,
-                                                   const int16_t *__restrict__ res_lds_base, const int lane)
+                                                   const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
 {
+    unsigned long long sa = 0, sb = 0, sc = 0, sd = 0, se = 0; (void)sa; (void)sb; (void)sc; (void)sd; (void)se;
+    STAMP(sa);
     const int slot = lane >> 4, sl = lane & 15, base = lane & 48;
     const bool act = slot < count;
     const uint4v *__restrict__ item = (const uint4v *)&items[first + (act ? slot : 0)];
     const uint4v q0 = item[0], q1 = item[1];
-    const uint32_t w0 = q0[0], w1 = q0[1], res_off = q0[2], w3 = q0[3], w4 = q1[0], w5 = q1[1], res_lds = q1[2];
-    const int bx = w0 & 0xffff, by = w0 >> 16, c = w1 & 0xff, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
+    const uint32_t w1 = q0[1], res_off = q0[2], w3 = q0[3], w4 = q1[0], w5 = q1[1], res_lds = q1[2];
+    const int log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
     const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
     const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
     const int n = 1 << log2, cls = (flags >> 4) & 7, ngroups = (n * n) >> 2;
@@ -387,18 +378,26 @@ static __device__ __forceinline__ void intra_slots(const int bd, const PlaneRegs
     const int i = sl;                                                  /* edge element this lane owns (2n <= 16) */
     const bool work = act && sl < ngroups;                             /* group this lane predicts */
 
-    short4v rv = short4v{ 0, 0, 0, 0 };
-    if (work && res_off != OH_NO_COEFF) rv = *(const short4v *)(res_lds_base + res_lds + 4 * sl);
-
-    int tv = 0, lv = 0, cv = 0;
-    {
-        const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
-        const int ti = i < n ? i : (i - n < tr_size ? i : n + tr_size - 1);
-        const int li = i < n ? i : (i - n < bl_size ? i : n + bl_size - 1);
-        if (t_ok) tv = M[top_off + ti];
-        if (l_ok) lv = M[cm_off - 1 + __mul24(li, rs)];
-        if (a_ul) cv = M[top_off - 1];
+    /* lane group g = sl: four samples of one line of the block — a row (o = y, m0 = x0), or for the horizontal modes a
+     * column (o = x, m0 = y0): transposed, those modes are the vertical ones with left[] and top[] swapped */
+    const bool is_h = cls == OH_IC_ANG_H || cls == OH_IC_PURE_H;
+    const int o = (4 * sl) >> log2, m0 = (4 * sl) & (n - 1);
+    int rv[4] = { 0, 0, 0, 0 };
+    if (work && res_off != OH_NO_COEFF) {
+        const int16_t *__restrict__ rp = res_lds_base + res_lds;
+        if (is_h) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) rv[j] = rp[((m0 + j) << log2) + o];
+        } else {
+            const short4v r4 = *(const short4v *)(rp + 4 * sl);
+            rv[0] = r4[0]; rv[1] = r4[1]; rv[2] = r4[2]; rv[3] = r4[3];
+        }
     }
+
+    /* unconditional loads, one wait (see intra_block): lanes >= 2n and unavailable neighbours fetch values nobody selects */
+    const int ti = i < n ? i : (i < 2 * n ? (i - n < tr_size ? i : n + tr_size - 1) : 0);
+    const int li = i < n ? i : (i < 2 * n ? (i - n < bl_size ? i : n + bl_size - 1) : 0);
+    const int tv = M[top_off + ti], lv = M[cm_off - 1 + __mul24(li, rs)], cv = M[top_off - 1];
     const int l_0 = __shfl(lv, base), l_n1 = __shfl(lv, base + n - 1), l_n = __shfl(lv, base + (n & 15));
     const int t_0 = __shfl(tv, base), t_n1 = __shfl(tv, base + n - 1), t_n = __shfl(tv, base + (n & 15));
     int corner, left_i, top_i;
@@ -415,15 +414,15 @@ static __device__ __forceinline__ void intra_slots(const int bd, const PlaneRegs
         /* smoothing (:288-326); never the strong filter here (32x32 only).  All lanes run the shifts, the flag selects. */
         const int lp = row_shr1(left_i, corner), ln = row_shl1(left_i, 0);
         const int tp = row_shr1(top_i, corner), tn = row_shl1(top_i, 0);
-        const int l0v = __shfl(left_i, base), t0v = __shfl(top_i, base);
         if (flags & OH_IF_FILTER) {
+            corner = (left_i + 2 * corner + top_i + 2) >> 2;      /* only lane 0 of the slot publishes the corner: its own left[0], top[0] */
             if (i < 2 * n - 1) {
                 left_i = (ln + 2 * left_i + lp + 2) >> 2;
                 top_i  = (tn + 2 * top_i + tp + 2) >> 2;
             }
-            corner = (l0v + 2 * corner + t0v + 2) >> 2;
         }
     }
+    STAMP(sb);
     int *E = edges + slot * 36;
     const int LB = 1, TB = 18;                               /* left[k] = E[LB + k], top[k] = E[TB + k] */
     if (act) {
@@ -432,76 +431,78 @@ static __device__ __forceinline__ void intra_slots(const int bd, const PlaneRegs
     }
     WSYNC();
 
-    const int g = sl, y = (4 * g) >> log2, x0 = (4 * g) & (n - 1);
-    const bool edge = flags & OH_IF_EDGE;
+    const bool edge = flags & OH_IF_EDGE;                    /* DC / mode 10 / mode 26 of small luma blocks only (host) */
     int v[4] = { 0, 0, 0, 0 };
     /* the DC sum needs every lane of the slot: outside the per-group predicate (and skipped when no slot is DC) */
     int dc = 0;
     if (__builtin_amdgcn_ballot_w64(act && cls == OH_IC_DC) != 0) {
-        int part = i < n ? left_i + top_i : 0;
-        part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
-        dc = (__shfl(part, base) + n) >> (log2 + 1);
+        int part = i < n ? left_i + top_i : 0;                         /* sum over the slot's 16 lanes: DPP, no LDS round trips */
+        part += __builtin_amdgcn_update_dpp(0, part, 0xb1, 0xf, 0xf, false);      /* quad_perm [1,0,3,2] */
+        part += __builtin_amdgcn_update_dpp(0, part, 0x4e, 0xf, 0xf, false);      /* quad_perm [2,3,0,1] */
+        part += __builtin_amdgcn_update_dpp(0, part, 0x141, 0xf, 0xf, false);     /* row_half_mirror */
+        part += __builtin_amdgcn_update_dpp(0, part, 0x140, 0xf, 0xf, false);     /* row_mirror */
+        dc = (part + n) >> (log2 + 1);
     }
+    STAMP(sc);
     if (work) {
-        if (cls == OH_IC_PLANAR) {
-            const int tn_ = E[TB + n], ln_ = E[LB + n], ly_ = E[LB + y];
+        if (cls >= OH_IC_ANG_V) {
+            /* every angular mode incl. 10 and 26 (angle 0): one (idx, fact) per line, five consecutive reference samples;
+             * ref[k] == main[k-1] for k >= 0, the projected side sample for k < 0 (:447-453, :480-486) */
+            const int MB = is_h ? LB : TB, SB = is_h ? TB : LB;
+            const int ta = (o + 1) * angle, id = ta >> 5, fact = ta & 31;
+            int r[5];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = x0 + j;
-                v[j] = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - y) * E[TB + x] + (y + 1) * ln_ + n) >> (log2 + 1);
+            for (int j = 0; j < 5; j++) {
+                const int kk = m0 + j + id + 1;
+                r[j] = E[kk >= 0 ? MB + kk - 1 : SB - 1 + ((kk * inv_a + 128) >> 8)];
             }
-        } else if (cls == OH_IC_DC) {
-            const int l0_ = E[LB], t0_ = E[TB], ly_ = E[LB + y];
+            const int so = E[SB + o], sm1 = E[SB - 1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = ((32 - fact) * r[j] + fact * r[j + 1] + 16) >> 5;     /* fact == 0: r[j] */
+            if (edge && m0 == 0) v[0] = clip_px(r[0] + ((so - sm1) >> 1), bd);                       /* :474-477, :501-508 */
+        } else if (cls == OH_IC_PLANAR) {
+            const int tn_ = E[TB + n], ln_ = E[LB + n], ly_ = E[LB + o];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + m0 + j];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int x = x0 + j;
+                const int x = m0 + j;
+                v[j] = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - o) * tx[j] + (o + 1) * ln_ + n) >> (log2 + 1);
+            }
+        } else {
+            const int l0_ = E[LB], t0_ = E[TB], ly_ = E[LB + o];
+            int tx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tx[j] = E[TB + m0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = m0 + j;
                 int pv = dc;
-                if (edge) {
-                    if (x == 0 && y == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
-                    else if (y == 0)      pv = (E[TB + x] + 3 * dc + 2) >> 2;
+                if (edge) {                                   /* :410-416 */
+                    if (x == 0 && o == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
+                    else if (o == 0)      pv = (tx[j] + 3 * dc + 2) >> 2;
                     else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
                 }
                 v[j] = pv;
             }
-        } else if (cls == OH_IC_PURE_V) {
-            const int t0_ = E[TB], lm1 = E[LB - 1], ly_ = E[LB + y];
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = E[TB + x0 + j];
-            if (edge && x0 == 0) v[0] = clip_px(t0_ + ((ly_ - lm1) >> 1), bd);
-        } else if (cls == OH_IC_PURE_H) {
-            const int l0_ = E[LB], tm1 = E[TB - 1], ly_ = E[LB + y];
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = (edge && y == 0) ? clip_px(l0_ + ((E[TB + x0 + j] - tm1) >> 1), bd) : ly_;
-        } else if (cls == OH_IC_ANG_V) {
-            const int id = ((y + 1) * angle) >> 5, fact = ((y + 1) * angle) & 31;
-            int r[5];
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int kk = x0 + j + id + 1;
-                r[j] = E[kk >= 0 ? TB + kk - 1 : LB - 1 + ((kk * inv_a + 128) >> 8)];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = fact ? ((32 - fact) * r[j] + fact * r[j + 1] + 16) >> 5 : r[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = x0 + j;
-                const int id = ((x + 1) * angle) >> 5, fact = ((x + 1) * angle) & 31;
-                const int k0 = y + id + 1, k1 = k0 + 1;
-                const int r0 = E[k0 >= 0 ? LB + k0 - 1 : TB - 1 + ((k0 * inv_a + 128) >> 8)];
-                const int r1 = E[k1 >= 0 ? LB + k1 - 1 : TB - 1 + ((k1 * inv_a + 128) >> 8)];
-                v[j] = fact ? ((32 - fact) * r0 + fact * r1 + 16) >> 5 : r0;
-            }
         }
+        STAMP(sd);
         if (res_off != OH_NO_COEFF) {
 #pragma unroll
             for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[j], bd);
         }
-        const int gstride = c ? pr.stride[1] : pr.stride[0];
-        GLOBAL PX *__restrict__ dst = G_MUT(PX, c == 0 ? pr.base[0] : (c == 1 ? pr.base[1] : pr.base[2])) + (size_t)(by + y) * gstride + bx + x0;
-        put4<PX>(M + cm_off + y * rs + x0, dst, v[0], v[1], v[2], v[3]);
+        uint16_t *__restrict__ cm = M + cm_off;
+        if (is_h) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) cm[(m0 + j) * rs + o] = (uint16_t)v[j];
+        } else {
+            put4(cm + o * rs + m0, v[0], v[1], v[2], v[3]);
+        }
     }
     WSYNC();                                                 /* the wave's edge arrays are reused by its next pass */
+    STAMP(se);
+    ACC(5, sa, sb); ACC(6, sb, sc); ACC(7, sc, sd); ACC(8, sd, se);
 }
 
 template <typename PX, bool CIP, bool STAGED>
@@ -527,9 +528,6 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
     const int n_sub = min((int)ctu.n_sub, OH_MAX_CTU_BLOCKS);
     const int bd = pp.bit_depth;
     const OhCtuAreas ar = oh_ctu_areas(lc, pp.chroma_format_idc);
-    PlaneRegs pr;
-    pr.base[0] = (uint64_t)f->cur.p[0]; pr.base[1] = (uint64_t)f->cur.p[1]; pr.base[2] = (uint64_t)f->cur.p[2];
-    pr.stride[0] = f->cur.stride[0]; pr.stride[1] = f->cur.stride[1];
 
     /* stage: block descriptors, sub-level table, residual blocks */
     const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items, (uint32_t)OH_MAX_CTU_BLOCKS);
@@ -572,7 +570,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
         }
     }
     __syncthreads();
-    unsigned long long acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t0 = 0, t1 = 0, t2 = 0, tk = 0, rt1 = 0; (void)acc; (void)t0; (void)t1; (void)t2; (void)tk; (void)rt1;
+    unsigned long long acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, t0 = 0, t1 = 0, t2 = 0, tk = 0, rt1 = 0; (void)acc; (void)t0; (void)t1; (void)t2; (void)tk; (void)rt1;
 #ifdef OH_STAMPS
     STAMP(tk);
     rt1 = __builtin_amdgcn_s_memrealtime();
@@ -586,14 +584,35 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
         const uint32_t ngrp = (ns + 3) >> 2, nunits = ngrp + (b1 - b0 - ns);
         for (uint32_t u = wave; u < nunits; u += nwaves) {
             if (u < ngrp)
-                intra_slots<PX>(bd, pr, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), edges.E, M, res_l, lane);
+                intra_slots<PX>(bd, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), edges.E, M, res_l, lane, acc);
             else
-                intra_block<PX, CIP, STAGED>(f, bd, pr, (const uint4v *)&items[b0 + ns + (u - ngrp)], edges, M, res_l, lane, acc);
+                intra_block<PX, CIP, STAGED>(f, bd, (const uint4v *)&items[b0 + ns + (u - ngrp)], edges, M, res_l, lane, acc);
         }
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */
         STAMP(t2);
         ACC(0, t0, t1); ACC(1, t1, t2);
+    }
+    /* the reconstructed CTU goes to HBM in one coalesced sweep: the staged rectangle inside the CTU (it covers every
+     * block; samples of inter blocks in it are rewritten with the values they were staged with).  The last sub-level's
+     * barrier has been passed. */
+    for (int c = 0; c < nplanes; c++) {
+        const int hs = hsh(pp, c), vs = vsh(pp, c);
+        const int wc = (1 << lc) >> hs, hc = (1 << lc) >> vs, rs = wc + 4;
+        const int x0 = cx0 >> hs, y0 = cy0 >> vs, pw = f->cur.w[c], ph = f->cur.h[c], stride = f->cur.stride[c];
+        const int px0 = ctu.bx0 >> hs, px1 = (ctu.bx1 + (1 << hs) - 1) >> hs, py0 = ctu.by0 >> vs, py1 = (ctu.by1 + (1 << vs) - 1) >> vs;
+        GLOBAL PX *__restrict__ g = G_MUT(PX, f->cur.p[c]);
+        const uint16_t *__restrict__ Mm = M + (c == 0 ? ar.main[0] : c == 1 ? ar.main[1] : ar.main[2]);
+        const int r0 = max(py0, 0), r1 = min(min(py1, hc), ph - y0);
+        const int cs = max(px0, 0) & ~3, ce = min(min((px1 + 3) & ~3, wc), pw - x0);
+        const int seg = tid & 15;
+        if (cs + 4 * seg < ce)
+            for (int row = r0 + (tid >> 4); row < r1; row += nthr >> 4) {
+                const uint2v pk = *(const uint2v *)&Mm[row * rs + cs + 4 * seg + 4];
+                GLOBAL PX *__restrict__ d = g + (size_t)(y0 + row) * stride + x0 + cs + 4 * seg;
+                if (sizeof(PX) == 1) *(GLOBAL uint32_t *)d = __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200);
+                else                 *(GLOBAL uint2v *)d = pk;
+            }
     }
 #ifdef OH_STAMPS
     if (f->dbg && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0) {
@@ -603,7 +622,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
         if (slot < 4000) {
             unsigned long long *o = (unsigned long long *)f->dbg + 16 + slot * 16;
             o[0] = n_sub; o[1] = te - tk; o[2] = rt2 - rt1; o[3] = acc[0]; o[4] = acc[1]; o[5] = acc[2]; o[6] = acc[3]; o[7] = acc[4];
-            o[8] = gridDim.x; o[9] = n_items; o[10] = tk;
+            o[8] = gridDim.x; o[9] = n_items; o[10] = tk; o[11] = acc[5]; o[12] = acc[6]; o[13] = acc[7]; o[14] = acc[8];
         }
     }
 #endif

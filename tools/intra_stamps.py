@@ -45,6 +45,8 @@ def main():
               f"= block work {r[:, 3].sum() / nsub.sum():.0f} + barrier wait {r[:, 4].sum() / nsub.sum():.0f}")
         print(f"  inside a block: gather+substitute+smooth {r[:, 5].sum() / nsub.sum():.0f}, publish {r[:, 6].sum() / nsub.sum():.0f}, "
               f"predict+store {r[:, 7].sum() / nsub.sum():.0f}  (per sub-level, wave 0 only)")
+        print(f"  inside a four-block pass: descriptors+gather+smooth {r[:, 11].sum() / nsub.sum():.0f}, publish+DC {r[:, 12].sum() / nsub.sum():.0f}, "
+              f"predict {r[:, 13].sum() / nsub.sum():.0f}, add+store {r[:, 14].sum() / nsub.sum():.0f}  (per sub-level, wave 0 only)")
         big = r[np.argsort(-cyc)[:5]]
         for row in big:
             print(f"    n_sub {int(row[0]):3d} blocks {int(row[9]):3d} grid {int(row[8]):3d}: {row[1]:.0f} cycles, {row[2] * 10:.0f} ns, "

@@ -1053,7 +1053,12 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             /* a small batch cannot fill the chip anyway: spend the waves on the single picture's latency (8 as soon as
              * sub-levels hold more than ~2 blocks); a large batch is issue-bound and runs best with 4 */
             IL.waves = wenv ? (uint32_t)atoi(wenv) : par > (nb < 8 ? 2.5 : 4.5) ? 8 : par > 1.25 ? 4 : 2;
-            if (IL.waves < 1 || IL.waves > 8) IL.waves = 8;
+            if (IL.waves != 2 && IL.waves != 4 && IL.waves != 8) IL.waves = 8;
+            /* sub-levels go round-robin to `phases` groups of waves (intra.hip): a group prepares its next sub-level while
+             * the others finish theirs */
+            static const char *penv = getenv("OHEVC_INTRA_PHASES");
+            IL.phases = penv ? (uint32_t)atoi(penv) : 2u;
+            if (IL.phases < 1 || IL.phases > IL.waves || IL.waves % IL.phases) IL.phases = 2;
             size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
             IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
             IL.off_sub = (uint32_t)off;   off += ((size_t)max_sub + 1) * sizeof(uint32_t);

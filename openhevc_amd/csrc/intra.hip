@@ -350,21 +350,38 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
 }
 
 /* Four blocks of <= 8x8 samples per wave, one per 16-lane slot (DPP row).  Same arithmetic as intra_block with the
- * block descriptor held per lane instead of in scalar registers: slot-local lane reads are ds_bpermute, the smoothing
- * shifts are DPP row shifts (they stop at the slot boundary by construction), the DC sum is an xor-butterfly inside the
- * slot.  Blocks of a sub-level are independent, so the four of a pass need no ordering.  edges: 4 x 36 ints,
+ * block descriptor held per lane instead of in scalar registers, split in two halves:
+ *
+ *   slots_prepare  everything that does not depend on sample values: descriptor decode, the LDS address each lane's
+ *                  left[i] / top[i] / corner comes from with the substitution (:251-286) ALREADY resolved (the
+ *                  reference's cascaded fills only ever copy one of a few fixed samples, so picking the source is
+ *                  address arithmetic), the edge-array indices the lane's prediction will read, its residual;
+ *   slots_finish   the dependent chain: three sample loads, smoothing (DPP row shifts, which stop at the slot
+ *                  boundary by construction), publish, seven edge reads, the mode-class arithmetic, residual, store.
+ *
+ * A sub-level can only start when the previous one is in LDS, but its slots_prepare can run before that: the kernel
+ * deals the sub-levels round-robin to K groups of waves, so a group prepares its next sub-level while others finish theirs.
+ * Blocks of a sub-level are independent, so the four of a pass need no ordering.  edges: 4 x 36 ints,
  * per slot [0] = left[-1], [1..16] = left[0..15], [17] = top[-1], [18..33] = top[0..15]. */
 static __device__ __forceinline__ int row_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); }
 static __device__ __forceinline__ int row_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false); }
 
-template <typename PX>
-static __device__ __forceinline__ void intra_slots(const int bd, const DevIntra *__restrict__ items, const uint32_t first,
-                                                   const int count, int *__restrict__ edges, uint16_t *__restrict__ M,
-                                                   const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
+enum { SLOT_LB = 1, SLOT_TB = 18 };                          /* left[k] = E[SLOT_LB + k], top[k] = E[SLOT_TB + k] */
+enum { SS_ACT = 1, SS_WORK = 2, SS_H = 4, SS_FILTER = 8, SS_EDGE = 16, SS_RES = 32, SS_SMOOTH_LANE = 64 };
+struct SlotState {                                           /* per lane, carried from slots_prepare to slots_finish */
+    int src_l, src_t, src_c;                                 /* M indices of the samples that become left[i], top[i], corner */
+    int e[7];                                                /* indices into the slot's E read by the prediction */
+    int rv[4];                                               /* residual of the lane's four samples */
+    int dst, dstep;                                          /* M index of the lane's first sample; step to the next (column lines) */
+    int bits;                                                /* SS_* | cls << 8 | log2 << 12 | fact << 16 */
+};
+
+static __device__ __forceinline__ void slots_prepare(SlotState &st, const DevIntra *__restrict__ items, const uint32_t first, const int count,
+                                                     const int16_t *__restrict__ res_lds_base, const int lane)
 {
-    unsigned long long sa = 0, sb = 0, sc = 0, sd = 0, se = 0; (void)sa; (void)sb; (void)sc; (void)sd; (void)se;
-    STAMP(sa);
-    const int slot = lane >> 4, sl = lane & 15, base = lane & 48;
+    /* straight-line code: every choice is a select (the compiler would turn if/else into exec-mask branches, and
+     * this runs beside the dependent chain of the sub-level before) */
+    const int slot = lane >> 4, sl = lane & 15;
     const bool act = slot < count;
     const uint4v *__restrict__ item = (const uint4v *)&items[first + (act ? slot : 0)];
     const uint4v q0 = item[0], q1 = item[1];
@@ -376,47 +393,78 @@ static __device__ __forceinline__ void intra_slots(const int bd, const DevIntra 
     const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
     const bool a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
     const int i = sl;                                                  /* edge element this lane owns (2n <= 16) */
-    const bool work = act && sl < ngroups;                             /* group this lane predicts */
+    const bool work = act && sl < ngroups;                             /* line this lane predicts */
 
     /* lane group g = sl: four samples of one line of the block — a row (o = y, m0 = x0), or for the horizontal modes a
      * column (o = x, m0 = y0): transposed, those modes are the vertical ones with left[] and top[] swapped */
     const bool is_h = cls == OH_IC_ANG_H || cls == OH_IC_PURE_H;
     const int o = (4 * sl) >> log2, m0 = (4 * sl) & (n - 1);
-    int rv[4] = { 0, 0, 0, 0 };
-    if (work && res_off != OH_NO_COEFF) {
-        const int16_t *__restrict__ rp = res_lds_base + res_lds;
-        if (is_h) {
+    const bool has_res = res_off != OH_NO_COEFF;
+    {   /* the line's residual: unconditional loads (offset 0 of the staged span when the block has none; SS_RES guards the use) */
+        const int16_t *__restrict__ rp = res_lds_base + (has_res ? res_lds : 0u) + (is_h ? (m0 << log2) + o : 4 * sl);
+        const int step = is_h ? n : 1;
 #pragma unroll
-            for (int j = 0; j < 4; j++) rv[j] = rp[((m0 + j) << log2) + o];
-        } else {
-            const short4v r4 = *(const short4v *)(rp + 4 * sl);
-            rv[0] = r4[0]; rv[1] = r4[1]; rv[2] = r4[2]; rv[3] = r4[3];
-        }
+        for (int j = 0; j < 4; j++) st.rv[j] = rp[j * step];
     }
 
-    /* unconditional loads, one wait (see intra_block): lanes >= 2n and unavailable neighbours fetch values nobody selects */
-    const int ti = i < n ? i : (i < 2 * n ? (i - n < tr_size ? i : n + tr_size - 1) : 0);
-    const int li = i < n ? i : (i < 2 * n ? (i - n < bl_size ? i : n + bl_size - 1) : 0);
-    const int tv = M[top_off + ti], lv = M[cm_off - 1 + __mul24(li, rs)], cv = M[top_off - 1];
-    const int l_0 = __shfl(lv, base), l_n1 = __shfl(lv, base + n - 1), l_n = __shfl(lv, base + (n & 15));
-    const int t_0 = __shfl(tv, base), t_n1 = __shfl(tv, base + n - 1), t_n = __shfl(tv, base + (n & 15));
-    int corner, left_i, top_i;
-    if (a_bl || a_l) {
-        left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
-        corner = a_ul ? cv : (a_l ? l_0 : l_n);
-    } else {
-        corner = a_ul ? cv : (a_u ? t_0 : (a_ur ? t_n : (1 << (bd - 1))));
-        left_i = corner;
+    /* gather (:164-183) + substitution (:251-286) as source addresses.  M[0] holds 1 << (bit_depth - 1) (kernel prologue).
+     * Lanes >= 2n fetch row 0 / column 0: values nobody reads. */
+    {
+        const int ti = i < n ? i : (i < 2 * n ? (i - n < tr_size ? i : n + tr_size - 1) : 0);
+        const int li = i < n ? i : (i < 2 * n ? (i - n < bl_size ? i : n + bl_size - 1) : 0);
+        const int own_t = top_off + ti, own_l = cm_off - 1 + __mul24(li, rs);
+        const int l_0 = cm_off - 1, l_n1 = l_0 + __mul24(n - 1, rs), l_n = l_n1 + rs;
+        const int t_0 = top_off, t_n1 = top_off + n - 1, t_n = top_off + n, c_own = top_off - 1;
+        const bool any_l = a_bl || a_l;
+        const int c_l = a_l ? l_0 : l_n, c_t = a_u ? t_0 : (a_ur ? t_n : 0);
+        const int corner = a_ul ? c_own : (any_l ? c_l : c_t);
+        const int left_a = i < n ? (a_l ? own_l : l_n) : (a_bl ? own_l : l_n1);
+        st.src_c = corner;
+        st.src_l = any_l ? left_a : corner;
+        st.src_t = i < n ? (a_u ? own_t : corner) : (a_ur ? own_t : (a_u ? t_n1 : corner));
     }
-    top_i = i < n ? (a_u ? tv : corner) : (a_ur ? tv : (a_u ? t_n1 : corner));
 
-    if (__builtin_amdgcn_ballot_w64(act && (flags & OH_IF_FILTER)) != 0) {
+    /* the prediction's reads of the published edges (:359-538).  Angular modes incl. 10 and 26 (angle 0): one
+     * (idx, fact) per line, five consecutive reference samples; ref[k] == main[k-1] for k >= 0, the projected side sample
+     * for k < 0 (:447-453, :480-486).  Planar / DC: the four top samples of the line, left[o], and top[n], left[n] /
+     * left[0], top[0]. */
+    const int LB = SLOT_LB, TB = SLOT_TB;
+    const bool ang = cls >= OH_IC_ANG_V, planar = cls == OH_IC_PLANAR;
+    const int MB = is_h ? LB : TB, SB = is_h ? TB : LB;
+    const int ta = (o + 1) * angle, id = ta >> 5, fact = ang ? ta & 31 : 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int kk = m0 + j + id + 1;
+        const int ea = kk >= 0 ? MB + kk - 1 : SB - 1 + ((kk * inv_a + 128) >> 8);
+        st.e[j] = ang ? ea : (j < 4 ? TB + m0 + j : LB + o);
+    }
+    st.e[5] = ang ? SB + o : (planar ? TB + n : LB);
+    st.e[6] = ang ? SB - 1 : (planar ? LB + n : TB);
+    st.dst = cm_off + (is_h ? __mul24(m0, rs) + o : __mul24(o, rs) + m0);
+    st.dstep = rs;
+    st.bits = (act ? SS_ACT : 0) | (work ? SS_WORK : 0) | (is_h ? SS_H : 0) | ((flags & OH_IF_FILTER) ? SS_FILTER : 0) |
+              ((flags & OH_IF_EDGE) ? SS_EDGE : 0) | (has_res ? SS_RES : 0) | (i < 2 * n - 1 ? SS_SMOOTH_LANE : 0) |
+              (cls << 8) | (log2 << 12) | (fact << 16);
+}
+
+template <typename PX>
+static __device__ __forceinline__ void slots_finish(const SlotState &st, const int bd, int *__restrict__ edges, uint16_t *__restrict__ M,
+                                                    const int lane, unsigned long long *acc)
+{
+    unsigned long long sa = 0, sb = 0, sc = 0, sd = 0, se = 0; (void)sa; (void)sb; (void)sc; (void)sd; (void)se; (void)acc;
+    STAMP(sa);
+    const int slot = lane >> 4, sl = lane & 15, bits = st.bits;
+    const int cls = (bits >> 8) & 7, log2 = (bits >> 12) & 7, fact = bits >> 16, n = 1 << log2;
+    const bool act = bits & SS_ACT, work = bits & SS_WORK;
+    int left_i = M[st.src_l], top_i = M[st.src_t], corner = M[st.src_c];
+
+    if (__builtin_amdgcn_ballot_w64(act && (bits & SS_FILTER)) != 0) {
         /* smoothing (:288-326); never the strong filter here (32x32 only).  All lanes run the shifts, the flag selects. */
         const int lp = row_shr1(left_i, corner), ln = row_shl1(left_i, 0);
         const int tp = row_shr1(top_i, corner), tn = row_shl1(top_i, 0);
-        if (flags & OH_IF_FILTER) {
+        if (bits & SS_FILTER) {
             corner = (left_i + 2 * corner + top_i + 2) >> 2;      /* only lane 0 of the slot publishes the corner: its own left[0], top[0] */
-            if (i < 2 * n - 1) {
+            if (bits & SS_SMOOTH_LANE) {
                 left_i = (ln + 2 * left_i + lp + 2) >> 2;
                 top_i  = (tn + 2 * top_i + tp + 2) >> 2;
             }
@@ -424,19 +472,15 @@ static __device__ __forceinline__ void intra_slots(const int bd, const DevIntra 
     }
     STAMP(sb);
     int *E = edges + slot * 36;
-    const int LB = 1, TB = 18;                               /* left[k] = E[LB + k], top[k] = E[TB + k] */
     if (act) {
-        E[LB + i] = left_i; E[TB + i] = top_i;               /* entries >= 2n are written too and never read */
+        E[SLOT_LB + sl] = left_i; E[SLOT_TB + sl] = top_i;   /* entries >= 2n are written too and never read */
         if (sl == 0) { E[0] = corner; E[17] = corner; }
     }
     WSYNC();
-
-    const bool edge = flags & OH_IF_EDGE;                    /* DC / mode 10 / mode 26 of small luma blocks only (host) */
-    int v[4] = { 0, 0, 0, 0 };
-    /* the DC sum needs every lane of the slot: outside the per-group predicate (and skipped when no slot is DC) */
+    /* the DC sum needs every lane of the slot: outside the per-line predicate (and skipped when no slot is DC) */
     int dc = 0;
     if (__builtin_amdgcn_ballot_w64(act && cls == OH_IC_DC) != 0) {
-        int part = i < n ? left_i + top_i : 0;                         /* sum over the slot's 16 lanes: DPP, no LDS round trips */
+        int part = sl < n ? left_i + top_i : 0;                        /* sum over the slot's 16 lanes: DPP, no LDS round trips */
         part += __builtin_amdgcn_update_dpp(0, part, 0xb1, 0xf, 0xf, false);      /* quad_perm [1,0,3,2] */
         part += __builtin_amdgcn_update_dpp(0, part, 0x4e, 0xf, 0xf, false);      /* quad_perm [2,3,0,1] */
         part += __builtin_amdgcn_update_dpp(0, part, 0x141, 0xf, 0xf, false);     /* row_half_mirror */
@@ -445,59 +489,44 @@ static __device__ __forceinline__ void intra_slots(const int bd, const DevIntra 
     }
     STAMP(sc);
     if (work) {
-        if (cls >= OH_IC_ANG_V) {
-            /* every angular mode incl. 10 and 26 (angle 0): one (idx, fact) per line, five consecutive reference samples;
-             * ref[k] == main[k-1] for k >= 0, the projected side sample for k < 0 (:447-453, :480-486) */
-            const int MB = is_h ? LB : TB, SB = is_h ? TB : LB;
-            const int ta = (o + 1) * angle, id = ta >> 5, fact = ta & 31;
-            int r[5];
+        const int o = (4 * sl) >> log2, m0 = (4 * sl) & (n - 1);
+        int r[7], v[4];
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int kk = m0 + j + id + 1;
-                r[j] = E[kk >= 0 ? MB + kk - 1 : SB - 1 + ((kk * inv_a + 128) >> 8)];
-            }
-            const int so = E[SB + o], sm1 = E[SB - 1];
+        for (int j = 0; j < 7; j++) r[j] = E[st.e[j]];
+        if (cls >= OH_IC_ANG_V) {
 #pragma unroll
             for (int j = 0; j < 4; j++) v[j] = ((32 - fact) * r[j] + fact * r[j + 1] + 16) >> 5;     /* fact == 0: r[j] */
-            if (edge && m0 == 0) v[0] = clip_px(r[0] + ((so - sm1) >> 1), bd);                       /* :474-477, :501-508 */
+            if ((bits & SS_EDGE) && m0 == 0) v[0] = clip_px(r[0] + ((r[5] - r[6]) >> 1), bd);        /* :474-477, :501-508 */
         } else if (cls == OH_IC_PLANAR) {
-            const int tn_ = E[TB + n], ln_ = E[LB + n], ly_ = E[LB + o];
-            int tx[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) tx[j] = E[TB + m0 + j];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int x = m0 + j;
-                v[j] = ((n - 1 - x) * ly_ + (x + 1) * tn_ + (n - 1 - o) * tx[j] + (o + 1) * ln_ + n) >> (log2 + 1);
+                v[j] = ((n - 1 - x) * r[4] + (x + 1) * r[5] + (n - 1 - o) * r[j] + (o + 1) * r[6] + n) >> (log2 + 1);
             }
         } else {
-            const int l0_ = E[LB], t0_ = E[TB], ly_ = E[LB + o];
-            int tx[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) tx[j] = E[TB + m0 + j];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int x = m0 + j;
                 int pv = dc;
-                if (edge) {                                   /* :410-416 */
-                    if (x == 0 && o == 0) pv = (l0_ + 2 * dc + t0_ + 2) >> 2;
-                    else if (o == 0)      pv = (tx[j] + 3 * dc + 2) >> 2;
-                    else if (x == 0)      pv = (ly_ + 3 * dc + 2) >> 2;
+                if (bits & SS_EDGE) {                         /* :410-416 */
+                    if (x == 0 && o == 0) pv = (r[5] + 2 * dc + r[6] + 2) >> 2;
+                    else if (o == 0)      pv = (r[j] + 3 * dc + 2) >> 2;
+                    else if (x == 0)      pv = (r[4] + 3 * dc + 2) >> 2;
                 }
                 v[j] = pv;
             }
         }
         STAMP(sd);
-        if (res_off != OH_NO_COEFF) {
+        if (bits & SS_RES) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[j], bd);
+            for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + st.rv[j], bd);
         }
-        uint16_t *__restrict__ cm = M + cm_off;
-        if (is_h) {
+        uint16_t *__restrict__ d = M + st.dst;
+        if (bits & SS_H) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) cm[(m0 + j) * rs + o] = (uint16_t)v[j];
+            for (int j = 0; j < 4; j++) d[j * st.dstep] = (uint16_t)v[j];
         } else {
-            put4(cm + o * rs + m0, v[0], v[1], v[2], v[3]);
+            put4(d, v[0], v[1], v[2], v[3]);
         }
     }
     WSYNC();                                                 /* the wave's edge arrays are reused by its next pass */
@@ -569,6 +598,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
                 Mt[xx + 4] = g[(size_t)(y0 - 1) * stride + x0 + xx];
         }
     }
+    if (tid == 0) M[0] = (uint16_t)(1 << (bd - 1));          /* the substitute when no neighbour exists at all (:251-257); a padding cell */
     __syncthreads();
     unsigned long long acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, t0 = 0, t1 = 0, t2 = 0, tk = 0, rt1 = 0; (void)acc; (void)t0; (void)t1; (void)t2; (void)tk; (void)rt1;
 #ifdef OH_STAMPS
@@ -576,17 +606,41 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const O
     rt1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    for (int s = 0; s < n_sub; s++) {
+    /* Sub-level s belongs to the waves of phase s % K (K = L.phases): while they finish s (the dependent chain), the
+     * waves that finished s-1 prepare their first four-block pass of s-1+K (everything that needs no samples) and then
+     * sit out the sub-levels in between.  Units of a sub-level: groups of up to four <=8x8 blocks (one 16-lane slot
+     * each), then the bigger blocks one per wave; the slot path needs the residual staged in LDS and has no
+     * constrained-intra variant. */
+    const int K = (int)L.phases, ph = wave % K, wi = wave / K, nwk = nwaves / K;
+    SlotState st;
+    bool ready = false;                                      /* st holds the prepared unit `wi` of this wave's next sub-level */
+    uint32_t b0 = 0, ns = 0, nunits = 0;                     /* this wave's next sub-level: first block, blocks in slots, units */
+    auto prepare = [&](int s) {
+        const uint32_t s0 = sub[s], s1 = sub[s + 1];
+        b0 = s0;
+        ns = (STAGED && !CIP) ? min(small[s], s1 - s0) : 0u;
+        nunits = ((ns + 3) >> 2) + (s1 - s0 - ns);
+        ready = (uint32_t)wi < ((ns + 3) >> 2);
+        if (ready)
+            slots_prepare(st, items, b0 + 4 * wi, (int)min(4u, ns - 4 * wi), res_l, lane);
+    };
+    if (ph < n_sub) prepare(ph);
+    for (int s = 0, sp = 0; s < n_sub; s++, sp = sp + 1 == K ? 0 : sp + 1) {      /* sp = s % K */
         STAMP(t0);
-        /* units of the sub-level: groups of up to four <=8x8 blocks (one 16-lane slot each), then the bigger blocks one
-         * per wave; the slot path needs the residual staged in LDS and has no constrained-intra variant */
-        const uint32_t b0 = sub[s], b1 = sub[s + 1], ns = (STAGED && !CIP) ? min(small[s], b1 - b0) : 0u;
-        const uint32_t ngrp = (ns + 3) >> 2, nunits = ngrp + (b1 - b0 - ns);
-        for (uint32_t u = wave; u < nunits; u += nwaves) {
-            if (u < ngrp)
-                intra_slots<PX>(bd, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), edges.E, M, res_l, lane, acc);
-            else
-                intra_block<PX, CIP, STAGED>(f, bd, (const uint4v *)&items[b0 + ns + (u - ngrp)], edges, M, res_l, lane, acc);
+        if (sp == ph) {
+            const uint32_t ngrp = (ns + 3) >> 2;
+            for (uint32_t u = wi; u < nunits; u += nwk) {
+                if (u < ngrp) {
+                    if (!ready)
+                        slots_prepare(st, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), res_l, lane);
+                    ready = false;
+                    slots_finish<PX>(st, bd, edges.E, M, lane, acc);
+                } else {
+                    intra_block<PX, CIP, STAGED>(f, bd, (const uint4v *)&items[b0 + ns + (u - ngrp)], edges, M, res_l, lane, acc);
+                }
+            }
+        } else if (sp == (ph + 1 == K ? 0 : ph + 1) && s - 1 + K < n_sub) {
+            prepare(s - 1 + K);
         }
         STAMP(t1);
         LDS_BARRIER();                                    /* next sub-level reads what this one wrote to LDS */

@@ -19,6 +19,8 @@ E.lib_path = lambda: os.path.join(F.PKG_DIR, "libohevc_hip_stamps.so")
 
 def main():
     w, h = (int(v) for v in (sys.argv[1:3] or (1920, 1080)))
+    knobs = dict(kv.split("=") for kv in sys.argv[3:])          # e.g. split_pct=100
+    knobs = {k: int(v) for k, v in knobs.items()}
     p = F.pic_params(w, h)
     rec = F.Recorder(p)
     eng = E.Engine(0)
@@ -28,7 +30,7 @@ def main():
     for i in ids[:2]:
         eng.pic_upload(i, F.HostPic(p, rng=rng))
     for st, name in ((0, "I picture"), (2, "B picture")):
-        f = rec.synth(F.synth_params(st, 7), ids[2], ids[:2])
+        f = rec.synth(F.synth_params(st, 7, **knobs), ids[2], ids[:2])
         df = eng.frame_upload(f)
         for _ in range(3):
             eng.frame_execute(df)

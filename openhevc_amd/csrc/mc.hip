@@ -40,7 +40,16 @@ static __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
 }
-static __device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+/* first term of a sum: the three-operand form with the constant 0 (the compiler would clear a register and use the
+ * accumulating two-operand form) */
+static __device__ __forceinline__ int dot2z(unsigned a, unsigned b)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+/* low halves of two registers -> one pair: one byte permute */
+static __device__ __forceinline__ unsigned pack2(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
 template <typename PX, int TAPS>
 __global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
@@ -152,13 +161,15 @@ __global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        int acc = 0;
+                        int acc;
                         if (j & 1) {
+                            acc = dot2z(P[j >> 1], co[HT]);
 #pragma unroll
-                            for (int q = 0; q <= HT; q++) acc = dot2(P[(j >> 1) + q], co[HT + q], acc);
+                            for (int q = 1; q <= HT; q++) acc = dot2(P[(j >> 1) + q], co[HT + q], acc);
                         } else {
+                            acc = dot2z(P[j >> 1], co[0]);
 #pragma unroll
-                            for (int q = 0; q < HT; q++) acc = dot2(P[(j >> 1) + q], co[q], acc);
+                            for (int q = 1; q < HT; q++) acc = dot2(P[(j >> 1) + q], co[q], acc);
                         }
                         o[rr][j] = acc >> sh;
                     }
@@ -177,11 +188,11 @@ __global__ __launch_bounds__(64) void mc_kernel(const OhBatch B)
             uint2v T[HT + 1];
 #pragma unroll
             for (int q = 0; q <= HT; q++) T[q] = *(const uint2v *)&tmp[s][(rp + q) * 8 + 2 * cp];
-            int e0 = 0, e1 = 0, o0 = 0, o1 = 0;
+            int e0 = dot2z(T[0].x, co[0]), e1 = dot2z(T[0].y, co[0]), o0 = dot2z(T[0].x, co[HT]), o1 = dot2z(T[0].y, co[HT]);
 #pragma unroll
-            for (int q = 0; q < HT; q++) { e0 = dot2(T[q].x, co[q], e0); e1 = dot2(T[q].y, co[q], e1); }
+            for (int q = 1; q < HT; q++) { e0 = dot2(T[q].x, co[q], e0); e1 = dot2(T[q].y, co[q], e1); }
 #pragma unroll
-            for (int q = 0; q <= HT; q++) { o0 = dot2(T[q].x, co[HT + q], o0); o1 = dot2(T[q].y, co[HT + q], o1); }
+            for (int q = 1; q <= HT; q++) { o0 = dot2(T[q].x, co[HT + q], o0); o1 = dot2(T[q].y, co[HT + q], o1); }
             v[0] = e0 >> sh; v[1] = e1 >> sh; v[2] = o0 >> sh; v[3] = o1 >> sh;
         }
     };

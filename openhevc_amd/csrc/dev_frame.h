@@ -143,7 +143,7 @@ struct OhUpPlane {
 
 /* a batch of mutually independent pictures of one geometry: every pass is ONE launch over all of them
  * (kernel argument; the picture is picked by a grid dimension) */
-#define OH_MAX_BATCH 64
+#define OH_MAX_BATCH 32
 struct OhBatch { const DevFrame *f[OH_MAX_BATCH]; };
 
 #endif

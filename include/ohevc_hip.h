@@ -12,6 +12,7 @@
  *   hls_slice_data end / frame done                     oh_frame_submit         hevc.c:3017-3090
  *   libOpenHevcDecode before exposing a picture         oh_engine_sync          openHevcWrapper.c:130-153
  *   libOpenHevcGetOutput(Cpy), calc_md5                 oh_pic_download         openHevcWrapper.c:338-398, hevc.c:4146-4169
+ *   ff_hevc_output_frame crop + GetOutputCpy            oh_pic_download_window  hevc_refs.c:248-254, openHevcWrapper.c:353-398
  *   ff_hevc_unref_frame                                 oh_pic_free             hevc_refs.c:45-65
  *
  * All functions return 0 on success and a negative OH_E_* code otherwise; the table slots of the
@@ -76,6 +77,14 @@ int oh_pic_set_final_half(OhEngine *e, int pic_id, int half);
 /* planes: tightly described by byte strides, sample type uint8_t (8 bit) or uint16_t (>8 bit) */
 int oh_pic_upload(OhEngine *e, int pic_id, const uint8_t *const planes[3], const ptrdiff_t strides[3]);
 int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3], const ptrdiff_t strides[3]);
+
+/* output side: the picture inside its conformance window, packed — what ff_hevc_output_frame's
+ * plane-pointer offsets (hevc_refs.c:248-254) followed by libOpenHevcGetOutputCpy's row copies (openHevcWrapper.c:353-398)
+ * hand to the application.  Plane c receives ((height - top - bottom) >> vshift) rows of ((width - left - right) >> hshift)
+ * samples starting at (left >> hshift, top >> vshift); strides[] are the destination pitches in bytes (>= the row size).
+ * The copy goes through a pinned staging buffer of the engine. */
+typedef struct OhWindow { int32_t left, right, top, bottom; } OhWindow;     /* luma samples, as HEVCWindow after hevc_ps.c scaled it */
+int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *win, uint8_t *const planes[3], const ptrdiff_t strides[3]);
 
 /* SHVC inter-layer reference picture: resample the finished base-layer picture src_pic into
  * the enhancement-layer picture dst_pic, bit-exact with the reference's whole-picture slot

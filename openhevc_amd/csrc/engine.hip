@@ -417,6 +417,73 @@ extern "C" int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3]
     return OH_OK;
 }
 
+/* a pinned buffer of at least `bytes` whose previous copy has completed (uploads and downloads share the pool) */
+static OhEngine::Stage *stage_acquire(OhEngine *e, size_t bytes)
+{
+    OhEngine::Stage *sg = nullptr;
+    for (auto &c : e->stages) {
+        if (c.busy && hipEventQuery(c.done) == hipSuccess)
+            c.busy = false;
+        if (!c.busy && c.bytes >= bytes && (!sg || c.bytes < sg->bytes))
+            sg = &c;
+    }
+    if (sg)
+        return sg;
+    OhEngine::Stage c;
+    c.bytes = align_up(bytes, (size_t)4 << 20); c.busy = false; c.p = nullptr; c.done = nullptr;
+    if (hipHostMalloc(&c.p, c.bytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess) {
+        if (c.p) (void)hipHostFree(c.p);
+        return nullptr;
+    }
+    e->stages.push_back(c);
+    return &e->stages.back();
+}
+
+/* Output side of the path: the conformance-window crop of ff_hevc_output_frame (hevc_refs.c:248-254:
+ * plane pointers advanced by (left >> hshift, top >> vshift)) followed by libOpenHevcGetOutputCpy's packed row copies
+ * (openHevcWrapper.c:353-398: `height >> vshift` rows of `(width >> hshift) << pixel_shift` bytes, width / height = the cropped
+ * size).  One strided device-to-pinned copy per plane, one wait, then the rows go to the caller's pitches. */
+extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *win, uint8_t *const planes[3], const ptrdiff_t strides[3])
+{
+    if (!e || !win || !planes || !strides)
+        return OH_E_ARG;
+    Pic *p = get_pic(e, pic_id);
+    if (!p)
+        FAIL(e, OH_E_ARG, "oh_pic_download_window: unknown picture %d", pic_id);
+    const int W = p->p.width - win->left - win->right, H = p->p.height - win->top - win->bottom;
+    if (win->left < 0 || win->right < 0 || win->top < 0 || win->bottom < 0 || W <= 0 || H <= 0)
+        FAIL(e, OH_E_ARG, "oh_pic_download_window: window (%d,%d,%d,%d) leaves nothing of %dx%d", win->left, win->right, win->top, win->bottom,
+             p->p.width, p->p.height);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t bpp = p->p.bit_depth > 8 ? 2 : 1;
+    const int np = p->p.chroma_format_idc ? 3 : 1;
+    size_t row[3], rows[3], off[3], total = 0;
+    for (int c = 0; c < np; c++) {
+        const int hs = oh_hshift(&p->p, c), vs = oh_vshift(&p->p, c);
+        row[c] = (size_t)(W >> hs) * bpp; rows[c] = (size_t)(H >> vs);
+        if ((ptrdiff_t)row[c] > strides[c] || !planes[c])
+            FAIL(e, OH_E_ARG, "oh_pic_download_window: plane %d pitch %td < %zu bytes", c, strides[c], row[c]);
+        off[c] = total; total += align_up(row[c] * rows[c], 256);
+    }
+    OhEngine::Stage *sg = stage_acquire(e, total);
+    if (!sg)
+        FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", total);
+    for (int c = 0; c < np; c++) {
+        const int hs = oh_hshift(&p->p, c), vs = oh_vshift(&p->p, c);
+        const uint8_t *src = (const uint8_t *)(p->final_b ? p->b[c] : p->a[c]) + ((size_t)(win->top >> vs) * p->stride[c] + (size_t)(win->left >> hs)) * bpp;
+        HIPCHK(e, hipMemcpy2DAsync((char *)sg->p + off[c], row[c], src, (size_t)p->stride[c] * bpp, row[c], rows[c], hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (int c = 0; c < np; c++) {
+        const char *s = (const char *)sg->p + off[c];
+        if ((size_t)strides[c] == row[c])
+            memcpy(planes[c], s, row[c] * rows[c]);
+        else
+            for (size_t y = 0; y < rows[c]; y++) memcpy(planes[c] + (ptrdiff_t)y * strides[c], s + y * row[c], row[c]);
+    }
+    return OH_OK;
+}
+
 extern "C" int oh_pic_device_planes(OhEngine *e, int pic_id, void *planes[3], int32_t stride[3], int32_t width[3], int32_t height[3])
 {
     if (!e)
@@ -913,23 +980,10 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
 
     /* stage everything in one host buffer -> one H2D copy */
     auto t_alloc = tnow();
-    OhEngine::Stage *sg = nullptr;
-    for (auto &c : e->stages) {                          /* a pinned buffer whose previous copy has completed */
-        if (c.busy && hipEventQuery(c.done) == hipSuccess)
-            c.busy = false;
-        if (!c.busy && c.bytes >= copy_bytes && (!sg || c.bytes < sg->bytes))
-            sg = &c;
-    }
+    OhEngine::Stage *sg = stage_acquire(e, copy_bytes);   /* a pinned buffer whose previous copy has completed */
     if (!sg) {
-        OhEngine::Stage c;
-        c.bytes = align_up(copy_bytes, (size_t)4 << 20); c.busy = false; c.p = nullptr; c.done = nullptr;
-        if (hipHostMalloc(&c.p, c.bytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess) {
-            if (c.p) (void)hipHostFree(c.p);
-            free_dev_frame(e, df);
-            FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
-        }
-        e->stages.push_back(c);
-        sg = &e->stages.back();
+        free_dev_frame(e, df);
+        FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
     }
     void *stage = sg->p;
     for (int i = 0; i < ns; i++)

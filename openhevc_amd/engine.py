@@ -20,6 +20,10 @@ class EngineError(RuntimeError):
     pass
 
 
+class OhWindow(C.Structure):                                  # include/ohevc_hip.h
+    _fields_ = [("left", C.c_int32), ("right", C.c_int32), ("top", C.c_int32), ("bottom", C.c_int32)]
+
+
 def lib_path():
     return os.path.join(F.PKG_DIR, "libohevc_hip.so")
 
@@ -52,6 +56,7 @@ def lib():
         L.oh_pic_free.argtypes = [V, I]
         L.oh_pic_upload.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
+        L.oh_pic_download_window.argtypes = [V, I, C.POINTER(OhWindow), C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
         L.oh_frame_execute.argtypes = [V, V]
         L.oh_pic_upsample.argtypes = [V, C.c_int, C.c_int, V]
@@ -139,6 +144,23 @@ class Engine:
         d, s = self._plane_args(hp)
         self._chk(self.L.oh_pic_download(self.h, pid, d, s), "oh_pic_download")
         return hp
+
+    def pic_download_window(self, pid, params, left=0, right=0, top=0, bottom=0, pad=0):
+        """the picture inside its conformance window as packed numpy planes (pad: extra bytes per destination row, to
+        exercise pitches larger than the row)"""
+        dt = np.uint8 if params.bit_depth <= 8 else np.uint16
+        W, H = params.width - left - right, params.height - top - bottom
+        planes = []
+        for c in range(F.n_planes(params)):
+            hs = 1 if c and params.chroma_format_idc in (1, 2) else 0
+            vs = 1 if c and params.chroma_format_idc == 1 else 0
+            planes.append(np.zeros((H >> vs, (W >> hs) + pad // dt().itemsize), dt))
+        n = len(planes)
+        d = (C.c_void_p * 3)(*[pl.ctypes.data for pl in planes] + [None] * (3 - n))
+        s = (C.c_ssize_t * 3)(*[pl.strides[0] for pl in planes] + [0] * (3 - n))
+        win = OhWindow(left, right, top, bottom)
+        self._chk(self.L.oh_pic_download_window(self.h, pid, C.byref(win), d, s), "oh_pic_download_window")
+        return [pl[:, :pl.shape[1] - pad // dt().itemsize] if pad else pl for pl in planes]
 
     def pic_device_planes(self, pid):
         p = (C.c_void_p * 3)()

@@ -406,3 +406,29 @@ def test_random_configurations(eng, seed, count, max_w8, max_h8):
         n_checked += 1
         rec.close()
     assert n_checked == count
+
+
+def test_output_window_download(eng):
+    """oh_pic_download_window against the reference's output arithmetic restated with numpy slices:
+    ff_hevc_output_frame advances plane i by (left >> hshift) samples and (top >> vshift) rows (hevc_refs.c:248-254),
+    libOpenHevcGetOutputCpy then copies `height >> vshift` rows of `(width >> hshift) << pixel_shift` bytes with width / height
+    = the cropped size (openHevcWrapper.c:353-398, pitches from libOpenHevcGetPictureInfoCpy :245-300)."""
+    from openhevc_amd.engine import EngineError
+    rng = np.random.default_rng(11)
+    for (w, h, bd, cf), (l, r, t, b), pad in [((416, 240, 8, 1), (0, 0, 0, 0), 0), ((416, 240, 8, 1), (8, 16, 2, 6), 0),
+                                              ((416, 240, 10, 2), (4, 2, 1, 3), 64), ((192, 128, 12, 3), (3, 5, 7, 9), 0),
+                                              ((192, 128, 8, 0), (64, 0, 0, 64), 32), ((1920, 1080, 10, 1), (0, 0, 0, 8), 0)]:
+        p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=cf)
+        hp = F.HostPic(p, rng=rng)
+        pid = eng.pic_alloc(p)
+        eng.pic_upload(pid, hp)
+        got = eng.pic_download_window(pid, p, l, r, t, b, pad=pad)
+        W, H = w - l - r, h - t - b
+        for c, pl in enumerate(got):
+            hs, vs = (1 if c and cf in (1, 2) else 0), (1 if c and cf == 1 else 0)
+            pw = F.plane_dims(p, c)[0]
+            want = hp.planes[c][:, :pw][t >> vs:(t >> vs) + (H >> vs), l >> hs:(l >> hs) + (W >> hs)]
+            assert pl.shape == want.shape and np.array_equal(pl, want), (w, h, bd, cf, l, r, t, b, c)
+        with pytest.raises(EngineError):                    # a window that leaves nothing is refused
+            eng.pic_download_window(pid, p, w // 2, w // 2, 0, 0)
+        eng.pic_free(pid)

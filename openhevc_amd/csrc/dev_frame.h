@@ -60,7 +60,7 @@ struct OhIntraLaunch {                             /* one wavefront level of a b
     uint32_t off_items, off_sub, off_small, off_res, off_wave, lds_bytes;   /* byte offsets into the dynamic LDS block */
     uint32_t waves;                                /* waves per workgroup (CTU)                               */
     uint32_t staged;                               /* 1: every CTU of the launch has its residual span contiguous: staged in LDS */
-    uint32_t phases;                               /* sub-level s is finished by the waves with wave % phases == s % phases; divides waves */
+    uint32_t phases;                               /* sub-level s is finished by the waves with wave % phases == s % phases; >= 2, divides waves */
 };
 
 enum { OH_IF_FILTER = 1, OH_IF_STRONG_CAND = 2, OH_IF_EDGE = 4,              /* DevIntra.flags bits 0..2 */

@@ -1112,7 +1112,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
              * the others finish theirs */
             static const char *penv = getenv("OHEVC_INTRA_PHASES");
             IL.phases = penv ? (uint32_t)atoi(penv) : 2u;
-            if (IL.phases < 1 || IL.phases > IL.waves || IL.waves % IL.phases) IL.phases = 2;
+            if (IL.phases < 2 || IL.phases > IL.waves || IL.waves % IL.phases) IL.phases = 2;   /* a group prepares while another finishes: at least two */
             size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
             IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
             IL.off_sub = (uint32_t)off;   off += ((size_t)max_sub + 1) * sizeof(uint32_t);

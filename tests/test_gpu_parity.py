@@ -432,3 +432,40 @@ def test_output_window_download(eng):
         with pytest.raises(EngineError):                    # a window that leaves nothing is refused
             eng.pic_download_window(pid, p, w // 2, w // 2, 0, 0)
         eng.pic_free(pid)
+
+
+_WAVES_SCRIPT = r"""
+import sys
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
+import numpy as np
+from openhevc_amd import frame as F
+from openhevc_amd.engine import Engine
+import test_gpu_parity as T
+eng = Engine(0)
+for (w, h, bd, cf, lc, st, knobs) in [(416, 240, 8, 1, 6, 0, {{}}), (416, 240, 10, 1, 6, 2, {{"intra_pct": 60}}), (200, 136, 10, 3, 5, 0, {{"split_pct": 90}}),
+                                      (416, 240, 8, 2, 4, 0, {{"split_pct": 10}}), (1920, 1080, 10, 1, 6, 0, {{}})]:
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=cf, log2_ctb_size=lc)
+    rec = F.Recorder(p)
+    f = rec.synth(F.synth_params(st, 77, **knobs), 2, [0, 1])
+    rng = np.random.default_rng(5)
+    pics = {{0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}}
+    want, got = T.run_both(eng, p, f, pics)
+    T.assert_same(want, got, f"{{w}}x{{h}} {{bd}}-bit chroma {{cf}} ctb {{lc}}")
+    rec.close()
+eng.close()
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("waves,phases", [(2, 2), (4, 2), (8, 2), (4, 4), (8, 4), (8, 8)])
+def test_intra_wave_layouts(waves, phases):
+    """the intra kernel deals the sub-levels of a CTU to `phases` groups of its waves; the engine picks 2 / 4 / 8 waves per
+    launch from the content and 2 phases.  Force every layout (environment switches read once per process, hence the child
+    process) over I / B pictures of several formats, with and without large blocks."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OHEVC_INTRA_WAVES=str(waves), OHEVC_INTRA_PHASES=str(phases))
+    r = subprocess.run([sys.executable, "-c", _WAVES_SCRIPT.format(tests=here, root=os.path.dirname(here))], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]

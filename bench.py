@@ -73,8 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
-    ap.add_argument("--chains", type=int, default=64, help="closed GOPs (steps) in flight per GPU")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
+    ap.add_argument("--chains", type=int, default=None, help="closed GOPs (steps) in flight per GPU (default: 96; 24 for the 8K workloads, whose pictures are 100-200 MB)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
     ap.add_argument("--sparse-pct", type=int, default=0, help="%% of transform blocks handed over as quantised levels (de-quantised on the GPU) instead of dense coefficients")
@@ -118,6 +118,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     params = F.pic_params(**WORKLOADS[args.workload])
+    if args.chains is None:
+        args.chains = 96 if params.width * params.height <= 3840 * 2160 else 24
     n_chains = max(1, args.chains)
     n_streams = max(1, min(args.streams, n_chains))
     groups = [[] for _ in range(n_streams)]                # per stream: [(plan, backend, process group)], one engine

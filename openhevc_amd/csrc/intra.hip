@@ -534,8 +534,10 @@ static __device__ __forceinline__ void slots_finish(const SlotState &st, const i
     ACC(5, sa, sb); ACC(6, sb, sc); ACC(7, sc, sd); ACC(8, sd, se);
 }
 
+/* waves_per_eu(6, 8): 80 VGPRs instead of 86, i.e. six waves per SIMD instead of five for the wide B-picture launches (no spills;
+ * asking for seven or eight spills and loses more than the occupancy gains) */
 template <typename PX, bool CIP, bool STAGED>
-__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
 {
     const DevFrame *__restrict__ f = B.f[blockIdx.y];
     const uint32_t first_ctu = f->lvl_start[L.level];

@@ -11,7 +11,9 @@
  * One workgroup reconstructs one CTU.  The CTU's samples (with the one-sample border above and
  * to the left that intra_pred() gathers from, :164-183), the CTU's block descriptors and residual
  * blocks are staged in LDS once; the waves then take the blocks of the current SUB-LEVEL (blocks
- * of one sub-level never read each other).  Per block a wave
+ * of one sub-level never read each other).  Blocks of up to 8x8 samples go four per wave (slots_prepare /
+ * slots_finish below: the sample-independent half runs one sub-level ahead on other waves); a bigger block has a
+ * wave to itself (intra_block), which
  *   - reads its 32-byte descriptor (everything that depends only on the block's geometry and mode
  *     was resolved on the host at upload: LDS offsets, edge sizes, filter / class flags, angles),
  *   - gathers left[]/top[] from the staged CTU, one element per lane, and substitutes missing

@@ -122,6 +122,9 @@ def _staged(dist, group, tensor):
     return tensor.is_cuda and dist.get_backend(group) == "gloo"
 
 
+P2P_CHAINS = 8          # chains per batch_isend_irecv call (bounds the operations inside one RCCL group call)
+
+
 def run_steps_batched(chains, dist=None, exchange=None):
     """Enqueue one step of EVERY chain in lockstep.  chains: list of (plan, backend, process group); the
     chains are independent GOPs with the same schedule, so wave w of all of them is one batch of
@@ -147,10 +150,12 @@ def run_steps_batched(chains, dist=None, exchange=None):
         elif plan0.world > 1:                             # only to the ranks that reference the picture: one P2P batch per wave
             send_to, recv_from = exchange[w]
             by_group, done, landed = {}, [], []            # a batch must stay inside one communicator
-            for pl, be, group in chains:
+            for k, (pl, be, group) in enumerate(chains):
                 half = be.final_half(pl.waves[w].name)
                 buf = be.wave_tensor(w)[half]
-                ops = by_group.setdefault(id(group), [])
+                # one point-to-point group per P2P_CHAINS chains: the cut falls between the same chains on every rank, so the
+                # sends of a group always meet their receives in the peer's group of the same number
+                ops = by_group.setdefault((id(group), k // P2P_CHAINS), [])
                 stage = _staged(dist, group, buf)
                 mine = buf[pl.rank].cpu() if stage and send_to else buf[pl.rank]
                 ops += [dist.P2POp(dist.isend, mine, dst, group) for dst in send_to]

@@ -46,6 +46,10 @@ def _worker(rank, world, port, w, h, out_path, batched=False, p2p=False):
         plan2 = P.make_step_plan(world, rank, n_waves=3, n_tail=2, seed=6)
         be2 = OracleBackend(p, plan2)
         chains = [(plan, be, None), (plan2, be2, dist.new_group())]
+        if p2p:                                        # a third chain on the first one's communicator, one chain per point-to-point
+            P.P2P_CHAINS = 1                           # group call: the exchange of a wave is then cut into several calls
+            plan3 = P.make_step_plan(world, rank, n_waves=3, n_tail=2, seed=7)
+            chains.append((plan3, OracleBackend(p, plan3), None))
     for _ in range(2):                                 # two steps: buffers are reused across steps
         if batched:
             P.run_steps_batched(chains, dist, P.exchange_map(world, rank, 3, 2) if p2p else None)

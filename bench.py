@@ -199,7 +199,25 @@ def main():
                 for pic in plan_k.pictures():
                     for k, v in P.algorithmic_bytes(be_k.stats[pic.name], b).items():
                         abytes[k] += v
+            # The dominant kernel is the one with the largest total GPU time in the rocprofv3 kernel stats of this same command
+            # (profiles/, committed): with several streams sharing the chip, a pass's stream-elapsed time (below) also counts the
+            # time its launch waited for the other streams' kernels, so the largest stream-elapsed pass can flip between the
+            # intra pass and SAO from run to run (rocprofv3: sao_kernel executes 2.1 ms per launch, its stream sees 3.3 ms).
             dom = max(pass_ms, key=lambda k: pass_ms[k])
+            spath = os.path.join(ROOT, "profiles", f"r01_kernel_stats_{args.workload}.csv")
+            if os.path.exists(spath):
+                import csv
+                share = {k: 0.0 for k in pass_ms}
+                for row in csv.DictReader(open(spath)):
+                    nm = row["Name"]
+                    k = ("intra" if nm.startswith("intra_ctu_kernel") else "sao" if nm.startswith("sao_kernel") else
+                         "inter" if nm.startswith("mc_kernel") else "residual" if nm.startswith(("residual_kernel", "cross_kernel")) else
+                         "deblock_v" if nm.startswith("deblock_") and nm.rstrip().endswith(", 0>") else
+                         "deblock_h" if nm.startswith("deblock_") else None)
+                    if k:
+                        share[k] += float(row["TotalDurationNs"])
+                if any(share.values()):
+                    dom = max(share, key=lambda k: share[k])
             steps_timed = n_exec / float(pics_per_step)
             ms_per_step_pass = pass_ms[dom] / steps_timed
             # launches of the dominant pass in the timed region: every launch covers a batch of pictures

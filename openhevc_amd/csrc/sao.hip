@@ -86,19 +86,26 @@ static __device__ __forceinline__ void sao_edge8(const GLOBAL PX *__restrict__ s
 
 /* Lane -> sample mapping: a wave covers ONE CTB-wide strip (wc samples x 512/wc rows) so that the
  * SAO type / class is the same for all its lanes (no divergent band/edge paths); a workgroup of
- * 4 waves covers 4 such strips stacked vertically.  grid = (CTB columns, strips of rows, planes). */
+ * 4 waves covers 4 such strips stacked vertically.  grid = (CTB columns, strips of rows of every plane, pictures). */
 template <typename PX>
-__global__ __launch_bounds__(256) void sao_kernel(const OhBatch B, const int nplanes_)
+__global__ __launch_bounds__(256) void sao_kernel(const OhBatch B, const int strips_luma, const int strips_chroma)
 {
-    const DevFrame *__restrict__ f = B.f[blockIdx.z / nplanes_];
+    const DevFrame *__restrict__ f = B.f[blockIdx.z];
     const OhPicParams &pp = f->pp;
-    const int c = blockIdx.z % nplanes_;
+    /* grid.y: the luma strips, then the strips of Cb, then those of Cr (a chroma plane of 4:2:0 needs a quarter of the
+     * luma plane's workgroups: no workgroup is launched just to exit) */
+    int strip = blockIdx.y, c = 0;
+    if (strip >= strips_luma) {
+        strip -= strips_luma;
+        c = strip >= strips_chroma ? 2 : 1;
+        strip -= (c - 1) * strips_chroma;
+    }
     const int pw = f->cur.w[c], ph = f->cur.h[c];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int log2_gx = pp.log2_ctb_size - hsh(pp, c) - 3;            /* 8-sample groups per CTB row: 1 << log2_gx */
     const int rows_per_wave = 64 >> log2_gx;
     const int x = (blockIdx.x << (log2_gx + 3)) + ((lane & ((1 << log2_gx) - 1)) << 3);
-    const int y = (blockIdx.y * 4 + wave) * rows_per_wave + (lane >> log2_gx);
+    const int y = (strip * 4 + wave) * rows_per_wave + (lane >> log2_gx);
     if (x >= pw || y >= ph)
         return;
     const int bd = pp.bit_depth, hs = hsh(pp, c), vs = vsh(pp, c), lc = pp.log2_ctb_size;
@@ -168,11 +175,12 @@ __global__ __launch_bounds__(256) void sao_kernel(const OhBatch B, const int npl
  * ======================================================================================= */
 extern "C" void ohk_sao(const OhBatch *B, int n, const OhPicParams *p, hipStream_t st)
 {
-    /* luma geometry decides the grid; chroma planes (smaller) leave their surplus workgroups idle */
-    const int ctbw = (p->width + (1 << p->log2_ctb_size) - 1) >> p->log2_ctb_size;
-    const int rows_per_block = 4 * (64 >> (p->log2_ctb_size - 3));            /* luma: 4 waves x (512 / ctb) rows */
-    const int np = p->chroma_format_idc ? 3 : 1;
-    dim3 grid(ctbw, (p->height + rows_per_block - 1) / rows_per_block, np * n);
-    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(sao_kernel<uint8_t>), grid, dim3(256), 0, st, *B, np);
-    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(sao_kernel<uint16_t>), grid, dim3(256), 0, st, *B, np);
+    const int lc = p->log2_ctb_size, ctbw = (p->width + (1 << lc) - 1) >> lc;
+    const int hs = p->chroma_format_idc == 1 || p->chroma_format_idc == 2, vs = p->chroma_format_idc == 1;
+    const int rows_luma = 4 * (64 >> (lc - 3)), rows_chroma = 4 * (64 >> (lc - hs - 3));     /* rows per workgroup: 4 waves x (512 / CTB width) */
+    const int sl = (p->height + rows_luma - 1) / rows_luma;
+    const int sc = p->chroma_format_idc ? ((p->height >> vs) + rows_chroma - 1) / rows_chroma : 0;
+    dim3 grid(ctbw, sl + 2 * sc, n);
+    if (p->bit_depth == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(sao_kernel<uint8_t>), grid, dim3(256), 0, st, *B, sl, sc);
+    else                   hipLaunchKernelGGL(HIP_KERNEL_NAME(sao_kernel<uint16_t>), grid, dim3(256), 0, st, *B, sl, sc);
 }

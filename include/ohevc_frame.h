@@ -186,7 +186,34 @@ typedef struct OhFrame {
     /* cross-component prediction: per OhTu, for OH_TUF_CROSS blocks `luma TU index | (res_scale_val & 0xff) << 24`
      * (res_scale_val = +-1, 2, 4, 8 as a signed byte), OH_NO_COEFF otherwise; NULL when the picture has none */
     const uint32_t     *tu_cross;
+    /* boundary strengths derived on the GPU: when set, vertical_bs / horizontal_bs may be NULL and the
+     * engine computes both grids from these maps, bit-exact with ff_hevc_deblocking_boundary_strengths (hevc_filter.c:584-941) */
+    const struct OhBsInputs *bs_in;
 } OhFrame;
+
+/* one entry of the reference's motion field = MvField as compiled (TEST_MV_POC defined, hevc.h:73, 1032-1041): 24 bytes, compared
+ * as a whole by boundary_strength()'s memcmp (hevc_filter.c:600), padding included */
+typedef struct OhMvField {
+    int16_t  mv[2][2];            /* Mv mv[2]: x, y in quarter samples                        */
+    int32_t  poc[2];              /* POC of the reference picture of each list                */
+    uint32_t pred_flag;           /* PF_INTRA 0, PF_L0 1, PF_L1 2, PF_BI 3                    */
+    uint8_t  ref_idx[2];
+    uint8_t  pad[2];
+} OhMvField;
+
+/* what ff_hevc_deblocking_boundary_strengths() reads, as whole-picture maps (hevc_filter.c:805-941) */
+typedef struct OhBsInputs {
+    const OhMvField *mvf;         /* min_pu_width x min_pu_height: s->ref->tab_mvf                                                  */
+    const uint8_t   *cbf_luma;    /* min_tb_width x min_tb_height: s->cbf_luma (hevc.c:1566-1575)                                   */
+    const uint8_t   *call_log2;   /* min_tb_width x min_tb_height: log2 size of the block the function was called for at the cell
+                                     (the transform unit, hevc.c:1578, or the whole coding block, :1607 :2400 :2484); 0 = never
+                                     called there (slice_deblocking_filter_disabled_flag): both grids stay 0                        */
+    const uint8_t   *ctb_flags;   /* ctb_width x ctb_height: OH_BSF_* of the CTB's slice / position (hevc.c:2636-2637)              */
+    int32_t loop_filter_across_tiles;          /* pps->loop_filter_across_tiles_enabled_flag                                        */
+} OhBsInputs;
+enum { OH_BSF_UP_SLICE = 1, OH_BSF_UP_TILE = 2,       /* lc->slice_or_tiles_up_boundary   */
+       OH_BSF_LEFT_SLICE = 4, OH_BSF_LEFT_TILE = 8,   /* lc->slice_or_tiles_left_boundary << 2 */
+       OH_BSF_ACROSS_SLICES = 16 };                   /* s->sh.slice_loop_filter_across_slices_enabled_flag */
 
 /* ---- derived geometry helpers (all integer, shared by every consumer) ---- */
 static inline int oh_hshift(const OhPicParams *p, int c) { return c && (p->chroma_format_idc == 1 || p->chroma_format_idc == 2); }

@@ -50,6 +50,9 @@ uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size,
 /* cross-component prediction (hevc.c:1319-1365): chroma block tu_c (index from oh_rec_tu*, recorded with its own coefficients
  * or, when cbf is 0, as an OH_TU_BYPASS block of zeros) takes (res_scale_val * residual of luma block tu_y) >> 3 on top */
 int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val);
+/* boundary strengths on the GPU: instead of filling the BS grids through oh_rec_bs*(), hand over the maps
+ * ff_hevc_deblocking_boundary_strengths() reads (caller-owned until the frame is submitted; ohevc_frame.h: OhBsInputs) */
+void oh_rec_bs_inputs(OhRecorder *r, const OhBsInputs *in);
 /* scaling lists of the picture (zeroed by oh_rec_create; only read when a block names a matrix) */
 OhScalingList *oh_rec_scaling_list(OhRecorder *r);
 

@@ -40,6 +40,7 @@ struct OhRecorder {
     /* side arrays */
     uint8_t *vbs, *hbs, *is_pcm, *is_intra;
     uint32_t *sparse, *tu_sparse, *tu_cross; uint64_t cap_sparse, cap_tu_sparse, cap_tu_cross; int any_sparse, any_matrix, any_cross;
+    const OhBsInputs *bs_in;                                  /* caller-owned maps for the GPU boundary-strength pass, or NULL */
     OhScalingList scaling;
     int8_t  *qp;
     OhDeblockCtb *deblock;
@@ -119,7 +120,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     for (int i = 0; i < OH_MAX_REFS; i++)
         r->f.ref_pics[i] = i < n_ref_pics ? ref_pics[i] : -1;
     r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = r->f.n_ictu = r->f.n_sub = 0;
-    r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0; r->any_cross = 0;
+    r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0; r->any_cross = 0; r->bs_in = NULL;
     r->f.n_coeff = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
@@ -203,6 +204,11 @@ uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size,
 }
 
 OhScalingList *oh_rec_scaling_list(OhRecorder *r) { return &r->scaling; }
+
+void oh_rec_bs_inputs(OhRecorder *r, const OhBsInputs *in)
+{
+    r->bs_in = in;
+}
 
 int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
 {
@@ -377,6 +383,7 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     f->tu_sparse = r->any_sparse ? r->tu_sparse : NULL;
     f->scaling = r->any_matrix ? &r->scaling : NULL;
     f->tu_cross = r->any_cross ? r->tu_cross : NULL;
+    f->bs_in = r->bs_in;
     f->deblock = r->deblock;
     f->sao = f->p.sao_enabled ? r->sao : NULL;
     return f;

@@ -75,8 +75,26 @@ class OhFrame(C.Structure):
         ("qp_y_tab", C.POINTER(C.c_int8)), ("is_pcm", C.POINTER(C.c_uint8)),
         ("deblock", C.POINTER(OhDeblockCtb)), ("sao", C.POINTER(OhSaoCtb)), ("is_intra", C.POINTER(C.c_uint8)),
         ("n_sparse", C.c_uint32), ("sparse", C.POINTER(C.c_uint32)), ("tu_sparse", C.POINTER(C.c_uint32)),
-        ("scaling", C.c_void_p), ("tu_cross", C.POINTER(C.c_uint32)),
+        ("scaling", C.c_void_p), ("tu_cross", C.POINTER(C.c_uint32)), ("bs_in", C.c_void_p),
     ]
+
+
+def bs_size(p):
+    """oh_bs_size() of include/ohevc_frame.h: bytes of one boundary-strength grid (the reference's padded allocation)"""
+    hs = 1 if p.chroma_format_idc in (1, 2) else 0
+    vs = 1 if p.chroma_format_idc == 1 else 0
+    bw, bh = p.width >> 2, p.height >> 2
+    return max((bw + 4 * (1 << hs)) * bh, bw * (bh + 4 * (1 << vs))) + 64
+
+
+class OhMvField(C.Structure):
+    _fields_ = [("mv", (C.c_int16 * 2) * 2), ("poc", C.c_int32 * 2), ("pred_flag", C.c_uint32), ("ref_idx", C.c_uint8 * 2),
+                ("pad", C.c_uint8 * 2)]
+
+
+class OhBsInputs(C.Structure):
+    _fields_ = [("mvf", C.c_void_p), ("cbf_luma", C.c_void_p), ("call_log2", C.c_void_p), ("ctb_flags", C.c_void_p),
+                ("loop_filter_across_tiles", C.c_int32)]
 
 
 class OhSynthParams(C.Structure):

@@ -834,3 +834,98 @@ int oh_or_upsample_frame(const OhHostPic *bl, OhHostPic *el, const OhUpsample *u
     free(tmp);
     return 0;
 }
+
+/* =========================================================================================
+ * boundary strengths: ff_hevc_deblocking_boundary_strengths, hevc_filter.c:805-941, over the maps
+ * it reads, one call per block in raster order of the block origins (every edge segment is written by exactly one call,
+ * so the order of the calls does not matter).  boundary_strength() is the TEST_MV_POC / memcmp build (:584-700).
+ * ======================================================================================= */
+static int bs_abs4(int a, int b) { int d = a - b; return (d < 0 ? -d : d) >= 4; }
+
+static int bs_motion(const OhMvField *curr, const OhMvField *neigh)
+{
+    if (memcmp(curr, neigh, sizeof(OhMvField)) == 0)                                            /* :600 */
+        return 0;
+    if (curr->pred_flag == 3 && neigh->pred_flag == 3) {                                        /* both PF_BI, :603 */
+        if (curr->poc[0] == neigh->poc[0] && curr->poc[0] == curr->poc[1] && neigh->poc[0] == neigh->poc[1]) {       /* :605-607 */
+            const int straight = bs_abs4(neigh->mv[0][0], curr->mv[0][0]) || bs_abs4(neigh->mv[0][1], curr->mv[0][1]) ||
+                                 bs_abs4(neigh->mv[1][0], curr->mv[1][0]) || bs_abs4(neigh->mv[1][1], curr->mv[1][1]);
+            const int crossed  = bs_abs4(neigh->mv[1][0], curr->mv[0][0]) || bs_abs4(neigh->mv[1][1], curr->mv[0][1]) ||
+                                 bs_abs4(neigh->mv[0][0], curr->mv[1][0]) || bs_abs4(neigh->mv[0][1], curr->mv[1][1]);
+            return straight && crossed;                                                         /* :623-630 */
+        } else if (neigh->poc[0] == curr->poc[0] && neigh->poc[1] == curr->poc[1]) {            /* :632-650 */
+            return bs_abs4(neigh->mv[0][0], curr->mv[0][0]) || bs_abs4(neigh->mv[0][1], curr->mv[0][1]) ||
+                   bs_abs4(neigh->mv[1][0], curr->mv[1][0]) || bs_abs4(neigh->mv[1][1], curr->mv[1][1]);
+        } else if (neigh->poc[1] == curr->poc[0] && neigh->poc[0] == curr->poc[1]) {            /* :651-671 */
+            return bs_abs4(neigh->mv[1][0], curr->mv[0][0]) || bs_abs4(neigh->mv[1][1], curr->mv[0][1]) ||
+                   bs_abs4(neigh->mv[0][0], curr->mv[1][0]) || bs_abs4(neigh->mv[0][1], curr->mv[1][1]);
+        }
+        return 1;                                                                               /* :672-674 */
+    } else if (curr->pred_flag != 3 && neigh->pred_flag != 3) {                                 /* one vector each, :675-698 */
+        const int la = (curr->pred_flag & 1) ? 0 : 1, lb = (neigh->pred_flag & 1) ? 0 : 1;
+        if (curr->poc[la] != neigh->poc[lb])
+            return 1;
+        return bs_abs4(curr->mv[la][0], neigh->mv[lb][0]) || bs_abs4(curr->mv[la][1], neigh->mv[lb][1]);
+    }
+    return 1;                                                                                   /* :700 */
+}
+
+int oh_or_bs_derive(const OhPicParams *p, const OhBsInputs *in, uint8_t *vbs, uint8_t *hbs)
+{
+    const int lpu = p->log2_min_pu_size, ltu = p->log2_min_tb_size, lc = p->log2_ctb_size;
+    const int mpw = p->width >> lpu, mtw = p->width >> ltu, mth = p->height >> ltu, bsw = p->width >> 2, ctbw = oh_ctb_width(p);
+    memset(vbs, 0, oh_bs_size(p));
+    memset(hbs, 0, oh_bs_size(p));
+    for (int ty = 0; ty < mth; ty++)
+        for (int tx = 0; tx < mtw; tx++) {
+            const int log2 = in->call_log2[ty * mtw + tx], x0 = tx << ltu, y0 = ty << ltu;
+            if (!log2 || (x0 & ((1 << log2) - 1)) || (y0 & ((1 << log2) - 1)))
+                continue;                                       /* not the origin of a call */
+            const int size = 1 << log2;
+            const int flags = in->ctb_flags[(y0 >> lc) * ctbw + (x0 >> lc)];
+            const int is_intra = in->mvf[(y0 >> lpu) * mpw + (x0 >> lpu)].pred_flag == 0;      /* :814-815 */
+            if (y0 > 0 && (y0 & 7) == 0) {                                                      /* :818-855 */
+                const int bd_ctby = y0 & ((1 << lc) - 1);
+                const int bd_slice = (flags & OH_BSF_ACROSS_SLICES) || !(flags & OH_BSF_UP_SLICE);
+                const int bd_tiles = in->loop_filter_across_tiles || !(flags & OH_BSF_UP_TILE);
+                if ((bd_slice && bd_tiles) || bd_ctby)
+                    for (int i = 0; i < size && x0 + i < p->width; i += 4) {
+                        const OhMvField *top = &in->mvf[((y0 - 1) >> lpu) * mpw + ((x0 + i) >> lpu)];
+                        const OhMvField *curr = &in->mvf[(y0 >> lpu) * mpw + ((x0 + i) >> lpu)];
+                        const int cbf = in->cbf_luma[((y0 - 1) >> ltu) * mtw + ((x0 + i) >> ltu)] || in->cbf_luma[(y0 >> ltu) * mtw + ((x0 + i) >> ltu)];
+                        hbs[((x0 + i) + y0 * bsw) >> 2] = (uint8_t)((curr->pred_flag == 0 || top->pred_flag == 0) ? 2 : cbf ? 1 : bs_motion(curr, top));
+                    }
+            }
+            if (x0 > 0 && (x0 & 7) == 0) {                                                      /* :858-895 */
+                const int bd_ctbx = x0 & ((1 << lc) - 1);
+                const int bd_slice = (flags & OH_BSF_ACROSS_SLICES) || !(flags & OH_BSF_LEFT_SLICE);
+                const int bd_tiles = in->loop_filter_across_tiles || !(flags & OH_BSF_LEFT_TILE);
+                if ((bd_slice && bd_tiles) || bd_ctbx)
+                    for (int i = 0; i < size && y0 + i < p->height; i += 4) {
+                        const OhMvField *left = &in->mvf[((y0 + i) >> lpu) * mpw + ((x0 - 1) >> lpu)];
+                        const OhMvField *curr = &in->mvf[((y0 + i) >> lpu) * mpw + (x0 >> lpu)];
+                        const int cbf = in->cbf_luma[((y0 + i) >> ltu) * mtw + ((x0 - 1) >> ltu)] || in->cbf_luma[((y0 + i) >> ltu) * mtw + (x0 >> ltu)];
+                        vbs[(x0 + (y0 + i) * bsw) >> 2] = (uint8_t)((curr->pred_flag == 0 || left->pred_flag == 0) ? 2 : cbf ? 1 : bs_motion(curr, left));
+                    }
+            }
+            if (log2 > lpu && !is_intra) {                                                      /* :897-940: prediction-unit edges inside the block */
+                for (int i = 0; i < size && x0 + i < p->width; i += 4) {
+                    const OhMvField *top = &in->mvf[((y0 + 8 - 1) >> lpu) * mpw + ((x0 + i) >> lpu)];
+                    for (int j = 8; j < size && y0 + j < p->height; j += 8) {
+                        const OhMvField *curr = &in->mvf[((y0 + j) >> lpu) * mpw + ((x0 + i) >> lpu)];
+                        hbs[((x0 + i) + (y0 + j) * bsw) >> 2] = (uint8_t)bs_motion(curr, top);
+                        top = curr;
+                    }
+                }
+                for (int j = 0; j < size && y0 + j < p->height; j += 4) {
+                    const OhMvField *left = &in->mvf[((y0 + j) >> lpu) * mpw + ((x0 + 8 - 1) >> lpu)];
+                    for (int i = 8; i < size && x0 + i < p->width; i += 8) {
+                        const OhMvField *curr = &in->mvf[((y0 + j) >> lpu) * mpw + ((x0 + i) >> lpu)];
+                        vbs[((x0 + i) + (y0 + j) * bsw) >> 2] = (uint8_t)bs_motion(curr, left);
+                        left = curr;
+                    }
+                }
+            }
+        }
+    return 0;
+}

@@ -114,6 +114,8 @@ void oh_or_up_cr_v  (int variant, int bd, uint8_t *dst, ptrdiff_t dststride, con
 /* whole picture, 8-bit 4:2:0 only like the reference's routine (its edge code and shift are written for bytes):
  * upsample_base_layer_frame, hevcdsp_template.c:2164-2438.  el/bl: coded sizes = width[0]/height[0]. */
 int  oh_or_upsample_frame(const OhHostPic *bl, OhHostPic *el, const OhUpsample *u);
+/* boundary strengths from the maps ff_hevc_deblocking_boundary_strengths reads (hevc_filter.c:584-941); vbs / hbs: oh_bs_size(p) bytes */
+int  oh_or_bs_derive(const OhPicParams *p, const OhBsInputs *in, uint8_t *vbs, uint8_t *hbs);
 
 #ifdef __cplusplus
 }

@@ -507,3 +507,41 @@ API int ref_up_blocks(uint8_t *const el[3], const int el_stride[3], int el_w, in
     free(fb); free(fe); free(blf); free(ilr); free(ref0); free(lc); free(vps); free(sps); free(s);
     return missing;
 }
+
+/* =========================================================================================
+ * boundary strengths: the reference's own ff_hevc_deblocking_boundary_strengths (hevc_filter.c:805-941), called once per
+ * block in raster order of the block origins with the per-CTB state hls_decode_neighbour leaves in lc / s->sh
+ * (hevc.c:2636-2637).  MvField must have the layout OhMvField mirrors (TEST_MV_POC build).
+ * ======================================================================================= */
+typedef char oh_mvfield_layout_check[(sizeof(MvField) == sizeof(OhMvField)) ? 1 : -1];
+
+API int ref_bs_derive(const OhPicParams *p, const OhBsInputs *in, uint8_t *vbs, uint8_t *hbs)
+{
+    uint8_t *none[3] = { NULL, NULL, NULL };
+    ptrdiff_t nostride[3] = { 0, 0, 0 };
+    RefCtx *r = ctx_new(p, none, nostride);
+    HEVCContext *s = &r->s;
+    HEVCLocalContext *lc = &r->lc;
+    const int ltu = p->log2_min_tb_size, lcs = p->log2_ctb_size, mtw = p->width >> ltu, mth = p->height >> ltu;
+
+    memset(vbs, 0, oh_bs_size(p));
+    memset(hbs, 0, oh_bs_size(p));
+    s->bs_width = p->width >> 2; s->bs_height = p->height >> 2;
+    s->vertical_bs = vbs; s->horizontal_bs = hbs;
+    s->cbf_luma = (uint8_t *)in->cbf_luma;
+    r->ref.tab_mvf = (MvField *)in->mvf;
+    r->pps.loop_filter_across_tiles_enabled_flag = (uint8_t)in->loop_filter_across_tiles;
+    for (int ty = 0; ty < mth; ty++)
+        for (int tx = 0; tx < mtw; tx++) {
+            int log2 = in->call_log2[ty * mtw + tx], x0 = tx << ltu, y0 = ty << ltu;
+            if (!log2 || (x0 & ((1 << log2) - 1)) || (y0 & ((1 << log2) - 1)))
+                continue;
+            int flags = in->ctb_flags[(y0 >> lcs) * r->sps.ctb_width + (x0 >> lcs)];
+            lc->slice_or_tiles_up_boundary = flags & 3;
+            lc->slice_or_tiles_left_boundary = (flags >> 2) & 3;
+            s->sh.slice_loop_filter_across_slices_enabled_flag = (flags & OH_BSF_ACROSS_SLICES) != 0;
+            ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2);
+        }
+    ctx_free(r);
+    return 0;
+}

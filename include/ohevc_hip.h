@@ -103,6 +103,10 @@ int oh_frame_execute(OhEngine *e, OhDevFrame *df);
  * frame threads, pthread_frame.c) fill the GPU while each picture's own dependency chain is short of it */
 int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n);
 int oh_frame_free(OhEngine *e, OhDevFrame *df);
+/* the boundary-strength grids of an uploaded work list as the deblock pass will read them: the ones handed over, or — with
+ * OhFrame.bs_in — the ones the engine derived from the motion field at upload (hevc_filter.c:584-941).
+ * bytes: size of each destination, at most oh_bs_size() is copied */
+int oh_frame_download_bs(OhEngine *e, OhDevFrame *df, uint8_t *vbs, uint8_t *hbs, size_t bytes);
 int oh_frame_submit(OhEngine *e, const OhFrame *f);     /* upload + execute + deferred free */
 
 /* per-pass device time of the executes since the last reset, measured with HIP events on the

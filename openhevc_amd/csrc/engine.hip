@@ -659,7 +659,12 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
         }
     }
     if (p.deblock_enabled) {
-        if (!f->vertical_bs || !f->horizontal_bs || !f->qp_y_tab || !f->deblock || f->bs_size < oh_bs_size(&p))
+        const OhBsInputs *bi = f->bs_in;                      /* boundary strengths derived on the GPU instead of handed over */
+        if (bi && (!bi->mvf || !bi->cbf_luma || !bi->call_log2 || !bi->ctb_flags))
+            FAIL(e, OH_E_ARG, "bs_in: all four maps are required");
+        if (bi && (p.log2_min_pu_size < 2 || p.log2_min_tb_size < 2))
+            FAIL(e, OH_E_ARG, "bs_in: min PU / TB size below 4");
+        if ((!bi && (!f->vertical_bs || !f->horizontal_bs || f->bs_size < oh_bs_size(&p))) || !f->qp_y_tab || !f->deblock)
             FAIL(e, OH_E_ARG, "deblock side arrays missing or too small");
     }
     if ((p.pcm_loop_filter_disable || p.transquant_bypass_enable) && !f->is_pcm)
@@ -698,7 +703,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
 
     /* arena layout: [DevFrame][pu][mc jobs][wp][tu][intra][vbs][hbs][qp][is_pcm][db][sao][coeffs] | [res] */
     struct Seg { const void *src; size_t bytes, off; };
-    Seg seg[26];
+    Seg seg[32];
     int ns = 0;
     size_t total = 0;
     auto add = [&](const void *src, size_t bytes) {
@@ -907,8 +912,15 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_lvl = add(levels.empty() ? nullptr : f->level_start, levels.empty() ? 0 : (levels.size() + 1) * sizeof(uint32_t));
     int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
     int s_small = add(sub_small.data(), sub_small.size() * sizeof(uint32_t));
-    int s_vbs = add(has_db ? f->vertical_bs : nullptr, has_db ? f->bs_size : 0);
-    int s_hbs = add(has_db ? f->horizontal_bs : nullptr, has_db ? f->bs_size : 0);
+    const OhBsInputs *bsi = has_db ? f->bs_in : nullptr;
+    const size_t bs_bytes = bsi ? oh_bs_size(&p) : f->bs_size;
+    int s_vbs = add(has_db && !bsi ? f->vertical_bs : nullptr, has_db ? bs_bytes : 0);     /* with bs_in: written by bs_kernel after the copy */
+    int s_hbs = add(has_db && !bsi ? f->horizontal_bs : nullptr, has_db ? bs_bytes : 0);
+    const size_t n_mtb = (size_t)(p.width >> p.log2_min_tb_size) * (p.height >> p.log2_min_tb_size);
+    int s_mvf = add(bsi ? bsi->mvf : nullptr, bsi ? n_pcm * sizeof(OhMvField) : 0);
+    int s_cbf = add(bsi ? bsi->cbf_luma : nullptr, bsi ? n_mtb : 0);
+    int s_call = add(bsi ? bsi->call_log2 : nullptr, bsi ? n_mtb : 0);
+    int s_bsf = add(bsi ? bsi->ctb_flags : nullptr, bsi ? n_ctb : 0);
     int s_qp = add(has_db ? f->qp_y_tab : nullptr, has_db ? oh_qp_tab_size(&p) : 0);
     int s_pcm = add(f->is_pcm, f->is_pcm ? n_pcm : 0);
     int s_db = add(has_db ? f->deblock : nullptr, has_db ? n_ctb * sizeof(OhDeblockCtb) : 0);
@@ -993,6 +1005,14 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, e->stream);
     if (hrc == hipSuccess)
         hrc = hipEventRecord(sg->done, e->stream);
+    if (hrc == hipSuccess && bsi) {                        /* both grids from the maps: once per work list, the maps never change */
+        char *b = (char *)df->arena;
+        hrc = hipMemsetAsync(b + seg[s_vbs].off, 0, bs_bytes, e->stream);                   /* the padded tail is read by the deblock pass */
+        if (hrc == hipSuccess) hrc = hipMemsetAsync(b + seg[s_hbs].off, 0, bs_bytes, e->stream);
+        if (hrc == hipSuccess)
+            ohk_bs_derive(&p, b + seg[s_mvf].off, b + seg[s_cbf].off, b + seg[s_call].off, b + seg[s_bsf].off, bsi->loop_filter_across_tiles,
+                          b + seg[s_vbs].off, b + seg[s_hbs].off, e->stream);
+    }
     sg->busy = hrc == hipSuccess;
     if (hrc != hipSuccess) {
         free_dev_frame(e, df);
@@ -1185,6 +1205,24 @@ extern "C" int oh_frame_submit(OhEngine *e, const OhFrame *f)
     rc = oh_frame_execute(e, df);
     e->deferred.push_back(df);
     return rc;
+}
+
+/* the two boundary-strength grids of an uploaded work list as the deblock pass reads them (handed over or derived from bs_in) */
+extern "C" int oh_frame_download_bs(OhEngine *e, OhDevFrame *df, uint8_t *vbs, uint8_t *hbs, size_t bytes)
+{
+    if (!e || !df || !vbs || !hbs)
+        return OH_E_ARG;
+    if (df->owner != e || !df->p.deblock_enabled)
+        FAIL(e, OH_E_ARG, "oh_frame_download_bs: work list of another engine / without deblocking");
+    HIPCHK(e, hipSetDevice(e->device));
+    DevFrame hd;
+    HIPCHK(e, hipMemcpyAsync(&hd, df->d, sizeof(hd), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const size_t n = bytes < oh_bs_size(&df->p) ? bytes : oh_bs_size(&df->p);
+    HIPCHK(e, hipMemcpyAsync(vbs, hd.vbs, n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(hbs, hd.hbs, n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return OH_OK;
 }
 
 /* ---------------- profiling ---------------- */

@@ -62,6 +62,7 @@ def lib():
         L.oh_pic_upsample.argtypes = [V, C.c_int, C.c_int, V]
         L.oh_frames_execute.argtypes = [V, C.POINTER(C.c_void_p), C.c_int]
         L.oh_frame_free.argtypes = [V, V]
+        L.oh_frame_download_bs.argtypes = [V, V, V, V, C.c_size_t]
         L.oh_frame_submit.argtypes = [V, C.POINTER(F.OhFrame)]
         L.oh_engine_profile.argtypes = [V, I]
         L.oh_engine_pass_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
@@ -187,6 +188,13 @@ class Engine:
         arr = (C.c_void_p * len(dfs))(*[d.value if isinstance(d, C.c_void_p) else d for d in dfs])
         self.n_batches = getattr(self, "n_batches", 0) + (len(dfs) + 31) // 32
         self._chk(self.L.oh_frames_execute(self.h, arr, len(dfs)), "oh_frames_execute")
+
+    def frame_download_bs(self, df, params):
+        """(vertical, horizontal) boundary-strength grids of an uploaded work list as the deblock pass reads them"""
+        n = F.bs_size(params)
+        v, h = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        self._chk(self.L.oh_frame_download_bs(self.h, df, v.ctypes.data, h.ctypes.data, n), "oh_frame_download_bs")
+        return v, h
 
     def frame_free(self, df):
         self._chk(self.L.oh_frame_free(self.h, df), "oh_frame_free")

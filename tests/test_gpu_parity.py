@@ -469,3 +469,53 @@ def test_intra_wave_layouts(waves, phases):
     r = subprocess.run([sys.executable, "-c", _WAVES_SCRIPT.format(tests=here, root=os.path.dirname(here))], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("w,h,bd,lc,lcb,seed", [(416, 240, 8, 6, 3, 1), (416, 240, 10, 4, 3, 2), (200, 136, 8, 5, 3, 3), (1920, 1080, 10, 6, 3, 4),
+                                                (272, 144, 8, 6, 4, 5), (3840, 2160, 10, 6, 3, 6)])
+def test_boundary_strengths_from_motion_field(eng, w, h, bd, lc, lcb, seed):
+    """with OhFrame.bs_in the engine derives both BS grids on the GPU (bs_kernel) — they must equal the CPU
+    checker's grids (oh_or_bs_derive, itself pinned against the reference's ff_hevc_deblocking_boundary_strengths in
+    tests/test_bs_derive.py), and the picture decoded with them must equal the picture decoded with those grids handed over."""
+    from bs_inputs import as_struct, make_inputs
+    from openhevc_amd.engine import remap_frame
+    p = F.pic_params(w, h, bit_depth=bd, log2_ctb_size=lc, log2_min_cb_size=lcb)
+    fn = oracle().oh_or_bs_derive
+    fn.argtypes, fn.restype = [C.c_void_p] * 4, C.c_int
+    rec = F.Recorder(p)
+    rng = np.random.default_rng(seed)
+    pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}
+    ids = {k: eng.pic_alloc(p) for k in pics}
+    for k, hp in pics.items():
+        eng.pic_upload(ids[k], hp)
+    for k in range(2):
+        maps = make_inputs(p, 100 * seed + k, intra_pct=(10, 35)[k])
+        bs_in = as_struct(*maps)
+        n = F.bs_size(p)
+        want_v, want_h = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        assert fn(C.byref(p), C.byref(bs_in), want_v.ctypes.data, want_h.ctypes.data) == 0
+        f = rec.synth(F.synth_params(2, 9000 + seed + k), 2, [0, 1])
+        # (a) the grids handed over (= the checker's), (b) derived on the GPU from the maps
+        fa = remap_frame(f, ids)
+        C.memmove(fa.vertical_bs, want_v.ctypes.data, min(n, fa.bs_size))
+        C.memmove(fa.horizontal_bs, want_h.ctypes.data, min(n, fa.bs_size))
+        eng.pic_upload(ids[2], pics[2])
+        eng.frame_submit(fa)
+        eng.sync()
+        pic_a = eng.pic_download(ids[2], p)
+        fb = remap_frame(f, ids)
+        fb.bs_in = C.addressof(bs_in)
+        fb.vertical_bs = fb.horizontal_bs = None
+        eng.pic_upload(ids[2], pics[2])
+        df = eng.frame_upload(fb)
+        got_v, got_h = eng.frame_download_bs(df, p)
+        assert np.array_equal(got_v, want_v), f"vertical grid: {np.nonzero(got_v != want_v)[0][:8]}"
+        assert np.array_equal(got_h, want_h), f"horizontal grid: {np.nonzero(got_h != want_h)[0][:8]}"
+        eng.frame_execute(df)
+        eng.sync()
+        assert_same(pic_a, eng.pic_download(ids[2], p), f"{w}x{h} picture decoded with derived vs handed-over strengths")
+        eng.frame_free(df)
+        assert {0, 1, 2} <= set(np.unique(got_v)) | set(np.unique(got_h))
+    for v in ids.values():
+        eng.pic_free(v)
+    rec.close()

@@ -664,6 +664,12 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
             FAIL(e, OH_E_ARG, "bs_in: all four maps are required");
         if (bi && (p.log2_min_pu_size < 2 || p.log2_min_tb_size < 2))
             FAIL(e, OH_E_ARG, "bs_in: min PU / TB size below 4");
+        if (bi) {
+            const size_t n_cells = (size_t)(p.width >> p.log2_min_tb_size) * (p.height >> p.log2_min_tb_size);
+            for (size_t i = 0; i < n_cells; i++)
+                if (bi->call_log2[i] && (bi->call_log2[i] < p.log2_min_tb_size || bi->call_log2[i] > p.log2_ctb_size))
+                    FAIL(e, OH_E_ARG, "bs_in: call_log2[%zu] = %d is not a block size of this picture", i, bi->call_log2[i]);
+        }
         if ((!bi && (!f->vertical_bs || !f->horizontal_bs || f->bs_size < oh_bs_size(&p))) || !f->qp_y_tab || !f->deblock)
             FAIL(e, OH_E_ARG, "deblock side arrays missing or too small");
     }

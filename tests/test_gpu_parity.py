@@ -516,6 +516,14 @@ def test_boundary_strengths_from_motion_field(eng, w, h, bd, lc, lcb, seed):
         assert_same(pic_a, eng.pic_download(ids[2], p), f"{w}x{h} picture decoded with derived vs handed-over strengths")
         eng.frame_free(df)
         assert {0, 1, 2} <= set(np.unique(got_v)) | set(np.unique(got_h))
+        if k == 0:                                          # a block size the picture cannot have is refused on the host
+            from openhevc_amd.engine import EngineError
+            bad = maps[2].copy()
+            bad[0, 0] = 9
+            bad_in = as_struct(maps[0], maps[1], bad, maps[3], maps[4])
+            fb.bs_in = C.addressof(bad_in)
+            with pytest.raises(EngineError):
+                eng.frame_upload(fb)
     for v in ids.values():
         eng.pic_free(v)
     rec.close()

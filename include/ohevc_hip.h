@@ -101,7 +101,7 @@ int oh_frame_execute(OhEngine *e, OhDevFrame *df);
 /* n mutually independent pictures (none is a reference of another one; same OhPicParams): every pass
  * is ONE launch over all of them, which is how pictures of independent sequences / GOPs (the reference's
  * frame threads, pthread_frame.c) fill the GPU while each picture's own dependency chain is short of it */
-int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n);
+int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n);      /* n == 0: nothing to do, OH_OK */
 int oh_frame_free(OhEngine *e, OhDevFrame *df);
 /* the boundary-strength grids of an uploaded work list as the deblock pass will read them: the ones handed over, or — with
  * OhFrame.bs_in — the ones the engine derived from the motion field at upload (hevc_filter.c:584-941).

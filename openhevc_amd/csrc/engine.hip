@@ -1051,8 +1051,10 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
  * reference of another one. */
 extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
 {
-    if (!e || !dfs || n < 1)
+    if (!e || n < 0 || (n && !dfs))
         return OH_E_ARG;
+    if (n == 0)
+        return OH_OK;                                       /* an empty batch is a no-op */
     for (int i = 0; i < n; i++) {
         if (!dfs[i])
             return OH_E_ARG;

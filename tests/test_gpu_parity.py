@@ -527,3 +527,29 @@ def test_boundary_strengths_from_motion_field(eng, w, h, bd, lc, lcb, seed):
     for v in ids.values():
         eng.pic_free(v)
     rec.close()
+
+
+@pytest.mark.parametrize("w,h,lc,bd,chroma", [(416, 240, 6, 8, 1), (16, 16, 4, 10, 1), (8, 8, 4, 8, 0), (24, 8, 4, 12, 3), (64, 64, 6, 8, 2)])
+def test_empty_and_minimal_work_lists(eng, w, h, lc, bd, chroma):
+    """edge cases: a work list with no blocks at all (the picture only passes through the in-loop filters, whose grids are
+    all zero), the smallest pictures the format allows (one min coding block; a single partial CTB), and an empty batch"""
+    from openhevc_amd.engine import remap_frame
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc)
+    rec = F.Recorder(p)
+    lib = F.host()
+    refs = (C.c_int32 * F.OH_MAX_REFS)(*([0, 1] + [-1] * (F.OH_MAX_REFS - 2)))
+    lib.oh_rec_begin(rec.h, 2, refs, F.OH_MAX_REFS)
+    f = lib.oh_rec_finish(rec.h).contents                  # nothing recorded
+    assert (f.n_pu, f.n_tu, f.n_intra) == (0, 0, 0)
+    rng = np.random.default_rng(w + h)
+    pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}
+    want, got = run_both(eng, p, f, pics)
+    assert_same(want, got, f"empty work list {w}x{h}")
+    assert_same(pics[2], got, "no block, zero strengths, SAO off everywhere: the picture is unchanged")
+    for st in (0, 2):                                       # and a full synthetic picture of the same minimal geometry
+        g = rec.synth(F.synth_params(st, 31 + st), 2, [0, 1] if st else [])
+        want, got = run_both(eng, p, g, pics)
+        assert_same(want, got, f"minimal picture {w}x{h} slice type {st}")
+    eng.frames_execute([])                                  # an empty batch is a no-op
+    eng.sync()
+    rec.close()

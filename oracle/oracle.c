@@ -663,6 +663,8 @@ int oh_or_pass_sao(const OhFrame *f, OhHostPic *pics)
     return 0;
 }
 
+int oh_or_bs_derive(const OhPicParams *p, const OhBsInputs *in, uint8_t *vbs, uint8_t *hbs);
+
 int oh_or_frame(const OhFrame *f, OhHostPic *pics)
 {
     int16_t *c = (int16_t *)malloc(sizeof(int16_t) * (size_t)(f->n_coeff ? f->n_coeff : 1));
@@ -674,7 +676,14 @@ int oh_or_frame(const OhFrame *f, OhHostPic *pics)
     if (!r) r = oh_or_pass_inter(f, pics);
     if (!r) r = oh_or_pass_residual(f, pics, c);
     if (!r) r = oh_or_pass_intra(f, pics, c);
-    if (!r) r = oh_or_pass_deblock(f, pics);
+    if (!r && f->bs_in && f->p.deblock_enabled) {                 /* the grids come from the motion field (oh_or_bs_derive below) */
+        OhFrame g = *f;
+        uint8_t *v = (uint8_t *)malloc(oh_bs_size(&f->p)), *h = (uint8_t *)malloc(oh_bs_size(&f->p));
+        r = (v && h) ? oh_or_bs_derive(&f->p, f->bs_in, v, h) : -1;
+        g.vertical_bs = v; g.horizontal_bs = h; g.bs_size = oh_bs_size(&f->p);
+        if (!r) r = oh_or_pass_deblock(&g, pics);
+        free(v); free(h);
+    } else if (!r) r = oh_or_pass_deblock(f, pics);
     if (!r) r = oh_or_pass_sao(f, pics);
     free(c);
     return r;

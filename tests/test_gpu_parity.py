@@ -514,6 +514,11 @@ def test_boundary_strengths_from_motion_field(eng, w, h, bd, lc, lcb, seed):
         eng.frame_execute(df)
         eng.sync()
         assert_same(pic_a, eng.pic_download(ids[2], p), f"{w}x{h} picture decoded with derived vs handed-over strengths")
+        chk = {k_: v_.copy() for k_, v_ in pics.items()}        # and the checker takes the same work list (derives the grids itself)
+        fo = remap_frame(f, {0: 0, 1: 1, 2: 2})
+        fo.bs_in, fo.vertical_bs, fo.horizontal_bs = C.addressof(bs_in), None, None
+        assert oracle().oh_or_frame(C.byref(fo), host_pic_array(chk)) == 0
+        assert_same(chk[2], pic_a, f"{w}x{h} checker with bs_in")
         eng.frame_free(df)
         assert {0, 1, 2} <= set(np.unique(got_v)) | set(np.unique(got_h))
         if k == 0:                                          # a block size the picture cannot have is refused on the host

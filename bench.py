@@ -82,6 +82,8 @@ def main():
                     help="N>1: send finished reference pictures to the ranks that reference them (point-to-point batches), or replicate them everywhere (one all-gather per chain and wave)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: REHEARSAL of the N>1 control flow with several ranks on one GPU (transfers staged through host memory)")
+    ap.add_argument("--bs-from-motion", action="store_true", help="work lists carry the motion field instead of finished boundary-strength grids; "
+                    "the engine derives the grids at upload (bs_kernel, outside the timed region like the upload itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
     args = ap.parse_args()
@@ -135,7 +137,7 @@ def main():
             g.append((stream, Engine(local_rank, stream=stream.cuda_stream), dist.new_group() if world > 1 else None))
         stream, engine, group = g[0]
         with torch.cuda.stream(stream):
-            be_k = P.EngineBackend(torch, local_rank, params, plan_k, knobs=dict(sparse_pct=args.sparse_pct), engine=engine)
+            be_k = P.EngineBackend(torch, local_rank, params, plan_k, knobs=dict(sparse_pct=args.sparse_pct, bs_from_motion=int(args.bs_from_motion)), engine=engine)
         g.append((plan_k, be_k, group))
         chains.append((plan_k, be_k, stream, group))
     engines = [g[0][1] for g in groups]
@@ -250,7 +252,7 @@ def main():
                             algorithmic_bytes_per_launch=round(abytes[dom] * steps_timed / n_launch_total, 1),
                             pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
                             pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms})
-        knobs = dict(P.default_synth_knobs(), sparse_pct=args.sparse_pct)
+        knobs = dict(P.default_synth_knobs(), sparse_pct=args.sparse_pct, bs_from_motion=int(args.bs_from_motion))
         out = {
             "metric": "decoded Mpixels/s (luma), synthetic stream, bit-exact vs reference-pinned oracle",
             "value": round(value, 2), "unit": "Mpixels/s", "fps": round(total_pics / dt, 2),

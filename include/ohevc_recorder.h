@@ -53,6 +53,9 @@ int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_v
 /* boundary strengths on the GPU: instead of filling the BS grids through oh_rec_bs*(), hand over the maps
  * ff_hevc_deblocking_boundary_strengths() reads (caller-owned until the frame is submitted; ohevc_frame.h: OhBsInputs) */
 void oh_rec_bs_inputs(OhRecorder *r, const OhBsInputs *in);
+/* same, with maps owned by the recorder: allocated on first use, zeroed at the first call after oh_rec_begin(); the caller fills them
+ * through the returned struct's pointers (cast away the const) and sets loop_filter_across_tiles (default 1) */
+OhBsInputs *oh_rec_bs_maps(OhRecorder *r);
 /* scaling lists of the picture (zeroed by oh_rec_create; only read when a block names a matrix) */
 OhScalingList *oh_rec_scaling_list(OhRecorder *r);
 

@@ -39,7 +39,8 @@ typedef struct OhSynthParams {
     int32_t  sparse_pct;        /* % of transform blocks handed over as quantised levels (OH_TUF_SPARSE) */
     int32_t  scaling_list;      /* 1: random scaling lists, blocks name their matrix            */
     int32_t  ccp_pct;           /* 4:4:4 only: % of transform units with cross-component prediction */
-    int32_t  reserved[5];
+    int32_t  bs_from_motion;    /* 1: no finished BS grids; the motion field, cbf map, call sizes and CTB flags go to the engine (OhBsInputs) */
+    int32_t  reserved[4];
 } OhSynthParams;
 
 /* sensible defaults for a mid-QP picture of the given slice type */

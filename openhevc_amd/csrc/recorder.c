@@ -41,6 +41,7 @@ struct OhRecorder {
     uint8_t *vbs, *hbs, *is_pcm, *is_intra;
     uint32_t *sparse, *tu_sparse, *tu_cross; uint64_t cap_sparse, cap_tu_sparse, cap_tu_cross; int any_sparse, any_matrix, any_cross;
     const OhBsInputs *bs_in;                                  /* caller-owned maps for the GPU boundary-strength pass, or NULL */
+    OhBsInputs own_bs; OhMvField *bs_mvf; uint8_t *bs_cbf, *bs_call, *bs_flags;     /* recorder-owned maps (oh_rec_bs_maps) */
     OhScalingList scaling;
     int8_t  *qp;
     OhDeblockCtb *deblock;
@@ -106,6 +107,7 @@ void oh_rec_destroy(OhRecorder *r)
     free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->it_ctu); free(r->it_sub);
     free(r->sorted); free(r->ctu_dep); free(r->ctu_nsub); free(r->ctu_level); free(r->ctu_entry); free(r->ictu);
     free(r->sub_start); free(r->level_start);
+    free(r->bs_mvf); free(r->bs_cbf); free(r->bs_call); free(r->bs_flags);
     free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->sparse); free(r->tu_sparse); free(r->tu_cross); free(r->qp); free(r->deblock); free(r->sao);
     for (int c = 0; c < 3; c++)
         free(r->lvl[c]);
@@ -208,6 +210,27 @@ OhScalingList *oh_rec_scaling_list(OhRecorder *r) { return &r->scaling; }
 void oh_rec_bs_inputs(OhRecorder *r, const OhBsInputs *in)
 {
     r->bs_in = in;
+}
+
+OhBsInputs *oh_rec_bs_maps(OhRecorder *r)
+{
+    const OhPicParams *p = &r->f.p;
+    const size_t n_pu = (size_t)oh_min_pu_width(p) * oh_min_pu_height(p);
+    const size_t n_tb = (size_t)(p->width >> p->log2_min_tb_size) * (p->height >> p->log2_min_tb_size);
+    if (!r->bs_mvf) {
+        r->bs_mvf = (OhMvField *)malloc(n_pu * sizeof(OhMvField));
+        r->bs_cbf = (uint8_t *)malloc(n_tb); r->bs_call = (uint8_t *)malloc(n_tb); r->bs_flags = (uint8_t *)malloc((size_t)r->n_ctb);
+        if (!r->bs_mvf || !r->bs_cbf || !r->bs_call || !r->bs_flags)
+            return NULL;
+    }
+    if (r->bs_in != &r->own_bs) {                             /* first request for this picture: cleared like the grids they replace */
+        memset(r->bs_mvf, 0, n_pu * sizeof(OhMvField));
+        memset(r->bs_cbf, 0, n_tb); memset(r->bs_call, 0, n_tb); memset(r->bs_flags, 0, (size_t)r->n_ctb);
+        r->own_bs.mvf = r->bs_mvf; r->own_bs.cbf_luma = r->bs_cbf; r->own_bs.call_log2 = r->bs_call; r->own_bs.ctb_flags = r->bs_flags;
+        r->own_bs.loop_filter_across_tiles = 1;
+        r->bs_in = &r->own_bs;
+    }
+    return &r->own_bs;
 }
 
 int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)

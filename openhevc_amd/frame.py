@@ -101,7 +101,7 @@ class OhSynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in (
         "slice_type", "n_refs", "intra_pct", "skip_pct", "bi_pct", "frac_mv_pct", "mv_range", "cbf_pct",
         "weighted_pct", "split_pct", "qp_base", "qp_var", "sao_pct", "tskip_pct", "pcm_pct", "bypass_pct",
-        "vary_deblock_offsets", "sparse_pct", "scaling_list", "ccp_pct")] + [("reserved", C.c_int32 * 5)]
+        "vary_deblock_offsets", "sparse_pct", "scaling_list", "ccp_pct", "bs_from_motion")] + [("reserved", C.c_int32 * 4)]
 
 
 assert C.sizeof(OhPu) == 20 and C.sizeof(OhWeights) == 28 and C.sizeof(OhTu) == 12

@@ -13,6 +13,7 @@
 
 typedef struct Cell {            /* one 4x4 luma block */
     uint8_t intra, cbf, edges;   /* edges: 1 TU-left 2 TU-top 4 PU-left 8 PU-top */
+    uint8_t call;                /* log2 size of the block ff_hevc_deblocking_boundary_strengths is called for here (hevc.c:1578, 1607, 2400, 2484) */
     int8_t  ref[2];              /* picture ids, -1 = list unused */
     int16_t mv[2][2];
 } Cell;
@@ -120,6 +121,13 @@ static void fill_cells(Gen *g, int x, int y, int w, int h, int intra, const int8
         }
 }
 
+static void set_call(Gen *g, int x, int y, int log2)
+{
+    for (int yy = y; yy < y + (1 << log2) && yy < g->p.height; yy += 4)
+        for (int xx = x; xx < x + (1 << log2) && xx < g->p.width; xx += 4)
+            cell(g, xx, yy)->call = (uint8_t)log2;
+}
+
 static void set_cbf(Gen *g, int x, int y, int n)
 {
     for (int yy = y; yy < y + n; yy += 4)
@@ -207,6 +215,7 @@ static void gen_tu(Gen *g, const CuInfo *cu, int x, int y, int log2, int blk_idx
     int avail = cu->intra ? oh_rec_avail(g->rec, x, y, 1 << log2, 1 << log2) : 0;
     int cbf_y = pct(g, g->sp->cbf_pct) || cu->bypass;
     mark_edges(g, x, y, 1 << log2, 1 << log2, 1, 0);
+    set_call(g, x, y, log2);                                /* one call per transform unit, hevc.c:1578 */
     uint32_t tu_y = emit_tb(g, cu, 0, x, y, log2, cu->mode[pu], avail, cbf_y, 0);
     /* cross_pf is only parsed when the luma block is coded (hevc.c:1286-1290); 4:4:4 only */
     int cross = nch == 3 && cbf_y && !cu->bypass && g->sp->ccp_pct > 0 && pct(g, g->sp->ccp_pct);
@@ -329,6 +338,7 @@ static void gen_cu(Gen *g, int x, int y, int log2)
     }
     if (pcm) {                                          /* hls_pcm_sample, hevc.c:1587-1640 */
         fill_cells(g, x, y, n, n, 1, NULL, NULL);
+        set_call(g, x, y, log2);                        /* hevc.c:1607 */
         gen_coeffs(g, log2, OH_TU_PCM);
         oh_rec_tu(g->rec, 0, x, y, log2, OH_TU_PCM, OH_TUF_ADD_NOW, g->blk);
         if (g->p.chroma_format_idc) {
@@ -374,6 +384,8 @@ static void gen_cu(Gen *g, int x, int y, int log2)
     oh_rec_mark_decoded(g->rec, x, y, n, n);
     if (!pct(g, sp->skip_pct) || cu.bypass)
         gen_tt(g, &cu, x, y, log2, 0, 0, x, y);
+    else
+        set_call(g, x, y, log2);                        /* skipped / no residual: one call for the coding block, hevc.c:2400, 2484 */
 }
 
 static void gen_cqt(Gen *g, int x, int y, int log2)
@@ -437,6 +449,37 @@ static void derive_bs(Gen *g)
                 hbs[(x + y * bsw) >> 2] = (uint8_t)bs;
             }
         }
+}
+
+/* the same picture as maps for the engine's boundary-strength pass (OhBsInputs): the reference's tab_mvf / cbf_luma as this
+ * generator's cells hold them (POC = picture id of the reference), the call sizes, single slice and tile */
+static void emit_bs_maps(Gen *g)
+{
+    OhBsInputs *in = oh_rec_bs_maps(g->rec);
+    if (!in)
+        return;
+    const int lpu = g->p.log2_min_pu_size, ltu = g->p.log2_min_tb_size, mpw = oh_min_pu_width(&g->p), mtw = g->p.width >> ltu;
+    OhMvField *mvf = (OhMvField *)in->mvf;
+    uint8_t *cbf = (uint8_t *)in->cbf_luma, *call = (uint8_t *)in->call_log2;
+    for (int y = 0; y < g->p.height; y += 4)
+        for (int x = 0; x < g->p.width; x += 4) {
+            const Cell *c = cell(g, x, y);
+            if (!(x & ((1 << lpu) - 1)) && !(y & ((1 << lpu) - 1))) {
+                OhMvField *m = &mvf[(y >> lpu) * mpw + (x >> lpu)];
+                memset(m, 0, sizeof(*m));
+                for (int l = 0; l < 2; l++)
+                    if (!c->intra && c->ref[l] >= 0) {
+                        m->pred_flag |= 1u << l;
+                        m->mv[l][0] = c->mv[l][0]; m->mv[l][1] = c->mv[l][1];
+                        m->poc[l] = c->ref[l]; m->ref_idx[l] = (uint8_t)c->ref[l];
+                    }
+            }
+            if (!(x & ((1 << ltu) - 1)) && !(y & ((1 << ltu) - 1))) {
+                cbf[(y >> ltu) * mtw + (x >> ltu)] = c->cbf;
+                call[(y >> ltu) * mtw + (x >> ltu)] = c->call;
+            }
+        }
+    in->loop_filter_across_tiles = 1;
 }
 
 static void gen_sao(Gen *g)
@@ -503,7 +546,10 @@ const OhFrame *oh_synth_picture(OhRecorder *rec, const OhSynthParams *sp, int cu
             db[i].beta_offset = (int8_t)beta; db[i].tc_offset = (int8_t)tc;
             gen_cqt(&g, x, y, g.p.log2_ctb_size);
         }
-    derive_bs(&g);
+    if (sp->bs_from_motion && g.p.deblock_enabled)
+        emit_bs_maps(&g);
+    else
+        derive_bs(&g);
     gen_sao(&g);
     free(g.cells);
     return oh_rec_finish(rec);

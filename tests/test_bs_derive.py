@@ -37,3 +37,25 @@ def test_oracle_matches_reference(w, h, lc, lcb, seed):
         assert np.array_equal(ho, hr), f"horizontal grid differs at {np.nonzero(ho != hr)[0][:8]}"
         seen |= set(np.unique(vo)) | set(np.unique(ho))
     assert seen == {0, 1, 2}                                 # every strength occurs
+
+
+@pytest.mark.parametrize("w,h,lc,st,seed", [(416, 240, 6, 2, 1), (416, 240, 4, 2, 2), (832, 480, 5, 1, 3), (1920, 1080, 6, 2, 4), (416, 240, 6, 0, 5)])
+def test_generator_grids_equal_map_derivation(w, h, lc, st, seed):
+    """two independent derivations of the same picture: the synthetic generator writes BS grids from its own cells by the
+    standard's rules (H.265 8.7.2.4, synth.c: derive_bs); with bs_from_motion it emits the reference's maps instead and the
+    restatement of ff_hevc_deblocking_boundary_strengths must arrive at the same grids"""
+    p = F.pic_params(w, h, log2_ctb_size=lc)
+    fn = oracle().oh_or_bs_derive
+    fn.argtypes, fn.restype = [C.c_void_p] * 4, C.c_int
+    rec = F.Recorder(p)
+    refs = [0, 1] if st else []
+    f = rec.synth(F.synth_params(st, seed), 2, refs)
+    n = F.bs_size(p)
+    gv, gh = np.ctypeslib.as_array(f.vertical_bs, (n,)).copy(), np.ctypeslib.as_array(f.horizontal_bs, (n,)).copy()
+    f2 = rec.synth(F.synth_params(st, seed, bs_from_motion=1), 2, refs)
+    assert f2.bs_in and (f2.n_pu, f2.n_tu, f2.n_intra) == (f.n_pu, f.n_tu, f.n_intra)
+    dv, dh = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    assert fn(C.byref(p), f2.bs_in, dv.ctypes.data, dh.ctypes.data) == 0
+    assert np.array_equal(gv, dv) and np.array_equal(gh, dh)
+    assert (gv > 0).sum() > 100
+    rec.close()

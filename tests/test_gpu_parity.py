@@ -84,6 +84,9 @@ CASES = [
     # cross-component prediction (4:4:4 range extension, hevc.c:1319-1365): chroma residual += (scale * luma residual) >> 3
     ("b8_444_ccp", 200, 136, 8, 3, 5, 2, {"ccp_pct": 60, "intra_pct": 30}),
     ("i10_444_ccp_sparse", 136, 88, 10, 3, 6, 0, {"ccp_pct": 80, "sparse_pct": 60, "tskip_pct": 20}),
+    ("b10_bs_from_motion", 416, 240, 10, 1, 6, 2, {"bs_from_motion": 1, "intra_pct": 25}),
+    ("p8_bs_from_motion_ctb16", 200, 136, 8, 1, 4, 1, {"bs_from_motion": 1, "vary_deblock_offsets": 1}),
+    ("i8_422_bs_from_motion", 416, 240, 8, 2, 5, 0, {"bs_from_motion": 1}),
 ]
 
 

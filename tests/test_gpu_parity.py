@@ -398,7 +398,7 @@ def test_random_configurations(eng, seed, count, max_w8, max_h8):
                      pcm_pct=int(rng.choice([0, 15])) if pcm else 0, bypass_pct=int(rng.choice([0, 15])) if byp else 0,
                      sao_pct=int(rng.integers(0, 101)), vary_deblock_offsets=int(rng.integers(0, 2)),
                      sparse_pct=int(rng.choice([0, 0, 50, 100])), scaling_list=int(rng.integers(0, 2)),
-                     ccp_pct=int(rng.choice([0, 50])) if chroma == 3 else 0)
+                     ccp_pct=int(rng.choice([0, 50])) if chroma == 3 else 0, bs_from_motion=int(rng.integers(0, 3) == 0))
         rec = F.Recorder(p)
         f = rec.synth(F.synth_params(st, 555000 + it + seed % 1000, **knobs), 2, [0, 1] if st else [])
         prng = np.random.default_rng(it)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off, longer version of tests/test_gpu_parity.py::test_random_configurations (needs a GPU and the built oracle):
 352 more seeded configurations up to 2400x1360, every picture bit-exact against the CPU checker.  Run from the repo root
-after kernel rewrites; last run: end of round 1, all ok."""
+after kernel rewrites; last run: end of round 1 (a third of the pictures with bs_from_motion), all ok."""
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import test_gpu_parity as T

@@ -417,6 +417,8 @@ static int decode_cmp(const void *a, const void *b)
     return ka < kb ? -1 : ka > kb;
 }
 
+API int ref_bs_derive(const OhPicParams *p, const OhBsInputs *in, uint8_t *vbs, uint8_t *hbs);
+
 API int ref_frame(const OhFrame *f_in, uint8_t *const cur[3], const ptrdiff_t cur_stride[3],
                   uint8_t *const refs[][3], int n_refs, const ptrdiff_t ref_stride[3], uint8_t *const sao_scratch[3])
 {
@@ -453,8 +455,15 @@ API int ref_frame(const OhFrame *f_in, uint8_t *const cur[3], const ptrdiff_t cu
     }
     if (f->n_intra)
         rc = ref_intra_picture(f, cur, cur_stride, pool);
+    uint8_t *dv = NULL, *dh = NULL;
+    if (!rc && p->deblock_enabled && f->bs_in) {           /* the strengths come from the reference's own derivation (ref_bs_derive below) */
+        dv = malloc(oh_bs_size(p)); dh = malloc(oh_bs_size(p));
+        rc = ref_bs_derive(p, f->bs_in, dv, dh);
+        fcopy.vertical_bs = dv; fcopy.horizontal_bs = dh; fcopy.bs_size = oh_bs_size(p);
+    }
     if (!rc && (p->deblock_enabled || p->sao_enabled))
         rc = ref_filter_picture(f, cur, cur_stride, sao_scratch);
+    free(dv); free(dh);
     free(pool);
     free(sorted);
     free(k);

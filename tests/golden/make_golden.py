@@ -100,6 +100,8 @@ PICTURE_CASES = [
     ("b_8b_pcm", 264, 200, 8, 1, 6, 2, 15, {"pcm_pct": 10, "bypass_pct": 10, "vary_deblock_offsets": 1}),
     # constrained_intra_pred_flag = 1: the intra stage of this one is produced by the reference's intra_pred slots
     ("b_10b_cip", 264, 200, 10, 1, 6, 2, 16, {"intra_pct": 50}),
+    # the boundary strengths of this one come from the reference's ff_hevc_deblocking_boundary_strengths over the generator's maps
+    ("b_10b_bs_from_motion", 416, 240, 10, 1, 6, 2, 17, {"bs_from_motion": 1, "intra_pct": 20}),
 ]
 
 

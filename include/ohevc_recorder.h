@@ -78,7 +78,9 @@ uint8_t      *oh_rec_is_intra(OhRecorder *r);   /* min-PU map of intra CUs (tab_
 OhDeblockCtb *oh_rec_deblock(OhRecorder *r);
 OhSaoCtb     *oh_rec_sao(OhRecorder *r);
 
-/* sort intra items into dependency levels and expose the picture's work list */
+/* sort intra items into dependency levels and expose the picture's work list.  Returns NULL when an allocation failed while
+ * the picture was recorded (the recording calls then returned -1 / OH_NO_COEFF and dropped their item; the table slots, which
+ * cannot report anything, leave it to this call — the decoder treats the picture as lost, like a decode error). */
 const OhFrame *oh_rec_finish(OhRecorder *r);
 
 /* resolved intra candidate flags for a block, from the recorder's own "already reconstructed"

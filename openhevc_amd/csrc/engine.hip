@@ -27,6 +27,7 @@ struct Pic {
     void       *a[3] = {}, *b[3] = {};
     int32_t     stride[3] = {}, w[3] = {}, h[3] = {};
     bool        final_b = false;         /* which buffer holds the finished picture */
+    uint32_t    gen = 0;                 /* bumped whenever the id is (re)installed: uploaded work lists remember it */
 };
 
 struct EventSet { hipEvent_t ev[OH_N_PASSES + 1]; int n_frames = 1; };
@@ -43,6 +44,13 @@ struct OhDevFrame {
     uint32_t   n_cross = 0;
     bool       has_sao = false;
     int        cur_pic = -1;      /* engine id of the picture the list reconstructs */
+    uint32_t   cur_gen = 0;
+    /* reference slots as uploaded: picture id, its generation, and which half DevFrame.refs[] points at — looked up again at
+     * every execute (a reference finished or received AFTER the upload moves to its other half: oh_pic_set_final_half, SAO) */
+    int        ref_id[OH_MAX_REFS];
+    uint32_t   ref_gen[OH_MAX_REFS];
+    uint8_t    ref_half[OH_MAX_REFS];
+    uint16_t   ref_used = 0;      /* bit i: some PU predicts from slot i */
     const struct OhEngine *owner = nullptr;   /* picture ids and arenas belong to one engine */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
@@ -66,6 +74,7 @@ struct OhEngine {
     double      pass_ms[OH_N_PASSES] = {};
     uint64_t    executes = 0;
     std::vector<OhDevFrame *> deferred;
+    uint32_t    pic_gen = 0;
     /* upload path: pinned staging buffers and device arenas are recycled (hipHostMalloc / hipMalloc cost milliseconds);
      * a staging buffer is busy until the H2D copy that reads it has passed `done` */
     struct Stage { void *p; size_t bytes; hipEvent_t done; bool busy; };
@@ -251,6 +260,7 @@ static int pic_install(OhEngine *e, const OhPicParams *p, void *half0, void *hal
     pic.used = true;
     pic.p = *p;
     pic.owned = owned;
+    pic.gen = ++e->pic_gen;
     size_t half = pic_layout(p, &pic, off) / 2;
     pic.base = half0;
     for (int c = 0; c < (p->chroma_format_idc ? 3 : 1); c++) {
@@ -550,7 +560,7 @@ static void group_by_lists(std::vector<DevMcJob> &jobs)
     }
 }
 
-static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<DevMcJob> &mc_luma, std::vector<DevMcJob> &mc_chroma)
+static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<DevMcJob> &mc_luma, std::vector<DevMcJob> &mc_chroma, uint16_t *ref_used)
 {
     const OhPicParams &p = f->p;
     const int nplanes = p.chroma_format_idc ? 3 : 1;
@@ -559,8 +569,11 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
         Pic *r = get_pic(e, f->ref_pics[i]);
         ref_ok[i] = r && same_geometry(r->p, p) && r != cur;
     }
+    *ref_used = 0;
     if (f->n_pu && !f->pu)
         FAIL(e, OH_E_ARG, "n_pu without pu[]");
+    if ((f->n_wp && !f->wp) || (f->n_tu && !f->tu) || (f->n_intra && !f->intra))
+        FAIL(e, OH_E_ARG, "a non-zero item count comes with a NULL array (wp / tu / intra)");
     for (uint32_t i = 0; i < f->n_pu; i++) {
         const OhPu &pu = f->pu[i];
         if (pu.w < 4 || pu.h < 4 || pu.w > 64 || pu.h > 64 || (pu.w & 3) || (pu.h & 3) || pu.x + pu.w > p.width || pu.y + pu.h > p.height ||
@@ -569,8 +582,11 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
         if (pu.ref[0] == OH_NO_REF && pu.ref[1] == OH_NO_REF)
             FAIL(e, OH_E_ARG, "PU %u: no reference list", i);
         for (int l = 0; l < 2; l++)
-            if (pu.ref[l] != OH_NO_REF && (pu.ref[l] >= OH_MAX_REFS || !ref_ok[pu.ref[l]]))
-                FAIL(e, OH_E_ARG, "PU %u: reference slot %d is not a usable picture", i, pu.ref[l]);
+            if (pu.ref[l] != OH_NO_REF) {
+                if (pu.ref[l] >= OH_MAX_REFS || !ref_ok[pu.ref[l]])
+                    FAIL(e, OH_E_ARG, "PU %u: reference slot %d is not a usable picture", i, pu.ref[l]);
+                *ref_used |= (uint16_t)(1u << pu.ref[l]);
+            }
         if (pu.wp != OH_NO_WP && pu.wp >= f->n_wp)
             FAIL(e, OH_E_ARG, "PU %u: weight index out of range", i);
         add_mc_jobs(mc_luma, pu, 0, 0, 0);
@@ -591,6 +607,8 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
             FAIL(e, OH_E_ARG, "TU %u: outside the plane", i);
         if ((uint64_t)t.coeff_off + (uint64_t)n * n > f->n_coeff)
             FAIL(e, OH_E_ARG, "TU %u: coefficients outside the pool", i);
+        if (!(t.flags & OH_TUF_SPARSE) && !f->coeffs)
+            FAIL(e, OH_E_ARG, "TU %u: dense block but coeffs[] is NULL", i);
         if ((t.coeff_off & 3) || (t.x & 3) || (t.y & 3))        /* the kernels move 4 elements per access */
             FAIL(e, OH_E_ARG, "TU %u: position / coefficient offset not a multiple of 4", i);
         if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
@@ -630,10 +648,32 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
             if (f->sub_start[s] > f->sub_start[s + 1])
                 FAIL(e, OH_E_ARG, "intra sub-level table not monotonic");
         uint32_t expect = 0;
+        const uint32_t n_ctb = (uint32_t)oh_ctb_width(&p) * (uint32_t)oh_ctb_height(&p);
+        const int lc = p.log2_ctb_size, ctbw = oh_ctb_width(&p);
+        std::vector<uint8_t> seen(n_ctb, 0);                  /* a CTU's intra blocks form ONE entry: its level is one number */
         for (uint32_t k = 0; k < f->n_ictu; k++) {
-            if (f->ictu[k].sub_first != expect || !f->ictu[k].n_sub)
+            const OhIntraCtu &ic = f->ictu[k];
+            if (ic.sub_first != expect || !ic.n_sub)
                 FAIL(e, OH_E_ARG, "intra CTU %u: sub-level range not contiguous", k);
-            expect += f->ictu[k].n_sub;
+            expect += ic.n_sub;
+            if (expect > f->n_sub)
+                FAIL(e, OH_E_ARG, "intra CTU %u: sub-level range runs past the table", k);
+            if (ic.ctu >= n_ctb || seen[ic.ctu])
+                FAIL(e, OH_E_ARG, "intra CTU %u: CTB address %u out of range or listed twice", k, ic.ctu);
+            seen[ic.ctu] = 1;
+            /* the kernel stages at most OH_MAX_CTU_BLOCKS descriptors / sub-levels of a CTU in LDS and writes the CTU back from
+             * the origin of ic.ctu: more items, or items of another CTB, must not reach it */
+            const uint32_t b0 = f->sub_start[ic.sub_first], b1 = f->sub_start[ic.sub_first + ic.n_sub];
+            if (ic.n_sub > OH_MAX_CTU_BLOCKS || b1 - b0 > OH_MAX_CTU_BLOCKS)
+                FAIL(e, OH_E_ARG, "intra CTU %u: %u blocks in %u sub-levels exceed the per-CTU limit %d", k, b1 - b0, ic.n_sub, OH_MAX_CTU_BLOCKS);
+            for (uint32_t b = b0; b < b1; b++) {
+                const OhIntra &it = f->intra[b];
+                if (it.c_idx >= nplanes)
+                    FAIL(e, OH_E_ARG, "intra %u: bad plane", b);
+                const int X = it.x << oh_hshift(&p, it.c_idx), Y = it.y << oh_vshift(&p, it.c_idx);
+                if ((uint32_t)((Y >> lc) * ctbw + (X >> lc)) != ic.ctu)
+                    FAIL(e, OH_E_ARG, "intra %u: block lies outside CTB %u it is listed under", b, ic.ctu);
+            }
         }
         if (expect != f->n_sub)
             FAIL(e, OH_E_ARG, "intra CTU table does not cover the sub-level table");
@@ -695,7 +735,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     std::vector<DevMcJob> mc_luma, mc_chroma;
     mc_luma.reserve((size_t)f->n_pu * 4);
     mc_chroma.reserve((size_t)f->n_pu * 4);
-    rc = validate(e, f, cur, mc_luma, mc_chroma);
+    uint16_t ref_used = 0;
+    rc = validate(e, f, cur, mc_luma, mc_chroma, &ref_used);
     if (rc)
         return rc;
     auto t_valid = tnow();
@@ -967,9 +1008,14 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     fill_planes(&hd.out, cur, has_sao);
     for (int i = 0; i < OH_MAX_REFS; i++) {
         Pic *r = get_pic(e, f->ref_pics[i]);
-        if (r && same_geometry(r->p, p))
+        df->ref_id[i] = -1; df->ref_gen[i] = 0; df->ref_half[i] = 0;
+        if (r && same_geometry(r->p, p) && r != cur) {
             fill_planes(&hd.refs[i], r, r->final_b);
+            df->ref_id[i] = f->ref_pics[i]; df->ref_gen[i] = r->gen; df->ref_half[i] = r->final_b ? 1 : 0;
+        }
     }
+    df->ref_used = ref_used;
+    df->cur_gen = cur->gen;
     hd.pu = (const OhPu *)(base + seg[s_pu].off);
     hd.mc_luma = (const DevMcJob *)(base + seg[s_mcl].off);
     hd.mc_chroma = (const DevMcJob *)(base + seg[s_mcc].off);
@@ -1039,8 +1085,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     if (f->n_intra) {
         df->levels = levels;
     }
-    cur->final_b = has_sao;
-    df->cur_pic = f->cur_pic;
+    df->cur_pic = f->cur_pic;                  /* which half of cur_pic is final changes when the list is EXECUTED, not here */
     df->owner = e;
     *out = df;
     return OH_OK;
@@ -1066,6 +1111,55 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
     }
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
+    {
+        /* Pictures are looked up NOW, not at upload: the work list may have been uploaded before its references were decoded or
+         * received (multi-GPU exchange: oh_pic_set_final_half after the upload), and ids may have been freed and reused since.
+         * A reference whose finished half differs from the one DevFrame.refs[] points at is patched in HBM, in stream order. */
+        std::vector<uint8_t> role(e->pics.size(), 0);             /* 1: written by this batch, 2: read by this batch */
+        struct Patch { DevPlanes *dst; DevPlanes v; };
+        std::vector<Patch> patches;
+        for (int i = 0; i < n; i++) {
+            OhDevFrame *df = dfs[i];
+            Pic *c = get_pic(e, df->cur_pic);
+            if (!c || c->gen != df->cur_gen)
+                FAIL(e, OH_E_ARG, "batch: picture %d's cur_pic %d was freed after the upload", i, df->cur_pic);
+            if (role[df->cur_pic] & 1)
+                FAIL(e, OH_E_ARG, "batch: two work lists reconstruct picture %d", df->cur_pic);
+            role[df->cur_pic] |= 1;
+        }
+        for (int i = 0; i < n; i++) {
+            OhDevFrame *df = dfs[i];
+            for (int s = 0; s < OH_MAX_REFS; s++) {
+                if (!(df->ref_used >> s & 1))
+                    continue;
+                Pic *r = get_pic(e, df->ref_id[s]);
+                if (!r || r->gen != df->ref_gen[s])
+                    FAIL(e, OH_E_ARG, "batch: picture %d references picture %d, which was freed after the upload", i, df->ref_id[s]);
+                if (role[df->ref_id[s]] & 1)
+                    FAIL(e, OH_E_ARG, "batch: picture %d is a reference of picture %d of the same batch (nothing orders them)", df->ref_id[s], i);
+                const uint8_t half = r->final_b ? 1 : 0;
+                if (half != df->ref_half[s]) {
+                    Patch pt;
+                    pt.dst = &df->d->refs[s];
+                    fill_planes(&pt.v, r, r->final_b);
+                    patches.push_back(pt);
+                    df->ref_half[s] = half;
+                }
+            }
+        }
+        if (!patches.empty()) {
+            OhEngine::Stage *sg = stage_acquire(e, patches.size() * sizeof(DevPlanes));
+            if (!sg)
+                FAIL(e, OH_E_NOMEM, "hipHostMalloc for %zu reference patches failed", patches.size());
+            DevPlanes *hp = (DevPlanes *)sg->p;
+            for (size_t k = 0; k < patches.size(); k++) {
+                hp[k] = patches[k].v;
+                HIPCHK(e, hipMemcpyAsync(patches[k].dst, &hp[k], sizeof(DevPlanes), hipMemcpyHostToDevice, st));
+            }
+            HIPCHK(e, hipEventRecord(sg->done, st));
+            sg->busy = true;
+        }
+    }
     /* per-launch events are a sample, not a log: stop bracketing once 100 k launches are pending collection */
     const bool prof = e->profile > 0, prof_launch = e->profile > 1 && e->lev_pending.size() < 200000;
     static const char *wenv = getenv("OHEVC_INTRA_WAVES");            /* experiments: force the waves per CTU */

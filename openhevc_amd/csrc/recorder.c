@@ -49,20 +49,29 @@ struct OhRecorder {
     /* per-plane sub-level map at 4x4-sample granularity, and the luma "decoded" map (4x4 luma) */
     uint16_t *lvl[3]; int lw[3], lh[3];
     uint8_t  *decoded; int dw, dh;
+    int oom;                                     /* an allocation failed while recording this picture: items were dropped, oh_rec_finish() returns NULL */
 };
 
-static void *grow(void *p, size_t elem, uint64_t *cap, uint64_t need)
+/* the table slots that feed the recorder cannot fail (void returns), so an allocation failure is latched in r->oom: the block
+ * is kept as it was (no write through NULL, the old block is not lost), the item is dropped, and oh_rec_finish() reports it */
+static void *grow(OhRecorder *r, void *p, size_t elem, uint64_t *cap, uint64_t need)
 {
     if (need <= *cap)
         return p;
     uint64_t n = *cap ? *cap : 1024;
     while (n < need)
         n *= 2;
-    p = realloc(p, (size_t)(n * elem));
+    void *q = realloc(p, (size_t)(n * elem));
+    if (!q) {
+        r->oom = 1;
+        return p;
+    }
     *cap = n;
-    return p;
+    return q;
 }
-#define GROW32(ptr, cap, need) do { uint64_t c_ = (cap); (ptr) = grow((ptr), sizeof(*(ptr)), &c_, (need)); (cap) = (uint32_t)c_; } while (0)
+#define GROW32(ptr, cap, need) do { uint64_t c_ = (cap); (ptr) = grow(r, (ptr), sizeof(*(ptr)), &c_, (need)); (cap) = (uint32_t)c_; } while (0)
+
+void oh_rec_destroy(OhRecorder *r);
 
 OhRecorder *oh_rec_create(const OhPicParams *p)
 {
@@ -95,6 +104,13 @@ OhRecorder *oh_rec_create(const OhPicParams *p)
     r->is_intra = (uint8_t *)calloc((size_t)oh_min_pu_width(p) * oh_min_pu_height(p) + 1, 1);
     r->deblock = (OhDeblockCtb *)calloc((size_t)r->n_ctb, sizeof(OhDeblockCtb));
     r->sao = (OhSaoCtb *)calloc((size_t)r->n_ctb, sizeof(OhSaoCtb));
+    int ok = r->decoded && r->ctu_dep && r->ctu_nsub && r->ctu_level && r->ctu_entry && r->ictu && r->level_start && r->vbs && r->hbs &&
+             r->qp && r->is_pcm && r->is_intra && r->deblock && r->sao;
+    for (int c = 0; c < nplanes; c++) ok = ok && r->lvl[c];
+    if (!ok) {
+        oh_rec_destroy(r);
+        return NULL;
+    }
     return r;
 }
 
@@ -124,6 +140,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = r->f.n_ictu = r->f.n_sub = 0;
     r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0; r->any_cross = 0; r->bs_in = NULL;
     r->f.n_coeff = 0;
+    r->oom = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
     memset(r->is_pcm, 0, (size_t)oh_min_pu_width(p) * oh_min_pu_height(p));
@@ -147,6 +164,9 @@ int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int
     if (ref0 < 0 && ref1 < 0)
         return -1;
     GROW32(r->pu, r->cap_pu, (uint64_t)r->f.n_pu + 1);
+    if (wp) GROW32(r->wp, r->cap_wp, (uint64_t)r->f.n_wp + 1);
+    if (r->oom)
+        return -1;
     OhPu *it = &r->pu[r->f.n_pu++];
     memset(it, 0, sizeof(*it));
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->w = (uint8_t)w; it->h = (uint8_t)h;
@@ -156,7 +176,6 @@ int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int
     it->mv[1][0] = (int16_t)mv1x; it->mv[1][1] = (int16_t)mv1y;
     it->wp = OH_NO_WP;
     if (wp) {
-        GROW32(r->wp, r->cap_wp, (uint64_t)r->f.n_wp + 1);
         r->wp[r->f.n_wp] = *wp;
         it->wp = (uint16_t)r->f.n_wp++;
     }
@@ -168,16 +187,19 @@ uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int ki
 {
     uint32_t n2 = 1u << (2 * log2_size);
     GROW32(r->tu, r->cap_tu, (uint64_t)r->f.n_tu + 1);
-    r->coeffs = (int16_t *)grow(r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
+    r->coeffs = (int16_t *)grow(r, r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
+    r->tu_sparse = (uint32_t *)grow(r, r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
+    if (r->any_cross) r->tu_cross = (uint32_t *)grow(r, r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
+    if (r->oom)
+        return OH_NO_COEFF;
     OhTu *it = &r->tu[r->f.n_tu];
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
     it->kind = (uint8_t)kind; it->flags = (uint8_t)flags;
     it->coeff_off = (uint32_t)r->f.n_coeff;
     memcpy(r->coeffs + r->f.n_coeff, coeffs, n2 * sizeof(int16_t));
     r->f.n_coeff += n2;
-    r->tu_sparse = (uint32_t *)grow(r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
     r->tu_sparse[r->f.n_tu] = OH_NO_COEFF;
-    if (r->any_cross) { r->tu_cross = (uint32_t *)grow(r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1); r->tu_cross[r->f.n_tu] = OH_NO_COEFF; }
+    if (r->any_cross) r->tu_cross[r->f.n_tu] = OH_NO_COEFF;
     return r->f.n_tu++;
 }
 
@@ -186,9 +208,12 @@ uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size,
 {
     uint32_t n2 = 1u << (2 * log2_size);
     GROW32(r->tu, r->cap_tu, (uint64_t)r->f.n_tu + 1);
-    r->coeffs = (int16_t *)grow(r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
-    r->tu_sparse = (uint32_t *)grow(r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
-    r->sparse = (uint32_t *)grow(r->sparse, sizeof(uint32_t), &r->cap_sparse, (uint64_t)r->f.n_sparse + 1 + (uint64_t)n);
+    r->coeffs = (int16_t *)grow(r, r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
+    r->tu_sparse = (uint32_t *)grow(r, r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
+    r->sparse = (uint32_t *)grow(r, r->sparse, sizeof(uint32_t), &r->cap_sparse, (uint64_t)r->f.n_sparse + 1 + (uint64_t)n);
+    if (r->any_cross) r->tu_cross = (uint32_t *)grow(r, r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
+    if (r->oom)
+        return OH_NO_COEFF;
     OhTu *it = &r->tu[r->f.n_tu];
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
     it->kind = (uint8_t)kind; it->flags = (uint8_t)(flags | OH_TUF_SPARSE);
@@ -201,7 +226,7 @@ uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size,
     r->f.n_sparse += 1 + (uint32_t)n;
     r->any_sparse = 1;
     if ((matrix_id & 0xff) != OH_FLAT_MATRIX) r->any_matrix = 1;
-    if (r->any_cross) { r->tu_cross = (uint32_t *)grow(r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1); r->tu_cross[r->f.n_tu] = OH_NO_COEFF; }
+    if (r->any_cross) r->tu_cross[r->f.n_tu] = OH_NO_COEFF;
     return r->f.n_tu++;
 }
 
@@ -239,7 +264,9 @@ int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_v
         r->tu[tu_y].log2_size != r->tu[tu_c].log2_size)
         return -1;
     if (!r->any_cross) {                                  /* first one of the picture: start from "none" */
-        r->tu_cross = (uint32_t *)grow(r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
+        r->tu_cross = (uint32_t *)grow(r, r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
+        if (r->oom)
+            return -1;
         for (uint32_t i = 0; i < r->f.n_tu; i++) r->tu_cross[i] = OH_NO_COEFF;
         r->any_cross = 1;
     }
@@ -298,9 +325,14 @@ int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode
     uint32_t cap = r->cap_intra;
     GROW32(r->intra, r->cap_intra, (uint64_t)r->f.n_intra + 1);
     if (r->cap_intra != cap) {
-        r->it_ctu = (uint32_t *)realloc(r->it_ctu, sizeof(uint32_t) * r->cap_intra);
-        r->it_sub = (uint16_t *)realloc(r->it_sub, sizeof(uint16_t) * r->cap_intra);
+        uint32_t *nc = (uint32_t *)realloc(r->it_ctu, sizeof(uint32_t) * r->cap_intra);
+        if (nc) r->it_ctu = nc;
+        uint16_t *nsb = (uint16_t *)realloc(r->it_sub, sizeof(uint16_t) * r->cap_intra);
+        if (nsb) r->it_sub = nsb;
+        if (!nc || !nsb) { r->oom = 1; r->cap_intra = cap; }       /* the item list keeps its old capacity: nothing indexes past the side lists */
     }
+    if (r->oom)
+        return -1;
     OhIntra *it = &r->intra[r->f.n_intra];
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c; it->log2_size = (uint8_t)log2_size;
     it->mode = (uint8_t)mode; it->avail = (uint8_t)avail; it->tu = tu;
@@ -335,6 +367,8 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     const int W = r->ctbw;
     uint32_t max_level = 0, n_ictu = 0, n_sub = 0;
 
+    if (r->oom)
+        return NULL;
     /* 1. CTU levels, in raster order (every dependency points to an earlier CTU) */
     for (int i = 0; i < r->n_ctb; i++) {
         unsigned lv = 0;
@@ -364,6 +398,8 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     }
     r->level_start[max_level] = acc;
     uint32_t *cursor = (uint32_t *)malloc(sizeof(uint32_t) * (max_level + 1));
+    if (!cursor)
+        return NULL;
     memcpy(cursor, r->level_start, sizeof(uint32_t) * (max_level + 1));
     for (int i = 0; i < r->n_ctb; i++)
         if (r->ctu_level[i])
@@ -381,14 +417,18 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
         n_sub += r->ictu[k].n_sub;
     }
     GROW32(r->sub_start, r->cap_sub, (uint64_t)n_sub + 2);
+    GROW32(r->sorted, r->cap_sorted, (uint64_t)f->n_intra + 1);
+    uint32_t *pos = (uint32_t *)malloc(sizeof(uint32_t) * (n_sub + 1));
+    if (r->oom || !pos) {
+        free(pos);
+        return NULL;
+    }
     memset(r->sub_start, 0, sizeof(uint32_t) * (n_sub + 2));
     for (uint32_t i = 0; i < f->n_intra; i++)              /* histogram at slot+1 */
         r->sub_start[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1 + 1]++;
     for (uint32_t s = 0; s < n_sub; s++)
         r->sub_start[s + 1] += r->sub_start[s];
     /* 4. place the blocks (stable: recording order inside one (CTU, sub-level)) */
-    GROW32(r->sorted, r->cap_sorted, (uint64_t)f->n_intra + 1);
-    uint32_t *pos = (uint32_t *)malloc(sizeof(uint32_t) * (n_sub + 1));
     memcpy(pos, r->sub_start, sizeof(uint32_t) * (n_sub + 1));
     for (uint32_t i = 0; i < f->n_intra; i++)
         r->sorted[pos[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1]++] = r->intra[i];

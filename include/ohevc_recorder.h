@@ -78,6 +78,70 @@ uint8_t      *oh_rec_is_intra(OhRecorder *r);   /* min-PU map of intra CUs (tab_
 OhDeblockCtb *oh_rec_deblock(OhRecorder *r);
 OhSaoCtb     *oh_rec_sao(OhRecorder *r);
 
+/* ---- slices and tiles ------------------------------------------------------------------------------------------------
+ * The passes never see slice headers; what they need arrives derived: OhSaoCtb.edge_flags (the unfilterable CTB edges of
+ * sao_filter_CTB, hevc_filter.c:206-252), the boundary-strength grids already gated at slice / tile boundaries
+ * (hevc_filter.c:819-824, 857-862) or OhBsInputs.ctb_flags, and the intra candidate flags.  A caller with several slices or
+ * tiles fills these per-CTB maps (raster order; the reference's s->tab_slice_address, s->filter_slice_edges, pps->tile_id
+ * looked up through ctb_addr_rs_to_ts, and the slice's slice_deblocking_filter_disabled_flag) and oh_rec_finish() derives the
+ * SAO edge flags and, with oh_rec_bs_maps(), the BS flags from them; oh_rec_avail() then also requires the neighbour to lie
+ * in the same slice and tile (6.4.1; hevc.c:2636-2641).  Without a call to oh_rec_ctb_maps() the picture is one slice, one tile. */
+typedef struct OhCtbMaps {
+    int32_t *slice_addr;            /* s->tab_slice_address[ctb]: raster address of the first CTB of the slice (hevc.c:2600)   */
+    uint8_t *filter_slice_edges;    /* slice_loop_filter_across_slices_enabled_flag of the CTB's slice (hevc.c:2679)           */
+    uint8_t *deblock_disabled;      /* slice_deblocking_filter_disabled_flag: no boundary strengths are derived (hevc.c:1577)  */
+    int32_t *tile_id;               /* pps->tile_id[ctb_addr_rs_to_ts[ctb]]                                                    */
+    int32_t  tiles_enabled;         /* pps->tiles_enabled_flag                                                                 */
+    int32_t  loop_filter_across_tiles;   /* pps->loop_filter_across_tiles_enabled_flag                                         */
+} OhCtbMaps;
+/* recorder-owned maps, reset at the first call after oh_rec_begin() (slice 0, tile 0, filtering across slices on) */
+OhCtbMaps *oh_rec_ctb_maps(OhRecorder *r);
+/* the maps if the current / last finished picture used them, else NULL (does not switch them on) */
+const OhCtbMaps *oh_rec_ctb_maps_in_use(const OhRecorder *r);
+
+/* lc->slice_or_tiles_{left,up}_boundary and the slice's across-slices flag of one CTB as OH_BSF_* bits (hevc.c:2619-2637) */
+static inline int oh_ctb_bs_flags(const OhCtbMaps *m, int ctb_width, int rs)
+{
+    const int x = rs % ctb_width, y = rs / ctb_width, in_slice = rs - m->slice_addr[rs];
+    int tl = 0, tu = 0, sl, su;
+    if (m->tiles_enabled) {
+        tl = x > 0 && m->tile_id[rs] != m->tile_id[rs - 1];
+        sl = x > 0 && m->slice_addr[rs] != m->slice_addr[rs - 1];
+        tu = y > 0 && m->tile_id[rs] != m->tile_id[rs - ctb_width];
+        su = y > 0 && m->slice_addr[rs] != m->slice_addr[rs - ctb_width];
+    } else {
+        sl = in_slice <= 0;
+        su = in_slice < ctb_width;
+    }
+    return (su ? OH_BSF_UP_SLICE : 0) | (tu ? OH_BSF_UP_TILE : 0) | (sl ? OH_BSF_LEFT_SLICE : 0) | (tl ? OH_BSF_LEFT_TILE : 0) |
+           (m->filter_slice_edges[rs] ? OH_BSF_ACROSS_SLICES : 0);
+}
+
+/* the unfilterable edges of one CTB for the SAO pass, OhSaoCtb.edge_flags layout (hevc_filter.c:206-252) */
+static inline int oh_ctb_sao_edge_flags(const OhCtbMaps *m, int ctb_width, int ctb_height, int rs)
+{
+    const int x = rs % ctb_width, y = rs / ctb_width;
+    const int lfase = m->filter_slice_edges[rs], no_tile = m->tiles_enabled && !m->loop_filter_across_tiles;
+    if (!no_tile && lfase)
+        return 0;
+    const int e0 = x == 0, e1 = y == 0, e2 = x == ctb_width - 1, e3 = y == ctb_height - 1;
+#define OH_SL_(d) (!lfase && m->slice_addr[rs] != m->slice_addr[rs + (d)])
+#define OH_TL_(d) (no_tile && m->tile_id[rs] != m->tile_id[rs + (d)])
+    const int lt = !e0 && OH_TL_(-1), rt = !e2 && OH_TL_(1), ut = !e1 && OH_TL_(-ctb_width), bt = !e3 && OH_TL_(ctb_width);
+    int f = 0;
+    if (!e0 && (OH_SL_(-1) || lt)) f |= 1;
+    if (!e2 && (OH_SL_(1) || rt)) f |= 2;
+    if (!e1 && (OH_SL_(-ctb_width) || ut)) f |= 4;
+    if (!e3 && (OH_SL_(ctb_width) || bt)) f |= 8;
+    if (!e0 && !e1 && (OH_SL_(-ctb_width - 1) || lt || ut)) f |= 16;
+    if (!e1 && !e2 && (OH_SL_(-ctb_width + 1) || rt || ut)) f |= 32;
+    if (!e2 && !e3 && (OH_SL_(ctb_width + 1) || rt || bt)) f |= 64;
+    if (!e0 && !e3 && (OH_SL_(ctb_width - 1) || lt || bt)) f |= 128;
+#undef OH_SL_
+#undef OH_TL_
+    return f;
+}
+
 /* sort intra items into dependency levels and expose the picture's work list.  Returns NULL when an allocation failed while
  * the picture was recorded (the recording calls then returned -1 / OH_NO_COEFF and dropped their item; the table slots, which
  * cannot report anything, leave it to this call — the decoder treats the picture as lost, like a decode error). */

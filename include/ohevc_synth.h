@@ -40,8 +40,16 @@ typedef struct OhSynthParams {
     int32_t  scaling_list;      /* 1: random scaling lists, blocks name their matrix            */
     int32_t  ccp_pct;           /* 4:4:4 only: % of transform units with cross-component prediction */
     int32_t  bs_from_motion;    /* 1: no finished BS grids; the motion field, cbf map, call sizes and CTB flags go to the engine (OhBsInputs) */
-    int32_t  reserved[4];
+    /* slices and tiles (0 / 1 everywhere = one slice, one tile: the streams of the older fixtures are unchanged) */
+    int32_t  n_slices;          /* > 1: that many slices at random CTB addresses (raster scan, no tiles)                      */
+    int32_t  tile_cols, tile_rows; /* > 1: uniform tile grid; see OH_SYNTH_SLICE_PER_TILE                                       */
+    int32_t  slice_knobs;       /* OH_SYNTH_* bits                                                                          */
 } OhSynthParams;
+enum { OH_SYNTH_NO_LF_ACROSS_SLICES = 1,   /* about half of the slices get slice_loop_filter_across_slices_enabled_flag = 0   */
+       OH_SYNTH_NO_LF_ACROSS_TILES = 2,    /* pps->loop_filter_across_tiles_enabled_flag = 0                                  */
+       OH_SYNTH_DEBLOCK_OFF_SLICES = 4,    /* about a third of the slices get slice_deblocking_filter_disabled_flag = 1       */
+       OH_SYNTH_SLICE_PER_TILE = 8,        /* every tile is its own slice (else one slice covers all tiles)                   */
+       OH_SYNTH_SLICE_OFFSETS = 16 };      /* every slice draws its own beta / tc offsets                                     */
 
 /* sensible defaults for a mid-QP picture of the given slice type */
 void oh_synth_defaults(OhSynthParams *sp, int slice_type, uint64_t seed);

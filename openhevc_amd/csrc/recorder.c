@@ -43,6 +43,7 @@ struct OhRecorder {
     const OhBsInputs *bs_in;                                  /* caller-owned maps for the GPU boundary-strength pass, or NULL */
     OhBsInputs own_bs; OhMvField *bs_mvf; uint8_t *bs_cbf, *bs_call, *bs_flags;     /* recorder-owned maps (oh_rec_bs_maps) */
     OhScalingList scaling;
+    OhCtbMaps ctb_maps; int ctb_maps_on;                       /* slices / tiles (oh_rec_ctb_maps); off = one slice, one tile */
     int8_t  *qp;
     OhDeblockCtb *deblock;
     OhSaoCtb *sao;
@@ -124,6 +125,7 @@ void oh_rec_destroy(OhRecorder *r)
     free(r->sorted); free(r->ctu_dep); free(r->ctu_nsub); free(r->ctu_level); free(r->ctu_entry); free(r->ictu);
     free(r->sub_start); free(r->level_start);
     free(r->bs_mvf); free(r->bs_cbf); free(r->bs_call); free(r->bs_flags);
+    free(r->ctb_maps.slice_addr); free(r->ctb_maps.filter_slice_edges); free(r->ctb_maps.deblock_disabled); free(r->ctb_maps.tile_id);
     free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->sparse); free(r->tu_sparse); free(r->tu_cross); free(r->qp); free(r->deblock); free(r->sao);
     for (int c = 0; c < 3; c++)
         free(r->lvl[c]);
@@ -141,6 +143,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0; r->any_cross = 0; r->bs_in = NULL;
     r->f.n_coeff = 0;
     r->oom = 0;
+    r->ctb_maps_on = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
     memset(r->is_pcm, 0, (size_t)oh_min_pu_width(p) * oh_min_pu_height(p));
@@ -257,6 +260,31 @@ OhBsInputs *oh_rec_bs_maps(OhRecorder *r)
     }
     return &r->own_bs;
 }
+
+OhCtbMaps *oh_rec_ctb_maps(OhRecorder *r)
+{
+    OhCtbMaps *m = &r->ctb_maps;
+    const size_t n = (size_t)r->n_ctb;
+    if (!m->slice_addr) {
+        m->slice_addr = (int32_t *)malloc(n * sizeof(int32_t)); m->tile_id = (int32_t *)malloc(n * sizeof(int32_t));
+        m->filter_slice_edges = (uint8_t *)malloc(n); m->deblock_disabled = (uint8_t *)malloc(n);
+        if (!m->slice_addr || !m->tile_id || !m->filter_slice_edges || !m->deblock_disabled) {
+            free(m->slice_addr); free(m->tile_id); free(m->filter_slice_edges); free(m->deblock_disabled);
+            memset(m, 0, sizeof(*m));
+            r->oom = 1;
+            return NULL;
+        }
+    }
+    if (!r->ctb_maps_on) {
+        memset(m->slice_addr, 0, n * sizeof(int32_t)); memset(m->tile_id, 0, n * sizeof(int32_t));
+        memset(m->filter_slice_edges, 1, n); memset(m->deblock_disabled, 0, n);
+        m->tiles_enabled = 0; m->loop_filter_across_tiles = 1;
+        r->ctb_maps_on = 1;
+    }
+    return m;
+}
+
+const OhCtbMaps *oh_rec_ctb_maps_in_use(const OhRecorder *r) { return r->ctb_maps_on ? &r->ctb_maps : NULL; }
 
 int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
 {
@@ -434,6 +462,15 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
         r->sorted[pos[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1]++] = r->intra[i];
     free(pos);
 
+    if (r->ctb_maps_on) {                                  /* slices / tiles: what the SAO and BS passes need of them */
+        for (int i = 0; i < r->n_ctb; i++)
+            r->sao[i].edge_flags = (uint8_t)oh_ctb_sao_edge_flags(&r->ctb_maps, r->ctbw, r->ctbh, i);
+        if (r->bs_in == &r->own_bs) {
+            for (int i = 0; i < r->n_ctb; i++)
+                r->bs_flags[i] = (uint8_t)oh_ctb_bs_flags(&r->ctb_maps, r->ctbw, i);
+            r->own_bs.loop_filter_across_tiles = r->ctb_maps.loop_filter_across_tiles;
+        }
+    }
     f->pu = r->pu; f->wp = r->wp; f->tu = r->tu; f->coeffs = r->coeffs;
     f->intra = r->sorted;
     f->n_ictu = n_ictu; f->ictu = r->ictu;
@@ -460,14 +497,27 @@ static int dec_at(const OhRecorder *r, int x, int y)
     return r->decoded[(y >> 2) * r->dw + (x >> 2)];
 }
 
+/* decoded earlier AND in the same slice and tile as (x0, y0) (6.4.1; the reference's ctb_*_flag, hevc.c:2638-2641) */
+static int avail_at(const OhRecorder *r, int x0, int y0, int x, int y)
+{
+    if (!dec_at(r, x, y))
+        return 0;
+    if (r->ctb_maps_on) {
+        const int lc = r->f.p.log2_ctb_size, a = (y0 >> lc) * r->ctbw + (x0 >> lc), b = (y >> lc) * r->ctbw + (x >> lc);
+        if (r->ctb_maps.slice_addr[a] != r->ctb_maps.slice_addr[b] || r->ctb_maps.tile_id[a] != r->ctb_maps.tile_id[b])
+            return 0;
+    }
+    return 1;
+}
+
 int oh_rec_avail(const OhRecorder *r, int x, int y, int w, int h)
 {
     int a = 0;
-    if (dec_at(r, x - 1, y + h)) a |= OH_AV_BOTTOM_LEFT;
-    if (dec_at(r, x - 1, y))     a |= OH_AV_LEFT;
-    if (dec_at(r, x - 1, y - 1)) a |= OH_AV_UP_LEFT;
-    if (dec_at(r, x, y - 1))     a |= OH_AV_UP;
-    if (dec_at(r, x + w, y - 1)) a |= OH_AV_UP_RIGHT;
+    if (avail_at(r, x, y, x - 1, y + h)) a |= OH_AV_BOTTOM_LEFT;
+    if (avail_at(r, x, y, x - 1, y))     a |= OH_AV_LEFT;
+    if (avail_at(r, x, y, x - 1, y - 1)) a |= OH_AV_UP_LEFT;
+    if (avail_at(r, x, y, x, y - 1))     a |= OH_AV_UP;
+    if (avail_at(r, x, y, x + w, y - 1)) a |= OH_AV_UP_RIGHT;
     return a;
 }
 

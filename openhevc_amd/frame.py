@@ -101,7 +101,17 @@ class OhSynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in (
         "slice_type", "n_refs", "intra_pct", "skip_pct", "bi_pct", "frac_mv_pct", "mv_range", "cbf_pct",
         "weighted_pct", "split_pct", "qp_base", "qp_var", "sao_pct", "tskip_pct", "pcm_pct", "bypass_pct",
-        "vary_deblock_offsets", "sparse_pct", "scaling_list", "ccp_pct", "bs_from_motion")] + [("reserved", C.c_int32 * 4)]
+        "vary_deblock_offsets", "sparse_pct", "scaling_list", "ccp_pct", "bs_from_motion", "n_slices", "tile_cols", "tile_rows", "slice_knobs")]
+
+
+# OhSynthParams.slice_knobs (include/ohevc_synth.h)
+SYNTH_NO_LF_ACROSS_SLICES, SYNTH_NO_LF_ACROSS_TILES, SYNTH_DEBLOCK_OFF_SLICES, SYNTH_SLICE_PER_TILE, SYNTH_SLICE_OFFSETS = 1, 2, 4, 8, 16
+
+
+class OhCtbMaps(C.Structure):
+    """include/ohevc_recorder.h: per-CTB slice / tile maps (raster order)"""
+    _fields_ = [("slice_addr", C.POINTER(C.c_int32)), ("filter_slice_edges", C.POINTER(C.c_uint8)), ("deblock_disabled", C.POINTER(C.c_uint8)),
+                ("tile_id", C.POINTER(C.c_int32)), ("tiles_enabled", C.c_int32), ("loop_filter_across_tiles", C.c_int32)]
 
 
 assert C.sizeof(OhPu) == 20 and C.sizeof(OhWeights) == 28 and C.sizeof(OhTu) == 12
@@ -214,6 +224,10 @@ def host():
         lib.oh_rec_finish.argtypes = [V]
         lib.oh_rec_finish.restype = C.POINTER(OhFrame)
         lib.oh_rec_avail.argtypes = [V, I, I, I, I]
+        lib.oh_rec_ctb_maps.argtypes = [V]
+        lib.oh_rec_ctb_maps.restype = C.POINTER(OhCtbMaps)
+        lib.oh_rec_ctb_maps_in_use.argtypes = [V]
+        lib.oh_rec_ctb_maps_in_use.restype = C.POINTER(OhCtbMaps)
         lib.oh_rec_mark_decoded.argtypes = [V, I, I, I, I]
         for n, t in (("oh_rec_vertical_bs", C.c_uint8), ("oh_rec_horizontal_bs", C.c_uint8), ("oh_rec_qp_y_tab", C.c_int8),
                      ("oh_rec_is_pcm", C.c_uint8), ("oh_rec_is_intra", C.c_uint8), ("oh_rec_deblock", OhDeblockCtb), ("oh_rec_sao", OhSaoCtb)):
@@ -242,6 +256,11 @@ class Recorder:
 
     def __del__(self):
         self.close()
+
+    def ctb_maps(self):
+        """the slice / tile maps of the picture just finished (None: one slice, one tile)"""
+        m = self.lib.oh_rec_ctb_maps_in_use(self.h)
+        return m.contents if m else None
 
     def synth(self, sp, cur_pic, ref_pics=()):
         refs = (C.c_int32 * OH_MAX_REFS)(*([int(r) for r in ref_pics] + [-1] * (OH_MAX_REFS - len(ref_pics))))

@@ -26,6 +26,7 @@ typedef struct Gen {
     Cell *cells; int cw, ch;
     int32_t ref_pics[OH_MAX_REFS]; int n_ref;
     int8_t *qp; uint8_t *is_pcm, *is_intra;
+    const OhCtbMaps *maps;           /* slices / tiles, NULL = one slice, one tile */
     int16_t blk[32 * 32];
 } Gen;
 
@@ -431,6 +432,23 @@ static int motion_bs(const Cell *p, const Cell *q)
 #undef FAR
 }
 
+/* slices / tiles: the block at (x, y) belongs to a slice without deblocking (no strengths are derived for its edges, hevc.c:1577),
+ * or the edge lies on a CTB boundary that is a slice / tile boundary the loop filter must not cross (hevc_filter.c:819-824, 857-862) */
+static int edge_off(const Gen *g, int x, int y, int vertical)
+{
+    if (!g->maps)
+        return 0;
+    const int lc = g->p.log2_ctb_size, ctbw = oh_ctb_width(&g->p), rs = (y >> lc) * ctbw + (x >> lc);
+    if (g->maps->deblock_disabled[rs])
+        return 1;
+    if ((vertical ? x : y) & ((1 << lc) - 1))
+        return 0;
+    const int fl = oh_ctb_bs_flags(g->maps, ctbw, rs);
+    const int slice_b = vertical ? fl & OH_BSF_LEFT_SLICE : fl & OH_BSF_UP_SLICE, tile_b = vertical ? fl & OH_BSF_LEFT_TILE : fl & OH_BSF_UP_TILE;
+    const int bd_slice = (fl & OH_BSF_ACROSS_SLICES) || !slice_b, bd_tiles = g->maps->loop_filter_across_tiles || !tile_b;
+    return !(bd_slice && bd_tiles);
+}
+
 static void derive_bs(Gen *g)
 {
     uint8_t *vbs = oh_rec_vertical_bs(g->rec), *hbs = oh_rec_horizontal_bs(g->rec);
@@ -438,12 +456,14 @@ static void derive_bs(Gen *g)
     for (int y = 0; y < g->p.height; y += 4)
         for (int x = 0; x < g->p.width; x += 4) {
             const Cell *q = cell(g, x, y);
-            if (x && !(x & 7) && (q->edges & 5)) {
+            if (edge_off(g, x, y, 1) && edge_off(g, x, y, 0))
+                continue;
+            if (x && !(x & 7) && (q->edges & 5) && !edge_off(g, x, y, 1)) {
                 const Cell *p = cell(g, x - 4, y);
                 int bs = (p->intra || q->intra) ? 2 : (((q->edges & 1) && (p->cbf || q->cbf)) ? 1 : motion_bs(p, q));
                 vbs[(x + y * bsw) >> 2] = (uint8_t)bs;
             }
-            if (y && !(y & 7) && (q->edges & 10)) {
+            if (y && !(y & 7) && (q->edges & 10) && !edge_off(g, x, y, 0)) {
                 const Cell *p = cell(g, x, y - 4);
                 int bs = (p->intra || q->intra) ? 2 : (((q->edges & 2) && (p->cbf || q->cbf)) ? 1 : motion_bs(p, q));
                 hbs[(x + y * bsw) >> 2] = (uint8_t)bs;
@@ -476,10 +496,11 @@ static void emit_bs_maps(Gen *g)
             }
             if (!(x & ((1 << ltu) - 1)) && !(y & ((1 << ltu) - 1))) {
                 cbf[(y >> ltu) * mtw + (x >> ltu)] = c->cbf;
-                call[(y >> ltu) * mtw + (x >> ltu)] = c->call;
+                call[(y >> ltu) * mtw + (x >> ltu)] = g->maps && g->maps->deblock_disabled[(y >> g->p.log2_ctb_size) * oh_ctb_width(&g->p) +
+                                                      (x >> g->p.log2_ctb_size)] ? 0 : c->call;
             }
         }
-    in->loop_filter_across_tiles = 1;
+    in->loop_filter_across_tiles = g->maps ? g->maps->loop_filter_across_tiles : 1;      /* ctb_flags: oh_rec_finish() from the CTB maps */
 }
 
 static void gen_sao(Gen *g)
@@ -538,8 +559,52 @@ const OhFrame *oh_synth_picture(OhRecorder *rec, const OhSynthParams *sp, int cu
     int ctb = 1 << g.p.log2_ctb_size;
     OhDeblockCtb *db = oh_rec_deblock(rec);
     int beta = 2 * rnd_range(&g, -3, 3), tc = 2 * rnd_range(&g, -3, 3), i = 0;
+    const int tiles = sp->tile_cols > 1 || sp->tile_rows > 1;
+    int8_t *slice_beta = NULL, *slice_tc = NULL;
+    if (sp->n_slices > 1 || tiles) {
+        /* slices: contiguous CTB ranges in raster scan starting at random addresses (no tiles), or one per tile / one for all
+         * tiles; per slice: loop filtering across its boundaries, deblocking on / off, its own beta / tc offsets */
+        OhCtbMaps *m = oh_rec_ctb_maps(rec);
+        const int W = oh_ctb_width(&g.p), H = oh_ctb_height(&g.p), n = W * H;
+        if (!m) { free(g.cells); return NULL; }
+        slice_beta = (int8_t *)calloc((size_t)n, 2); slice_tc = slice_beta ? slice_beta + n : NULL;
+        if (!slice_beta) { free(g.cells); return NULL; }
+        if (tiles) {
+            const int tc_ = sp->tile_cols > 1 ? (sp->tile_cols < W ? sp->tile_cols : W) : 1, tr_ = sp->tile_rows > 1 ? (sp->tile_rows < H ? sp->tile_rows : H) : 1;
+            m->tiles_enabled = 1;
+            m->loop_filter_across_tiles = !(sp->slice_knobs & OH_SYNTH_NO_LF_ACROSS_TILES);
+            for (int cy = 0; cy < H; cy++)
+                for (int cx = 0; cx < W; cx++) {
+                    int tx = 0, ty = 0;                            /* uniform spacing, hevc_ps.c: column_width = ((i+1)*W)/cols - (i*W)/cols */
+                    while (((tx + 1) * W) / tc_ <= cx) tx++;
+                    while (((ty + 1) * H) / tr_ <= cy) ty++;
+                    m->tile_id[cy * W + cx] = ty * tc_ + tx;
+                    m->slice_addr[cy * W + cx] = (sp->slice_knobs & OH_SYNTH_SLICE_PER_TILE) ? ((ty * H) / tr_) * W + (tx * W) / tc_ : 0;
+                }
+        } else {
+            int addr = 0;
+            for (int k = 0; k < n; k++) {
+                if (k && rnd(&g, n) < sp->n_slices - 1) addr = k;      /* on average n_slices - 1 further slice starts */
+                m->slice_addr[k] = addr;
+            }
+        }
+        for (int k = 0; k < n; k++) {
+            const int a = m->slice_addr[k];
+            if (a == k || (tiles && !(sp->slice_knobs & OH_SYNTH_SLICE_PER_TILE) && k == 0)) {     /* first CTB of a slice: draw its header */
+                m->filter_slice_edges[k] = !((sp->slice_knobs & OH_SYNTH_NO_LF_ACROSS_SLICES) && rnd(&g, 2));
+                m->deblock_disabled[k] = (sp->slice_knobs & OH_SYNTH_DEBLOCK_OFF_SLICES) && rnd(&g, 3) == 0;
+                if (sp->slice_knobs & OH_SYNTH_SLICE_OFFSETS) { beta = 2 * rnd_range(&g, -6, 6); tc = 2 * rnd_range(&g, -6, 6); }
+                slice_beta[k] = (int8_t)beta; slice_tc[k] = (int8_t)tc;
+            } else {
+                m->filter_slice_edges[k] = m->filter_slice_edges[a]; m->deblock_disabled[k] = m->deblock_disabled[a];
+                slice_beta[k] = slice_beta[a]; slice_tc[k] = slice_tc[a];
+            }
+        }
+        g.maps = m;
+    }
     for (int y = 0; y < g.p.height; y += ctb)
         for (int x = 0; x < g.p.width; x += ctb, i++) {
+            if (slice_beta) { beta = slice_beta[i]; tc = slice_tc[i]; }
             if (sp->vary_deblock_offsets && rnd(&g, 4) == 0) {
                 beta = 2 * rnd_range(&g, -6, 6); tc = 2 * rnd_range(&g, -6, 6);
             }
@@ -552,5 +617,6 @@ const OhFrame *oh_synth_picture(OhRecorder *rec, const OhSynthParams *sp, int cu
         derive_bs(&g);
     gen_sao(&g);
     free(g.cells);
+    free(slice_beta);
     return oh_rec_finish(rec);
 }

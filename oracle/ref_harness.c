@@ -19,8 +19,14 @@
 #include "libavcodec/videodsp.h"
 
 #include "../include/ohevc_frame.h"
+#include "../include/ohevc_recorder.h"          /* OhCtbMaps: the per-CTB slice / tile maps of a picture */
 
 #define API __attribute__((visibility("default")))
+
+/* slices / tiles of the pictures the next calls work on (NULL = one slice, one tile); the maps hold what the reference's CTU
+ * loop leaves in s->tab_slice_address, s->filter_slice_edges and pps->tile_id (hevc.c:2600, 2679; hevc_ps.c) */
+static const OhCtbMaps *g_maps;
+API void ref_set_ctb_maps(const OhCtbMaps *m) { g_maps = m; }
 
 static HEVCDSPContext  g_dsp[15];
 static HEVCPredContext g_pred[15];
@@ -153,12 +159,12 @@ typedef struct RefCtx {
     HEVCPPS           pps;
     HEVCFrame         ref;
     AVFrame           frame, sao_frame;
-    int              *zs_tab, *rs_to_ts, *tile_id;
+    int              *zs_tab, *rs_to_ts, *ts_to_rs, *tile_id;
 } RefCtx;
 
 static void ctx_free(RefCtx *r)
 {
-    free(r->zs_tab); free(r->rs_to_ts); free(r->tile_id);
+    free(r->zs_tab); free(r->rs_to_ts); free(r->ts_to_rs); free(r->tile_id);
     free(r->s.filter_slice_edges); free(r->s.tab_slice_address);
     free(r->s.sao); free(r->s.deblock);
     free(r);
@@ -200,9 +206,21 @@ static RefCtx *ctx_new(const OhPicParams *p, uint8_t *const data[3], const ptrdi
     pps->loop_filter_across_tiles_enabled_flag = 1;
     ctbs = sps->ctb_size;
     r->rs_to_ts = malloc(sizeof(int) * (size_t)(ctbs + 1));
+    r->ts_to_rs = malloc(sizeof(int) * (size_t)(ctbs + 1));
     r->tile_id  = calloc((size_t)(ctbs + 1), sizeof(int));
-    for (int i = 0; i <= ctbs; i++) r->rs_to_ts[i] = i;
-    pps->ctb_addr_rs_to_ts = r->rs_to_ts; pps->ctb_addr_ts_to_rs = r->rs_to_ts; pps->tile_id = r->tile_id;
+    for (int i = 0; i <= ctbs; i++) r->rs_to_ts[i] = r->ts_to_rs[i] = i;
+    if (g_maps && g_maps->tiles_enabled) {
+        /* tile scan (6.5.1): tiles in raster order of the tile grid, CTBs in raster order inside a tile; pps->tile_id is
+         * indexed by the tile-scan address (hevc_ps.c:2151) */
+        int max_id = 0, ts = 0;
+        for (int i = 0; i < ctbs; i++) if (g_maps->tile_id[i] > max_id) max_id = g_maps->tile_id[i];
+        for (int t = 0; t <= max_id; t++)
+            for (int i = 0; i < ctbs; i++)
+                if (g_maps->tile_id[i] == t) { r->rs_to_ts[i] = ts; r->ts_to_rs[ts] = i; r->tile_id[ts] = t; ts++; }
+        pps->tiles_enabled_flag = 1;
+        pps->loop_filter_across_tiles_enabled_flag = (uint8_t)g_maps->loop_filter_across_tiles;
+    }
+    pps->ctb_addr_rs_to_ts = r->rs_to_ts; pps->ctb_addr_ts_to_rs = r->ts_to_rs; pps->tile_id = r->tile_id;
     n = sps->tb_mask + 2; d = p->log2_ctb_size - p->log2_min_tb_size;
     r->zs_tab = malloc(sizeof(int) * (size_t)(n * n));
     pps->min_tb_addr_zs_tab = r->zs_tab;
@@ -264,12 +282,25 @@ API int ref_intra_picture(const OhFrame *f, uint8_t *const data[3], const ptrdif
         int x_ctb = x0 & ~(ctb - 1), y_ctb = y0 & ~(ctb - 1);
         int x0b = x0 & (ctb - 1), y0b = y0 & (ctb - 1);
         int ctb_addr = (y_ctb >> p->log2_ctb_size) * r->sps.ctb_width + (x_ctb >> p->log2_ctb_size);
-        /* hls_decode_neighbour for slice_addr 0, no tiles */
-        lc->ctb_left_flag     = x_ctb > 0 && ctb_addr > 0;
-        lc->ctb_up_flag       = y_ctb > 0 && ctb_addr >= r->sps.ctb_width;
-        lc->ctb_up_right_flag = y_ctb > 0 && ctb_addr + 1 >= r->sps.ctb_width;
-        lc->ctb_up_left_flag  = x_ctb > 0 && y_ctb > 0 && ctb_addr - 1 >= r->sps.ctb_width;
-        lc->end_of_tiles_x = p->width;
+        /* hls_decode_neighbour (hevc.c:2592-2642) for the CTB's slice address and tile */
+        {
+            const int W = r->sps.ctb_width, tiles = g_maps && g_maps->tiles_enabled;
+            const int in_slice = ctb_addr - (g_maps ? g_maps->slice_addr[ctb_addr] : 0);
+#define TID(rs) (g_maps ? g_maps->tile_id[rs] : 0)
+            const int tile_left = tiles && x_ctb > 0 && TID(ctb_addr) != TID(ctb_addr - 1);
+            const int tile_up = tiles && y_ctb > 0 && TID(ctb_addr) != TID(ctb_addr - W);
+            lc->ctb_left_flag     = x_ctb > 0 && in_slice > 0 && !tile_left;
+            lc->ctb_up_flag       = y_ctb > 0 && in_slice >= W && !tile_up;
+            lc->ctb_up_right_flag = y_ctb > 0 && in_slice + 1 >= W && TID(ctb_addr) == TID(ctb_addr + 1 - W);
+            lc->ctb_up_left_flag  = x_ctb > 0 && y_ctb > 0 && in_slice - 1 >= W && TID(ctb_addr) == TID(ctb_addr - 1 - W);
+            lc->end_of_tiles_x = p->width;
+            if (tiles) {                                       /* right edge of the CTB's tile (column_width[], hevc.c:2609-2613) */
+                int cx = x_ctb >> p->log2_ctb_size;
+                while (cx + 1 < W && TID(ctb_addr - (x_ctb >> p->log2_ctb_size) + cx + 1) == TID(ctb_addr)) cx++;
+                lc->end_of_tiles_x = (cx + 1) << p->log2_ctb_size < p->width ? (cx + 1) << p->log2_ctb_size : p->width;
+            }
+#undef TID
+        }
         lc->end_of_tiles_y = y_ctb + ctb < p->height ? y_ctb + ctb : p->height;
         /* ff_hevc_set_neighbour_available(s, x0, y0, n_h, n_v) */
         lc->na.cand_up       = lc->ctb_up_flag || y0b;
@@ -322,7 +353,8 @@ API int ref_filter_picture(const OhFrame *f, uint8_t *const data[3], const ptrdi
     for (int i = 0; i < ctbs; i++) {
         s->deblock[i].beta_offset = f->deblock[i].beta_offset;
         s->deblock[i].tc_offset = f->deblock[i].tc_offset;
-        s->filter_slice_edges[i] = 1;
+        s->filter_slice_edges[i] = g_maps ? g_maps->filter_slice_edges[i] : 1;
+        s->tab_slice_address[i] = g_maps ? g_maps->slice_addr[i] : 0;          /* read per CTB through CTB(), hevc_filter.c:195 */
         if (f->sao)
             for (int c = 0; c < 3; c++) {
                 for (int k = 0; k < 5; k++)

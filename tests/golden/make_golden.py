@@ -102,6 +102,12 @@ PICTURE_CASES = [
     ("b_10b_cip", 264, 200, 10, 1, 6, 2, 16, {"intra_pct": 50}),
     # the boundary strengths of this one come from the reference's ff_hevc_deblocking_boundary_strengths over the generator's maps
     ("b_10b_bs_from_motion", 416, 240, 10, 1, 6, 2, 17, {"bs_from_motion": 1, "intra_pct": 20}),
+    # several slices / tiles: the reference side works from the raw CTB maps (tab_slice_address, filter_slice_edges, tile ids) and derives
+    # the SAO restore flags, the gated boundary strengths and the neighbour availability itself (oracle/ref_harness.c)
+    ("b_8b_slices", 416, 240, 8, 1, 5, 2, 18, {"n_slices": 6, "sao_pct": 80, "intra_pct": 25, "slice_knobs": 1 | 4 | 16}),
+    ("i_10b_slices", 264, 200, 10, 1, 5, 0, 19, {"n_slices": 5, "sao_pct": 80, "slice_knobs": 1 | 16}),
+    ("b_8b_tiles", 416, 240, 8, 1, 5, 2, 20, {"tile_cols": 3, "tile_rows": 2, "sao_pct": 80, "intra_pct": 25, "slice_knobs": 1 | 2 | 8 | 16}),
+    ("p_10b_tiles_bs_from_motion", 416, 240, 10, 1, 6, 1, 21, {"tile_cols": 2, "tile_rows": 2, "bs_from_motion": 1, "sao_pct": 80, "slice_knobs": 2}),
 ]
 
 
@@ -158,8 +164,9 @@ def main():
     import json
     with open(os.path.join(HERE, "upsample.json"), "w") as fh:
         json.dump({"cases": [list(c) for c in UPSAMPLE_CASES], "expected": {c[0]: upsample_case(*c) for c in UPSAMPLE_CASES}}, fh, indent=1)
-    for bd in (8, 10):
-        np.savez_compressed(os.path.join(HERE, f"slots_{bd}bit.npz"), **slot_vectors(bd))
+    if "--pictures-only" not in sys.argv:            # the slot vectors only change with the slot set
+        for bd in (8, 10):
+            np.savez_compressed(os.path.join(HERE, f"slots_{bd}bit.npz"), **slot_vectors(bd))
     import json
     pics = {c[0]: picture_case(*c) for c in PICTURE_CASES}
     with open(os.path.join(HERE, "pictures.json"), "w") as fh:

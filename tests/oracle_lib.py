@@ -95,6 +95,7 @@ _REF_SIGS = {
     "ref_up_frame": [V, V, I, I, V, V, I, I, V],
     "ref_frame": [V, V, V, V, I, V, V],
     "ref_up_blocks": [V, V, I, I, V, V, I, I, V, I],
+    "ref_set_ctb_maps": [V],
 }
 
 

@@ -87,6 +87,17 @@ CASES = [
     ("b10_bs_from_motion", 416, 240, 10, 1, 6, 2, {"bs_from_motion": 1, "intra_pct": 25}),
     ("p8_bs_from_motion_ctb16", 200, 136, 8, 1, 4, 1, {"bs_from_motion": 1, "vary_deblock_offsets": 1}),
     ("i8_422_bs_from_motion", 416, 240, 8, 2, 5, 0, {"bs_from_motion": 1}),
+    # several slices / tiles (pinned through the reference's own drivers in tests/test_oracle_picture_vs_ref.py): SAO restore flags
+    # (sao_edge_filter[1]), boundary strengths gated at slice / tile edges, per-slice deblocking off / offsets, neighbour availability
+    ("b8_slices_lf_off", 416, 240, 8, 1, 5, 2, dict(n_slices=6, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
+    ("b10_slices_deblock_off", 264, 200, 10, 1, 5, 2, dict(n_slices=9, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),
+    ("i8_slices", 264, 200, 8, 1, 6, 0, dict(n_slices=5, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
+    ("b8_tiles_lf_off", 416, 240, 8, 1, 5, 2, dict(tile_cols=3, tile_rows=2, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES)),
+    ("b10_tiles_slices", 832, 480, 10, 1, 6, 2, dict(tile_cols=2, tile_rows=3, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES | F.SYNTH_SLICE_PER_TILE |
+                                                      F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
+    ("i8_444_tiles", 200, 136, 8, 3, 5, 0, dict(tile_cols=2, tile_rows=2, sao_pct=80, slice_knobs=F.SYNTH_SLICE_PER_TILE | F.SYNTH_NO_LF_ACROSS_SLICES)),
+    ("b8_slices_bs_from_motion", 416, 240, 8, 1, 5, 2, dict(n_slices=6, bs_from_motion=1, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),
+    ("p10_422_tiles_bs_from_motion", 416, 240, 10, 2, 5, 1, dict(tile_cols=3, tile_rows=2, bs_from_motion=1, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES | F.SYNTH_SLICE_PER_TILE)),
 ]
 
 
@@ -189,8 +200,10 @@ def test_1080p_b_and_i_pictures(eng):
 
 
 @pytest.mark.parametrize("name,w,h,bd,chroma,seeds", [
-    ("2160p_main10", 3840, 2160, 10, 1, ((0, 21), (2, 22))),            # BASELINE configs[2]/[3] geometry, the bench workload
-    ("4320p_444_10bit", 7680, 4320, 10, 3, ((2, 23),)),                  # BASELINE configs[4] geometry (range extension 4:4:4)
+    ("480p_main8", 832, 480, 8, 1, ((0, 19), (2, 20))),                 # BASELINE configs[0] geometry (BQMall_832x480 class; the stream itself is not available offline)
+    ("2160p_main8", 3840, 2160, 8, 1, ((0, 24), (2, 25))),              # BASELINE configs[2]: 4K Main 8-bit
+    ("2160p_main10", 3840, 2160, 10, 1, ((0, 21), (2, 22))),            # BASELINE configs[3] geometry, the bench workload
+    ("4320p_444_10bit", 7680, 4320, 10, 3, ((2, 23), (0, 26))),          # BASELINE configs[4] geometry (range extension 4:4:4): B and I picture
 ])
 def test_full_size_pictures(eng, name, w, h, bd, chroma, seeds):
     """BASELINE.json's full sizes, bit-exact against the oracle (a 4K picture costs the oracle ~0.3 s, the 8K 4:4:4 one a

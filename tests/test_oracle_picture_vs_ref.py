@@ -199,7 +199,21 @@ def ref_frame(rec, f, pics):
         rs = plane_ptrs(hp)[1]
     if rs is None:
         rs = s
-    return ref().ref_frame(C.byref(f), d, s, C.cast(refs, C.c_void_p), n_refs, rs, d2)      # sorts the blocks into decode order itself
+    with ctb_maps_of(rec):
+        return ref().ref_frame(C.byref(f), d, s, C.cast(refs, C.c_void_p), n_refs, rs, d2)      # sorts the blocks into decode order itself
+
+
+class ctb_maps_of:
+    """the reference harness works on the slices / tiles of the picture `rec` just finished (none: one slice, one tile)"""
+
+    def __init__(self, rec):
+        self.m = rec.ctb_maps()
+
+    def __enter__(self):
+        ref().ref_set_ctb_maps(C.byref(self.m) if self.m is not None else None)
+
+    def __exit__(self, *a):
+        ref().ref_set_ctb_maps(None)
 
 
 PIPELINE_CASES = [
@@ -234,4 +248,52 @@ def test_whole_picture_through_reference_kernels(case):
         assert ref_frame(rec, f, pics) == 0
         for c in range(F.n_planes(p)):
             assert np.array_equal(want[2].visible(c), pics[2].visible(c)), (name, seed, c)
+    rec.close()
+
+
+# ---- several slices / tiles -------------------------------------------------------------------------------------------
+SLICE_CASES = [
+    # name, w, h, bd, chroma, log2_ctb, slice_type, synth knobs
+    ("slices_lf_off", 416, 240, 8, 1, 5, 2, dict(n_slices=6, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
+    ("slices_deblock_off", 264, 200, 10, 1, 5, 2, dict(n_slices=9, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),
+    ("slices_intra", 264, 200, 8, 1, 5, 0, dict(n_slices=5, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
+    ("tiles_lf_off", 416, 240, 8, 1, 5, 2, dict(tile_cols=3, tile_rows=2, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES)),
+    ("tiles_slices", 416, 240, 10, 1, 5, 2, dict(tile_cols=2, tile_rows=3, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES | F.SYNTH_SLICE_PER_TILE |
+                                                 F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
+    ("tiles_lf_on_444", 200, 136, 8, 3, 5, 0, dict(tile_cols=2, tile_rows=2, slice_knobs=F.SYNTH_SLICE_PER_TILE | F.SYNTH_NO_LF_ACROSS_SLICES)),
+    ("slices_bs_from_motion", 416, 240, 8, 1, 5, 2, dict(n_slices=6, bs_from_motion=1, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),
+    ("tiles_bs_from_motion", 416, 240, 10, 2, 5, 1, dict(tile_cols=3, tile_rows=2, bs_from_motion=1, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES | F.SYNTH_SLICE_PER_TILE)),
+]
+
+
+@pytest.mark.parametrize("case", SLICE_CASES, ids=[c[0] for c in SLICE_CASES])
+def test_slices_and_tiles_through_reference_drivers(case):
+    """Pictures of several slices / tiles (hevc.c:2592-2642: neighbour availability; hevc_filter.c:206-252: the SAO restore flags
+    -> sao_edge_filter[1]; :819-824, :857-862: boundary strengths gated at slice / tile edges; per-slice deblocking off and
+    offsets).  The engine-side inputs — OhSaoCtb.edge_flags, the gated BS grids or OhBsInputs.ctb_flags, the intra candidate
+    flags — are derived by the recorder / generator from the CTB maps; the reference side gets the RAW maps
+    (tab_slice_address, filter_slice_edges, tile ids) and derives everything itself in sao_filter_CTB,
+    ff_hevc_deblocking_boundary_strengths and the harness's hls_decode_neighbour."""
+    name, w, h, bd, chroma, lc, st, knobs = case
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc)
+    rec = F.Recorder(p)
+    any_flags = any_off = False
+    for seed in range(3):
+        f = rec.synth(F.synth_params(st, 8100 + seed, sao_pct=80, intra_pct=25, **knobs), 2, [0, 1] if st else [])
+        m = rec.ctb_maps()
+        assert m is not None
+        n_ctb = ((w + (1 << lc) - 1) >> lc) * ((h + (1 << lc) - 1) >> lc)
+        any_flags |= any(f.sao[i].edge_flags for i in range(n_ctb))
+        any_off |= any(m.deblock_disabled[i] for i in range(n_ctb))
+        rng = np.random.default_rng(seed)
+        pics = {0: smooth_picture(p, rng), 1: smooth_picture(p, rng), 2: F.HostPic(p, rng=rng)}
+        want = {k: v.copy() for k, v in pics.items()}
+        assert oracle().oh_or_frame(C.byref(f), host_pic_array(want)) == 0
+        assert ref_frame(rec, f, pics) == 0
+        for c in range(F.n_planes(p)):
+            assert np.array_equal(want[2].visible(c), pics[2].visible(c)), (name, seed, c)
+    if "lf_off" in name or "tiles_slices" in name:
+        assert any_flags, "no CTB edge was unfilterable: the case does not exercise sao_edge_filter[1]"
+    if "deblock_off" in name:
+        assert any_off
     rec.close()

@@ -180,9 +180,18 @@ __global__ __launch_bounds__(256) void deblock_chroma_kernel(const OhBatch B)
         return;
     const int bsw = W >> 2;
     const int bs = (HORIZ ? f->hbs : f->vbs)[(x + y * bsw) >> 2];
+    const int lc = pp.log2_ctb_size, ctbw = (W + (1 << lc) - 1) >> lc;
+    if (HORIZ && f->sao_stale && !(gx & 1)) {
+        /* 16x16 CTBs, subsampled chroma: deblocking_filter_CTB handles the horizontal chroma edges of a CTB's columns in the call
+         * for the NEXT CTB (hevc_filter.c:526-530), after sao_filter_CTB of the previous one has copied this column
+         * (ff_hevc_hls_filter, :1027-1052): keep what that SAO call saw — the unfiltered p0 / q0 of the CTB's first column */
+        const int st = f->cur.stride[c], xc = x >> hs, yc = y >> vs;
+        const GLOBAL PX *q = G_CONST(PX, f->cur.p[c]) + (size_t)yc * st + xc;
+        GLOBAL uint16_t *o = G_MUT(uint16_t, f->sao_stale) + oh_sao_stale_index(&pp, c, yc >> 3, xc >> 3);
+        o[0] = q[-st]; o[1] = q[0];
+    }
     if (bs != 2)
         return;
-    const int lc = pp.log2_ctb_size, ctbw = (W + (1 << lc) - 1) >> lc;
     int qp, tc_off;
     if (!HORIZ) {
         qp = (get_qpy(f, x - 1, y) + get_qpy(f, x, y) + 1) >> 1;

@@ -130,7 +130,17 @@ struct DevFrame {
     const OhSaoCtb  *sao;             /* may be null                                          */
     uint32_t n_pu, n_mc_luma, n_mc_chroma, n_tu, n_intra;
     uint64_t *dbg;                    /* diagnostic builds only (OH_STAMPS), null otherwise       */
+    /* 16x16 CTBs with horizontally subsampled chroma only (else null): the first chroma column of every CTB on the two rows of
+     * every horizontal chroma edge as it was BEFORE the horizontal-edge pass — the reference's CTB driver lets the SAO of the
+     * left neighbour read exactly that (deblock.hip: oh_sao_stale_*) */
+    uint16_t *sao_stale;              /* [plane - 1][edge row / 8][CTB column][p0, q0] */
 };
+static __host__ __device__ inline bool oh_sao_stale_config(const OhPicParams *p) { return p->log2_ctb_size == 4 && (p->chroma_format_idc == 1 || p->chroma_format_idc == 2); }
+static __host__ __device__ inline size_t oh_sao_stale_index(const OhPicParams *p, int plane, int edge_row8, int ctb_col)
+{
+    const int ctbw = (p->width + 15) >> 4, hc = p->height >> (p->chroma_format_idc == 1);
+    return (((size_t)(plane - 1) * (size_t)((hc >> 3) + 1) + (size_t)edge_row8) * (size_t)ctbw + (size_t)ctb_col) * 2;
+}
 
 /* one plane of the SHVC up-sampling pass (kernel argument) */
 struct OhUpPlane {

@@ -977,6 +977,10 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     const size_t copy_bytes = any_dense || !f->n_tu ? total : seg[s_coef].off;
     const size_t res_off = total;
     total += align_up((size_t)(f->n_coeff ? f->n_coeff : 1) * sizeof(int16_t), 256);
+    const bool stale_cfg = has_db && has_sao && oh_sao_stale_config(&p);       /* see DevFrame.sao_stale */
+    const size_t stale_off = total;
+    if (stale_cfg)
+        total += align_up(oh_sao_stale_index(&p, 3, 0, 0) * sizeof(uint16_t), 256);
 
     auto t_lists = tnow();
     OhDevFrame *df = new OhDevFrame();
@@ -1026,6 +1030,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.scaling = f->scaling ? (const OhScalingList *)(base + seg[s_scaling].off) : nullptr;
     hd.coeffs = (const int16_t *)(base + seg[s_coef].off);
     hd.res = (int16_t *)(base + res_off);
+    hd.sao_stale = stale_cfg ? (uint16_t *)(base + stale_off) : nullptr;
     hd.intra = (const DevIntra *)(base + seg[s_intra].off);
     hd.ictu = (const DevIntraCtu *)(base + seg[s_ictu].off);
     hd.sub_start = (const uint32_t *)(base + seg[s_sub].off);

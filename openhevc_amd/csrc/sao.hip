@@ -41,11 +41,22 @@ static __device__ __forceinline__ void store8(GLOBAL PX *p, const int v[8])
     __builtin_nontemporal_store(r, (GLOBAL typename Vec8<PX>::T *)p);     /* the output is next read by another picture's MC: stream it past the L2 */
 }
 
-struct SaoEdgeCtx { int x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd; };
+struct SaoEdgeCtx { int x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd; const GLOBAL uint16_t *stale; int stale_r, vs; };
+
+/* 16x16 CTBs with subsampled chroma (DevFrame.sao_stale): sample (x0 + 8, yr) — first column of the right neighbour — as
+ * sao_filter_CTB of this CTB saw it: rows touched by a horizontal chroma edge of a CTB row >= stale_r were not filtered yet */
+static __device__ __forceinline__ int sao_stale_or(const SaoEdgeCtx &e, const OhPicParams &pp, int c, int yr, int v)
+{
+    const int p0 = (yr & 7) == 7, ye = p0 ? yr + 1 : yr;
+    if ((ye & 7) == 0 && ye > 0 && ye < e.ph && ((ye << e.vs) >> 4) >= e.stale_r)
+        return e.stale[oh_sao_stale_index(&pp, c, ye >> 3, e.cx + 1) + (p0 ? 0 : 1)];
+    return v;
+}
 
 /* first neighbour a = (x+DX, y+DY), second b = (x-DX, y-DY) (pos[][] of hevcdsp_template.c:379-384) */
 template <typename PX, int DX, int DY>
-static __device__ __forceinline__ void sao_edge8(const GLOBAL PX *__restrict__ src, const SaoEdgeCtx &e, const int off[5], const int v[8], int r[8])
+static __device__ __forceinline__ void sao_edge8(const GLOBAL PX *__restrict__ src, const SaoEdgeCtx &e, const int off[5], const int v[8], int r[8],
+                                                 const OhPicParams &pp, const int c)
 {
     int a[10], b[10];                                       /* samples x-1..x+8 of rows y+DY and y-DY */
     const int ya = min(max(e.y + DY, 0), e.ph - 1), yb = min(max(e.y - DY, 0), e.ph - 1);
@@ -55,6 +66,7 @@ static __device__ __forceinline__ void sao_edge8(const GLOBAL PX *__restrict__ s
     if (DX != 0) {
         if (e.x > 0)        { a[0] = src[(size_t)ya * e.sstride + e.x - 1]; b[0] = src[(size_t)yb * e.sstride + e.x - 1]; }
         if (e.x + 8 < e.pw) { a[9] = src[(size_t)ya * e.sstride + e.x + 8]; b[9] = src[(size_t)yb * e.sstride + e.x + 8]; }
+        if (e.stale && e.cx + 2 < e.ctbw) { a[9] = sao_stale_or(e, pp, c, ya, a[9]); b[9] = sao_stale_or(e, pp, c, yb, b[9]); }
     }
     const int ly = e.y - e.y0;
 #pragma unroll
@@ -139,12 +151,15 @@ __global__ __launch_bounds__(256) void sao_kernel(const OhBatch B, const int str
         int off[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) off[k] = s->offset_val[c][k];
-        const SaoEdgeCtx ec = { x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd };
+        /* the chroma CTB is one 8-sample group wide in that configuration: x + 8 is the neighbour's first column */
+        const GLOBAL uint16_t *stale = c && pp.deblock_enabled ? G_CONST(uint16_t, f->sao_stale) : nullptr;
+        const SaoEdgeCtx ec = { x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd, stale,
+                                cy + 1 < ctbh - 2 ? cy + 1 : (ctbh >= 2 ? ctbh - 2 : 0), vs };
         switch (eo) {                                       /* compile-time neighbour offsets: no indexed registers */
-        case 0:  sao_edge8<PX, -1, 0>(src, ec, off, v, r); break;
-        case 1:  sao_edge8<PX, 0, -1>(src, ec, off, v, r); break;
-        case 2:  sao_edge8<PX, -1, -1>(src, ec, off, v, r); break;
-        default: sao_edge8<PX, 1, -1>(src, ec, off, v, r); break;
+        case 0:  sao_edge8<PX, -1, 0>(src, ec, off, v, r, pp, c); break;
+        case 1:  sao_edge8<PX, 0, -1>(src, ec, off, v, r, pp, c); break;
+        case 2:  sao_edge8<PX, -1, -1>(src, ec, off, v, r, pp, c); break;
+        default: sao_edge8<PX, 1, -1>(src, ec, off, v, r, pp, c); break;
         }
     }
     if (type && f->is_pcm && (pp.transquant_bypass_enable || pp.pcm_loop_filter_disable)) {

@@ -491,10 +491,24 @@ static int chroma_tc(const OhFrame *f, int qp_y, int c_idx, int tc_offset) /* he
     return oh_tc_table[oh_clip3(qp + 2 + tc_offset, 0, 53)];
 }
 
+/* The reference's CTB driver order leaks into the result in ONE configuration: 16x16 CTBs with horizontally subsampled chroma
+ * (chroma CTBs 8 samples wide).  deblocking_filter_CTB filters the chroma horizontal edges over [x0 - 16, x_end - 16) luma samples
+ * (hevc_filter.c:526-530), so the chroma columns of CTB X get their horizontal-edge filtering inside the call for CTB X + 1 — and
+ * sao_filter_CTB(X - 1, Y - 1) runs right after deblocking_filter_CTB(X, Y) (ff_hevc_hls_filter, :1027-1052), i.e. BEFORE the
+ * call for X + 1: the SAO of CTB (cx, cy) copies the first chroma column of its right neighbour (copy_CTB, :305-307) while the
+ * horizontal edges of the CTB rows r >= min(cy + 1, ctb_height - 2) have not touched that column yet (SAO(cx, cy) is triggered by
+ * decoding CTB (cx + 2, min(cy + 2, last row)), the deblocking call for CTB (cx + 2, r) by CTB (cx + 3, min(r + 1, last row)):
+ * in the last two CTB rows the lag between the two shrinks to one CTB).  With wider chroma CTBs, and for luma, the own first columns of a CTB are filtered in its own call and
+ * nothing is pending.  To reproduce it the deblock pass keeps the chroma planes as they are before its horizontal chroma
+ * edges; the SAO pass of the SAME picture (next call on this thread) patches the neighbour column from that. */
+static __thread struct { uint8_t *px[3]; size_t bytes[3]; const void *pic; int w, h, valid; } g_pre_h;
+static int sao_sees_stale_column(const OhPicParams *p) { return p->log2_ctb_size == 4 && oh_hshift(p, 1) == 1; }
+
 int oh_or_pass_deblock(const OhFrame *f, OhHostPic *pics)
 {
     const OhPicParams *p = &f->p;
     OhHostPic *cur = &pics[f->cur_pic];
+    g_pre_h.valid = 0;
     if (!p->deblock_enabled)
         return 0;
     int bd = p->bit_depth, bpp = bd > 8 ? 2 : 1;
@@ -570,6 +584,15 @@ int oh_or_pass_deblock(const OhFrame *f, OhHostPic *pics)
             oh_or_loop_filter_luma(bd, cur->data[0] + (ptrdiff_t)y * cur->stride[0] + x * bpp,
                                    cur->stride[0], bpp, beta, tc, no_p, no_q);
         }
+    if (p->chroma_format_idc && sao_sees_stale_column(p)) {
+        for (int c = 1; c < 3; c++) {
+            size_t n = (size_t)cur->stride[c] * cur->height[c];
+            if (g_pre_h.bytes[c] < n) { free(g_pre_h.px[c]); g_pre_h.px[c] = (uint8_t *)malloc(n); g_pre_h.bytes[c] = g_pre_h.px[c] ? n : 0; }
+            if (!g_pre_h.px[c]) return -1;
+            memcpy(g_pre_h.px[c], cur->data[c], n);
+        }
+        g_pre_h.pic = cur->data[0]; g_pre_h.w = W; g_pre_h.h = H; g_pre_h.valid = 1;
+    }
     if (p->chroma_format_idc)
         for (int y = 8 * vv; y < H; y += 8 * vv)
             for (int x = 0; x < W; x += 8 * hh) {
@@ -634,10 +657,27 @@ int oh_or_pass_sao(const OhFrame *f, OhHostPic *pics)
                 const uint8_t *src = copy + (ptrdiff_t)y0 * st + x0 * bpp;
                 if (s->type_idx[c] == 1)
                     oh_or_sao_band(bd, dst, src, st, st, s->offset_val[c], s->band_position[c], w, h);
-                else if (s->type_idx[c] == 2)
+                else if (s->type_idx[c] == 2) {
+                    /* 16x16 CTBs, subsampled chroma: the right neighbour's first column as the reference's driver order shows it
+                     * (comment at g_pre_h): rows touched by the horizontal edges of CTB rows >= r_pending are not filtered yet */
+                    const int stale = c && sao_sees_stale_column(p) && p->deblock_enabled && g_pre_h.valid && g_pre_h.pic == cur->data[0] &&
+                                      g_pre_h.w == p->width && g_pre_h.h == p->height && cx + 2 < ctbw;
+                    uint8_t saved[2 * (16 + 2)];
+                    const int r_pending = cy + 1 < ctbh - 2 ? cy + 1 : (ctbh >= 2 ? ctbh - 2 : 0), ya = y0 > 0 ? y0 - 1 : 0, yb = y0 + h < ph ? y0 + h : ph - 1;
+                    if (stale)
+                        for (int y = ya; y <= yb; y++) {
+                            uint8_t *px = copy + (ptrdiff_t)y * st + (x0 + w) * bpp;
+                            memcpy(saved + (y - ya) * bpp, px, (size_t)bpp);
+                            const int ye = (y & 7) == 7 ? y + 1 : y;                    /* the horizontal edge that touches row y: p0 row or q0 row */
+                            if ((ye & 7) == 0 && ye > 0 && ((ye << vs) >> lc) >= r_pending)
+                                memcpy(px, g_pre_h.px[c] + (ptrdiff_t)y * st + (x0 + w) * bpp, (size_t)bpp);
+                        }
                     oh_or_sao_edge(bd, dst, src, st, st, s->offset_val[c], s->eo_class[c], borders, w, h,
                                    s->edge_flags != 0, ve, he, de);
-                else
+                    if (stale)
+                        for (int y = ya; y <= yb; y++)
+                            memcpy(copy + (ptrdiff_t)y * st + (x0 + w) * bpp, saved + (y - ya) * bpp, (size_t)bpp);
+                } else
                     continue;
                 /* restore_tqb_pixels (hevc_filter.c:163-193): called with the CTB's LUMA origin but
                  * the COMPONENT's width/height, so for subsampled chroma only the min-PUs of the

@@ -87,6 +87,13 @@ CASES = [
     ("b10_bs_from_motion", 416, 240, 10, 1, 6, 2, {"bs_from_motion": 1, "intra_pct": 25}),
     ("p8_bs_from_motion_ctb16", 200, 136, 8, 1, 4, 1, {"bs_from_motion": 1, "vary_deblock_offsets": 1}),
     ("i8_422_bs_from_motion", 416, 240, 8, 2, 5, 0, {"bs_from_motion": 1}),
+    # 16x16 CTBs with subsampled chroma: the SAO of a CTB sees the first chroma column of its right neighbour before the horizontal-edge
+    # deblocking reached it (the reference's driver order, oracle.c: g_pre_h; deblock.hip / sao.hip: sao_stale); 1 and 2 CTB rows are special
+    ("i10_422_ctb16", 136, 88, 10, 2, 4, 0, {"sao_pct": 90}),
+    ("b8_ctb16_sao", 264, 200, 8, 1, 4, 2, {"sao_pct": 90, "intra_pct": 30}),
+    ("b8_ctb16_one_row", 96, 16, 8, 1, 4, 2, {"sao_pct": 90, "intra_pct": 30}),
+    ("i10_ctb16_two_rows", 96, 32, 10, 1, 4, 0, {"sao_pct": 90}),
+    ("b10_ctb16_slices", 264, 200, 10, 1, 4, 2, dict(n_slices=9, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),
     # several slices / tiles (pinned through the reference's own drivers in tests/test_oracle_picture_vs_ref.py): SAO restore flags
     # (sao_edge_filter[1]), boundary strengths gated at slice / tile edges, per-slice deblocking off / offsets, neighbour availability
     ("b8_slices_lf_off", 416, 240, 8, 1, 5, 2, dict(n_slices=6, sao_pct=80, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),

@@ -29,6 +29,13 @@ CASES = [
     (64, 64, 8, 0, 6),
     (136, 88, 8, 2, 6),          # 4:2:2
     (200, 136, 10, 2, 5),
+    # 16x16 CTBs with subsampled chroma: the reference's SAO sees its right neighbour's first chroma column before the
+    # horizontal-edge deblocking reached it (driver order, see oracle.c: g_pre_h); one and two CTB rows are special cases
+    (200, 136, 8, 1, 4),
+    (136, 88, 10, 2, 4),
+    (96, 16, 8, 1, 4),
+    (96, 32, 10, 1, 4),
+    (96, 40, 8, 2, 4),
 ]
 
 
@@ -255,10 +262,10 @@ def test_whole_picture_through_reference_kernels(case):
 SLICE_CASES = [
     # name, w, h, bd, chroma, log2_ctb, slice_type, synth knobs
     ("slices_lf_off", 416, 240, 8, 1, 5, 2, dict(n_slices=6, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
-    ("slices_deblock_off", 264, 200, 10, 1, 5, 2, dict(n_slices=9, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),
+    ("slices_deblock_off", 264, 200, 10, 1, 4, 2, dict(n_slices=9, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),
     ("slices_intra", 264, 200, 8, 1, 5, 0, dict(n_slices=5, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
     ("tiles_lf_off", 416, 240, 8, 1, 5, 2, dict(tile_cols=3, tile_rows=2, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES)),
-    ("tiles_slices", 416, 240, 10, 1, 5, 2, dict(tile_cols=2, tile_rows=3, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES | F.SYNTH_SLICE_PER_TILE |
+    ("tiles_slices", 416, 240, 10, 1, 4, 2, dict(tile_cols=2, tile_rows=3, slice_knobs=F.SYNTH_NO_LF_ACROSS_TILES | F.SYNTH_SLICE_PER_TILE |
                                                  F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_SLICE_OFFSETS)),
     ("tiles_lf_on_444", 200, 136, 8, 3, 5, 0, dict(tile_cols=2, tile_rows=2, slice_knobs=F.SYNTH_SLICE_PER_TILE | F.SYNTH_NO_LF_ACROSS_SLICES)),
     ("slices_bs_from_motion", 416, 240, 8, 1, 5, 2, dict(n_slices=6, bs_from_motion=1, slice_knobs=F.SYNTH_NO_LF_ACROSS_SLICES | F.SYNTH_DEBLOCK_OFF_SLICES)),

@@ -69,28 +69,38 @@ def cpu_baseline(params, plan_kwargs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
     ap.add_argument("--chains", type=int, default=None, help="closed GOPs (steps) in flight per GPU (default: 96; 24 for the 8K workloads, whose pictures are 100-200 MB)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
-    ap.add_argument("--sparse-pct", type=int, default=0, help="%% of transform blocks handed over as quantised levels (de-quantised on the GPU) instead of dense coefficients")
+    ap.add_argument("--mode", default="decode", choices=["decode", "kernel_only"],
+                    help="decode (the headline): every picture's work list is handed over inside the timed region — oh_frame_upload (validation, "
+                         "list preparation, H2D copy, boundary-strength pass when used), the passes, stream-ordered release; a second, shorter timed "
+                         "region then replays resident work lists and is reported beside it as `kernel_only`.  kernel_only: only that second figure")
+    ap.add_argument("--host-gops", type=int, default=4, help="distinct GOPs kept as host work lists (the chains in flight decode them round-robin, "
+                    "each into its own pictures): bounds host memory, every hand-over still copies its own bytes")
+    ap.add_argument("--sparse-pct", type=int, default=100, help="%% of transform blocks handed over as quantised levels and de-quantised on the GPU "
+                    "(SURVEY 8f rank 1: what residual_coding parses) instead of dense de-quantised coefficients (2 B per coded sample over PCIe)")
     ap.add_argument("--exchange", default="readers", choices=["readers", "allgather"],
                     help="N>1: send finished reference pictures to the ranks that reference them (point-to-point batches), or replicate them everywhere (one all-gather per chain and wave)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: REHEARSAL of the N>1 control flow with several ranks on one GPU (transfers staged through host memory)")
     ap.add_argument("--bs-from-motion", action="store_true", help="work lists carry the motion field instead of finished boundary-strength grids; "
-                    "the engine derives the grids at upload (bs_kernel, outside the timed region like the upload itself)")
+                    "the engine derives the grids at upload (bs_kernel: inside the timed region in decode mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
+    ap.add_argument("--no-check", action="store_true", help="skip the picture check after the timed region")
     args = ap.parse_args()
 
     # One HIP stream per chain only overlaps if the runtime maps them to distinct hardware queues
     # (ROCm default: 4).  Must be set before the HIP runtime starts.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, min(2 * args.streams + 4, 24))))   # engine streams + the collectives' own
+
+    import threading
 
     import torch
     import torch.distributed as dist
@@ -124,24 +134,31 @@ def main():
         args.chains = 96 if params.width * params.height <= 3840 * 2160 else 24
     n_chains = max(1, args.chains)
     n_streams = max(1, min(args.streams, n_chains))
-    groups = [[] for _ in range(n_streams)]                # per stream: [(plan, backend, process group)], one engine
+    knobs = dict(sparse_pct=args.sparse_pct, bs_from_motion=int(args.bs_from_motion))
+    # host work lists: --host-gops distinct GOPs (seeds), generated once — the stand-in for what the reference's CTU loop records
+    n_host = max(1, min(args.host_gops, n_chains))
+    host = []
+    for m in range(n_host):
+        plan_m = P.make_step_plan(world, rank, n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + m)
+        host.append((plan_m, P.host_work_lists(params, plan_m, knobs)))
+    host_bytes = sum(fc.bytes for _, (lists, _) in host for fc in lists.values())
+    groups = [[] for _ in range(n_streams)]                # per stream: [(stream, engine, process group), (plan, backend, group)...]
     chains = []
     for k in range(n_chains):
-        plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + k)
-        plan_k = P.make_step_plan(world, rank, **plan_kwargs)
+        plan_k, lists_k = host[k % n_host]
         g = groups[k % n_streams]
-        if not g:                                          # [0] = (stream, engine, process group) of the group
+        if not g:
             stream = torch.cuda.Stream()
             # the collectives of one stream are issued in the same order on every rank, so its chains share a
             # communicator; different streams must not (their collectives interleave differently per rank)
             g.append((stream, Engine(local_rank, stream=stream.cuda_stream), dist.new_group() if world > 1 else None))
         stream, engine, group = g[0]
         with torch.cuda.stream(stream):
-            be_k = P.EngineBackend(torch, local_rank, params, plan_k, knobs=dict(sparse_pct=args.sparse_pct, bs_from_motion=int(args.bs_from_motion)), engine=engine)
+            be_k = P.EngineBackend(torch, local_rank, params, plan_k, engine=engine, host_lists=lists_k, resident=False)
         g.append((plan_k, be_k, group))
         chains.append((plan_k, be_k, stream, group))
     engines = [g[0][1] for g in groups]
-    plan, be = chains[0][0], chains[0][1]
+    plan = chains[0][0]
     plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643)
     pics_per_step = P.pictures_per_step(plan) * n_chains      # a step advances every chain in flight by one GOP
 
@@ -151,126 +168,179 @@ def main():
         torch.cuda.synchronize()
 
     exchange = P.exchange_map(world, rank, args.waves, args.tail) if world > 1 and args.exchange == "readers" else None
+    # one host thread per engine / stream (an engine is a single-submitter object).  With N > 1 the streams' collectives must be
+    # issued in the same relative order on every rank, so one thread enqueues all streams.
+    host_threads = n_streams if world == 1 else 1
+
+    def run_group(g, n_steps):
+        with torch.cuda.stream(g[0][0]):
+            for _ in range(n_steps):
+                P.run_steps_batched(g[1:], dist if world > 1 else None, exchange)
 
     def run(n_steps):
         """one step = every chain in flight advances by one GOP: each stream runs its chains as lockstep batches"""
-        for _ in range(n_steps):
-            for g in groups:
-                with torch.cuda.stream(g[0][0]):
-                    P.run_steps_batched(g[1:], dist if world > 1 else None, exchange)
+        if host_threads == 1:
+            for _ in range(n_steps):
+                for g in groups:
+                    run_group(g, 1)
+            return
+        errs = []
 
-    run(max(args.warmup, 1))
-    barrier()
-    for eng in engines:
-        eng.pass_times(reset=True)
-        eng.n_batches = 0
-        eng.profile(0 if args.no_profile else 2)          # events between passes and around every intra launch
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    dt_enqueue = time.perf_counter() - t0                  # host time to record nothing and enqueue everything
-    barrier()
-    dt = time.perf_counter() - t0
-    for eng in engines:
-        eng.profile(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        def work(g):
+            try:
+                torch.cuda.set_device(local_rank)
+                run_group(g, n_steps)
+            except BaseException as exc:        # noqa: BLE001 - re-raised on the main thread
+                errs.append(exc)
+        ths = [threading.Thread(target=work, args=(g,)) for g in groups]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    def timed(n_warm, n_steps):
+        """(seconds of n_steps steps, host seconds until everything was enqueued); per-pass events of the region stay in the engines"""
+        run(max(n_warm, 1))
+        barrier()
+        for eng in engines:
+            eng.pass_times(reset=True)
+            eng.intra_launch_times(reset=True)
+            eng.n_batches = 0
+            eng.profile(0 if args.no_profile else 2)      # events between passes and around every intra launch
+        for _, be_k, _, _ in chains:
+            be_k.upload_s, be_k.uploads = 0.0, 0
+        barrier()
+        t0 = time.perf_counter()
+        run(n_steps)
+        dt_enqueue = time.perf_counter() - t0              # host time to hand everything over / enqueue everything
+        barrier()
+        dt = time.perf_counter() - t0
+        for eng in engines:
+            eng.profile(0)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, dt_enqueue
 
     luma_px = params.width * params.height
-    total_pics = world * pics_per_step * args.steps
-    value = total_pics * luma_px / dt / 1e6
+    b = 2 if params.bit_depth > 8 else 1
 
-    out = None
-    if rank == 0:
-        b = 2 if params.bit_depth > 8 else 1
-        pass_ms, n_exec, intra_ms, intra_n = None, 0, 0.0, 0
+    def collect(dt, n_steps):
+        """per-pass figures of the region just timed: HIP events on the engines' streams (this run, nothing read from profiles/)"""
+        pass_ms, n_exec, intra_ms, intra_n, per_stream = None, 0, 0.0, 0, []
         for eng in engines:                                # sum over the streams
             ms_k, n_k = eng.pass_times()
+            per_stream.append({k: round(v / n_steps, 3) for k, v in ms_k.items()})
             pass_ms = ms_k if pass_ms is None else {k: pass_ms[k] + ms_k[k] for k in ms_k}
             n_exec += n_k
             im, inn = eng.intra_launch_times()
             intra_ms += im
             intra_n += inn
-        roofline = None
-        if n_exec:
-            # algorithmic bytes of this rank's step, per pass (SURVEY.md §8d; openhevc_amd/parallel.py)
-            abytes = {k: 0.0 for k in pass_ms}             # per step: all chains (their streams differ by seed)
-            for plan_k, be_k, _, _ in chains:
-                for pic in plan_k.pictures():
-                    for k, v in P.algorithmic_bytes(be_k.stats[pic.name], b).items():
-                        abytes[k] += v
-            # The dominant kernel is the one with the largest total GPU time in the rocprofv3 kernel stats of this same command
-            # (profiles/, committed): with several streams sharing the chip, a pass's stream-elapsed time (below) also counts the
-            # time its launch waited for the other streams' kernels, so the largest stream-elapsed pass can flip between the
-            # intra pass and SAO from run to run (rocprofv3: sao_kernel executes 2.1 ms per launch, its stream sees 3.3 ms).
-            dom = max(pass_ms, key=lambda k: pass_ms[k])
-            spath = os.path.join(ROOT, "profiles", f"r01_kernel_stats_{args.workload}.csv")
-            if os.path.exists(spath):
-                import csv
-                share = {k: 0.0 for k in pass_ms}
-                for row in csv.DictReader(open(spath)):
-                    nm = row["Name"]
-                    k = ("intra" if nm.startswith("intra_ctu_kernel") else "sao" if nm.startswith("sao_kernel") else
-                         "inter" if nm.startswith("mc_kernel") else "residual" if nm.startswith(("residual_kernel", "cross_kernel")) else
-                         "deblock_v" if nm.startswith("deblock_") and nm.rstrip().endswith(", 0>") else
-                         "deblock_h" if nm.startswith("deblock_") else None)
-                    if k:
-                        share[k] += float(row["TotalDurationNs"])
-                if any(share.values()):
-                    dom = max(share, key=lambda k: share[k])
-            steps_timed = n_exec / float(pics_per_step)
-            ms_per_step_pass = pass_ms[dom] / steps_timed
-            # launches of the dominant pass in the timed region: every launch covers a batch of pictures
-            # (<= 32), so count what was launched, not pictures
-            if dom == "intra" and intra_n:                 # every launch bracketed by its own events
-                n_launch_total = intra_n
-                avg_launch_us = intra_ms * 1e3 / intra_n
-                launch_source = "HIP events around every launch of the pass, timed region, all streams"
-            else:
-                per_batch = dict(inter=2, residual=4, deblock_v=2, deblock_h=2, sao=1)[dom] if dom != "intra" else 1
-                n_launch_total = max(sum(e.n_batches for e in engines) * per_batch, 1)
-                avg_launch_us = pass_ms[dom] * 1e3 / n_launch_total
-                launch_source = "pass time between HIP events / launches, timed region, all streams"
-            n_launch = n_launch_total / steps_timed        # per step; a launch serves a batch of up to 32 pictures
-            achieved = (abytes[dom] * steps_timed / n_launch_total) / (avg_launch_us * 1e-6) / 1e9
-            # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
-            # rocprofv3 --pmc passes of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes
-            # for gfx950); recorded under profiles/ because bench.py cannot run the profiler on itself
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
-            if os.path.exists(tpath):
-                with open(tpath) as fh:
-                    for kname, rec in json.load(fh).items():
-                        if kname.startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0]):
-                            traffic = rec["hbm_bytes_per_launch_corrected"]
-                            break
-            roofline = dict(bound="hbm", kernel=PASS_KERNEL[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
-                            launches_per_step=round(n_launch, 3), avg_launch_us=round(avg_launch_us, 3), avg_launch_source=launch_source,
-                            algorithmic_bytes_per_launch=round(abytes[dom] * steps_timed / n_launch_total, 1),
-                            pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
-                            pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms})
-        knobs = dict(P.default_synth_knobs(), sparse_pct=args.sparse_pct, bs_from_motion=int(args.bs_from_motion))
+        if not n_exec:
+            return None
+        abytes = {k: 0.0 for k in pass_ms}                 # algorithmic bytes of this rank's step, per pass (SURVEY.md 8d; parallel.py)
+        for plan_k, be_k, _, _ in chains:
+            for pic in plan_k.pictures():
+                for k, v in P.algorithmic_bytes(be_k.stats[pic.name], b).items():
+                    abytes[k] += v
+        steps_timed = n_exec / float(pics_per_step)
+        # dominant pass = the largest share of the streams' time in THIS region.  With several streams sharing the chip a pass's
+        # stream-elapsed time also counts the time its launches waited for the other streams' kernels; the per-launch events of the
+        # intra pass (one launch per wavefront level) and launch counts of the other passes give the launch durations.
+        dom = max(pass_ms, key=lambda k: pass_ms[k])
+        if dom == "intra" and intra_n:
+            n_launch_total, avg_launch_us = intra_n, intra_ms * 1e3 / intra_n
+            launch_source = "HIP events around every launch of the pass, timed region, all streams"
+        else:
+            per_batch = dict(inter=2, residual=4, deblock_v=2, deblock_h=2, sao=1, intra=1)[dom]
+            n_launch_total = max(sum(e.n_batches for e in engines) * per_batch, 1)
+            avg_launch_us = pass_ms[dom] * 1e3 / n_launch_total
+            launch_source = "pass time between HIP events / launches of the pass, timed region, all streams"
+        achieved = (abytes[dom] * steps_timed / n_launch_total) / (avg_launch_us * 1e-6) / 1e9
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.workload}.json")
+        if os.path.exists(tpath):                          # rocprofv3 --pmc passes of this command, recorded under profiles/ (bench.py cannot profile itself)
+            with open(tpath) as fh:
+                for kname, rec in json.load(fh).items():
+                    if kname.startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0]):
+                        traffic, traffic_source = rec["hbm_bytes_per_launch_corrected"], os.path.relpath(tpath, ROOT)
+                        break
+        return dict(bound="hbm", kernel=PASS_KERNEL[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_source,
+                    dominant_pass=dom, dominant_by="largest sum of stream-elapsed pass time between HIP events, this run",
+                    launches_per_step=round(n_launch_total / steps_timed, 3), avg_launch_us=round(avg_launch_us, 3), avg_launch_source=launch_source,
+                    algorithmic_bytes_per_launch=round(abytes[dom] * steps_timed / n_launch_total, 1),
+                    pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
+                    pass_ms_per_step_per_stream=per_stream,
+                    pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms},
+                    pass_share={k: round(v / max(sum(pass_ms.values()), 1e-9), 4) for k, v in pass_ms.items()})
+
+    total_pics = world * pics_per_step * args.steps
+    decode = None
+    if args.mode == "decode":
+        dt, dt_enq = timed(args.warmup, args.steps)
+        up_s = sum(be_k.upload_s for _, be_k, _, _ in chains)
+        n_up = sum(be_k.uploads for _, be_k, _, _ in chains)
+        decode = dict(dt=dt, dt_enqueue=dt_enq, roofline=collect(dt, args.steps) if rank == 0 else None,
+                      upload_ms_per_picture=round(up_s * 1e3 / max(n_up, 1), 4))
+    # resident work lists: the same passes without the hand-over
+    k_steps = args.steps if args.mode == "kernel_only" else max(2, args.steps // 2)
+    k_warm = args.warmup if args.mode == "kernel_only" else 1
+    for g in groups:
+        with torch.cuda.stream(g[0][0]):
+            for _, be_k, _ in g[1:]:
+                be_k.make_resident()
+    kdt, kdt_enq = timed(k_warm, k_steps)
+    kernel_only = dict(dt=kdt, dt_enqueue=kdt_enq, roofline=collect(kdt, k_steps) if rank == 0 else None)
+
+    # the pictures of the timed regions are real pictures: one chain's GOP against the checker (bit-exact) before anything is printed
+    check = None
+    if rank == 0 and not args.no_check:
+        check = check_pictures(params, chains[0], world)
+        if not check["ok"]:
+            print(f"bench.py: PICTURE MISMATCH against the checker: {check}", file=sys.stderr)
+            sys.exit(4)
+
+    out = None
+    if rank == 0:
+        head = decode if decode is not None else kernel_only
+        steps_h = args.steps if decode is not None else k_steps
+        dt_h = head["dt"]
+        n_pics_h = world * pics_per_step * steps_h
+        kv = world * pics_per_step * k_steps
+        gen = dict(P.default_synth_knobs(), **knobs)
         out = {
-            "metric": "decoded Mpixels/s (luma), synthetic stream, bit-exact vs reference-pinned oracle",
-            "value": round(value, 2), "unit": "Mpixels/s", "fps": round(total_pics / dt, 2),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 4),
+            "metric": "decoded Mpixels/s (luma), synthetic stream" + ("" if check is None else ", pictures of the run checked bit-exact against the reference-pinned oracle"),
+            "value": round(n_pics_h * luma_px / dt_h / 1e6, 2), "unit": "Mpixels/s", "fps": round(n_pics_h / dt_h, 2),
+            "n_gpus": world, "steps": steps_h, "warmup": args.warmup if decode is not None else k_warm, "ms_per_step": round(dt_h / steps_h * 1e3, 4),
+            "host_enqueue_ms_per_step": round(head["dt_enqueue"] / steps_h * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if params.bit_depth == 8 else "u16", "data": "synthetic",
+            "mode": ("decode: every picture's work list handed over inside the timed region (oh_frame_upload = validation + list preparation + H2D, "
+                     "passes, stream-ordered release)" if decode is not None else "kernel_only: resident work lists replayed"),
+            "host_threads": host_threads,
+            "upload_ms_per_picture": decode["upload_ms_per_picture"] if decode is not None else None,
+            "kernel_only": {"value": round(kv * luma_px / kernel_only["dt"] / 1e6, 2), "fps": round(kv / kernel_only["dt"], 2), "steps": k_steps,
+                            "ms_per_step": round(kernel_only["dt"] / k_steps * 1e3, 4),
+                            "host_enqueue_ms_per_step": round(kernel_only["dt_enqueue"] / k_steps * 1e3, 4),
+                            "what": "the same passes over work lists already resident in HBM (no hand-over)",
+                            "roofline": kernel_only["roofline"] if decode is not None else None},
             "config": {"workload": args.workload, "width": params.width, "height": params.height, "bit_depth": params.bit_depth,
                        "chroma_format_idc": params.chroma_format_idc, "pictures_per_step_per_gpu": pics_per_step,
                        "step": f"every chain in flight advances by one closed GOP (1 I + {args.waves - 1} reference B + {args.tail} "
                                f"non-reference B pictures): {n_chains} GOPs per GPU and step",
                        "chains_in_flight_per_gpu": n_chains, "streams_per_gpu": n_streams,
+                       "host_work_lists": f"{n_host} distinct GOPs, {round(host_bytes / n_host / P.pictures_per_step(plan) / 1e6, 2)} MB per picture on average",
                        "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
                        "exchange": ("none (1 GPU)" if world == 1 else
                                     "finished reference pictures sent point-to-point (RCCL) to the ranks that reference them, one batch per wave and stream"
                                     if exchange is not None else "one RCCL all-gather of the finished reference pictures per chain and wave"),
-                       "generator": dict(knobs, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
-            "roofline": roofline,
+                       "generator": dict(gen, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
+            "roofline": head["roofline"],
+            "check": check,
         }
     for _, be_k, _, _ in chains:
         be_k.close()
@@ -284,6 +354,34 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def check_pictures(params, chain, world):
+    """Downloads pictures of chain 0 as the timed regions left them — the last reference picture and the last non-reference picture of
+    its GOP — and decodes the same GOP with the CPU checker (oracle/, test infrastructure: never part of what was timed).  With N > 1
+    the references decoded by other ranks are taken from this rank's copies of them (which the exchange delivered)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
+    from oracle_lib import host_pic_array, oracle
+    plan, be, stream, _ = chain
+    be.engine.sync()
+    names = [p.name for p in plan.pictures()]
+    host_id = {n: i for i, n in enumerate(be.store.names())}
+    pics = {}
+    for n in be.store.names():
+        pics[host_id[n]] = be.engine.pic_download(be.ids[n], params)
+    want = {k: v.copy() for k, v in pics.items()}
+    bad = []
+    for pic in plan.pictures():                              # decode order: waves, then the tail
+        f = be.host_lists[pic.name].with_ids(host_id[pic.name], [host_id[r] for r in pic.refs])
+        if oracle().oh_or_frame(C.byref(f), host_pic_array(want)) != 0:
+            return dict(ok=False, error="checker failed")
+        if not want[host_id[pic.name]].equal(pics[host_id[pic.name]]):
+            bad.append(str(pic.name))
+        if world > 1:                                        # keep going from the engine's pictures: remote references are inputs
+            want[host_id[pic.name]] = pics[host_id[pic.name]].copy()
+    return dict(ok=not bad, pictures=len(names), mismatching=bad, checker="oracle/liboracle.so (pinned against the reference, tests/)")
 
 
 if __name__ == "__main__":

@@ -102,7 +102,10 @@ int oh_frame_execute(OhEngine *e, OhDevFrame *df);
  * is ONE launch over all of them, which is how pictures of independent sequences / GOPs (the reference's
  * frame threads, pthread_frame.c) fill the GPU while each picture's own dependency chain is short of it */
 int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n);      /* n == 0: nothing to do, OH_OK */
-int oh_frame_free(OhEngine *e, OhDevFrame *df);
+int oh_frame_free(OhEngine *e, OhDevFrame *df);          /* waits for the engine stream, then frees */
+/* same without the wait: legal right after the last oh_frame(s)_execute of df was ENQUEUED — the device memory is recycled in
+ * stream order (a decoder that uploads, executes and forgets one work list per picture never blocks on the GPU) */
+int oh_frame_release(OhEngine *e, OhDevFrame *df);
 /* the boundary-strength grids of an uploaded work list as the deblock pass will read them: the ones handed over, or — with
  * OhFrame.bs_in — the ones the engine derived from the motion field at upload (hevc_filter.c:584-941).
  * bytes: size of each destination, at most oh_bs_size() is copied */

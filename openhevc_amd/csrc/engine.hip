@@ -51,6 +51,8 @@ struct OhDevFrame {
     uint32_t   ref_gen[OH_MAX_REFS];
     uint8_t    ref_half[OH_MAX_REFS];
     uint16_t   ref_used = 0;      /* bit i: some PU predicts from slot i */
+    hipEvent_t ready = nullptr;   /* recorded on the copy stream behind the work list's H2D copy */
+    bool       waited = false;    /* the engine stream already waits for `ready` */
     const struct OhEngine *owner = nullptr;   /* picture ids and arenas belong to one engine */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
@@ -79,8 +81,13 @@ struct OhEngine {
      * a staging buffer is busy until the H2D copy that reads it has passed `done` */
     struct Stage { void *p; size_t bytes; hipEvent_t done; bool busy; };
     std::vector<Stage> stages;
-    struct Arena { void *p; size_t bytes; };
+    /* work lists travel on their own stream so that the copy of picture n+1 overlaps the passes of picture n; the engine stream
+     * waits for a list's `ready` event before the first kernel that reads it, and a recycled arena is not overwritten before
+     * the engine stream has passed the event recorded when it was released */
+    hipStream_t copy_stream = nullptr;
+    struct Arena { void *p; size_t bytes; hipEvent_t free_ev; };
     std::vector<Arena> arenas;               /* free device arenas */
+    std::vector<hipEvent_t> sync_events;     /* pool of timing-disabled events (ready / free_ev) */
     int16_t    *up_tmp = nullptr;        /* intermediate rows of oh_pic_upsample */
     size_t      up_tmp_elems = 0;
     uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
@@ -106,6 +113,7 @@ struct OhEngine {
     } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+enum { OH_MAX_STAGES = 48 };             /* pinned staging buffers per engine before the host is made to wait */
 
 static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_ext)
 {
@@ -126,6 +134,8 @@ static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_e
     } else if (ok) {
         ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
     }
+    if (ok)
+        ok = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) == hipSuccess;
     if (!ok || ohk_init() != 0) {
         fprintf(stderr, "ohevc_hip: device %d initialisation failed\n", device);
         delete e;
@@ -162,17 +172,40 @@ extern "C" int oh_engine_create_on_stream(OhEngine **out, int device, void *hip_
 extern "C" const char *oh_engine_last_error(const OhEngine *e) { return e ? e->err.c_str() : "no engine"; }
 extern "C" void *oh_engine_stream(OhEngine *e) { return e ? (void *)e->stream : nullptr; }
 
-/* arenas go back to the engine's pool: the next upload that reuses one is ordered behind everything enqueued on the
- * engine stream, so kernels that still read the old contents are not disturbed */
-static void free_dev_frame(OhEngine *e, OhDevFrame *df)
+static hipEvent_t sync_event_get(OhEngine *e)
+{
+    hipEvent_t ev = nullptr;
+    if (!e->sync_events.empty()) { ev = e->sync_events.back(); e->sync_events.pop_back(); return ev; }
+    return hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess ? ev : nullptr;
+}
+static void sync_event_put(OhEngine *e, hipEvent_t ev)
+{
+    if (!ev) return;
+    if (e->sync_events.size() < 4096) e->sync_events.push_back(ev); else (void)hipEventDestroy(ev);
+}
+
+/* arenas go back to the engine's pool.  in_flight: kernels enqueued on the engine stream may still read the arena — an event
+ * recorded there now tells the copy stream when the next work list may overwrite it. */
+static void free_dev_frame(OhEngine *e, OhDevFrame *df, bool in_flight = false)
 {
     if (!df)
         return;
+    if (e && df->ready)
+        sync_event_put(e, df->ready);
     if (df->arena) {
-        if (e && e->arenas.size() < 256)
-            e->arenas.push_back({ df->arena, df->arena_bytes });
-        else
+        if (e && e->arenas.size() < 256) {
+            hipEvent_t fe = nullptr;
+            if (in_flight && (fe = sync_event_get(e)) != nullptr && hipEventRecord(fe, e->stream) != hipSuccess) {
+                sync_event_put(e, fe);
+                fe = nullptr;
+            }
+            if (in_flight && !fe)
+                (void)hipStreamSynchronize(e->stream);           /* no event to be had: wait instead */
+            e->arenas.push_back({ df->arena, df->arena_bytes, fe });
+        } else {
+            if (in_flight) (void)hipStreamSynchronize(e->stream);
             (void)hipFree(df->arena);
+        }
     }
     delete df;
 }
@@ -195,6 +228,7 @@ extern "C" void oh_engine_destroy(OhEngine *e)
         return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     for (OhDevFrame *df : e->deferred)
         free_dev_frame(e, df);
     for (Pic &p : e->pics)
@@ -207,7 +241,9 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &s : e->ev_pending)
         for (auto &ev : s.ev) (void)hipEventDestroy(ev);
     for (auto &c : e->stages) { (void)hipEventDestroy(c.done); (void)hipHostFree(c.p); }
-    for (auto &a : e->arenas) (void)hipFree(a.p);
+    for (auto &a : e->arenas) { if (a.free_ev) (void)hipEventDestroy(a.free_ev); (void)hipFree(a.p); }
+    for (auto &ev : e->sync_events) (void)hipEventDestroy(ev);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->up_tmp)
         (void)hipFree(e->up_tmp);
     if (e->own_stream)
@@ -439,6 +475,17 @@ static OhEngine::Stage *stage_acquire(OhEngine *e, size_t bytes)
     }
     if (sg)
         return sg;
+    /* every buffer is busy: beyond OH_MAX_STAGES wait for one whose copy is furthest along instead of pinning more host memory
+     * (this is what throttles a host that hands pictures over faster than PCIe and the passes take them) */
+    if (e->stages.size() >= OH_MAX_STAGES) {
+        for (auto &c : e->stages)
+            if (c.busy && c.bytes >= bytes) {
+                if (hipEventSynchronize(c.done) != hipSuccess)
+                    return nullptr;
+                c.busy = false;
+                return &c;
+            }
+    }
     OhEngine::Stage c;
     c.bytes = align_up(bytes, (size_t)4 << 20); c.busy = false; c.p = nullptr; c.done = nullptr;
     if (hipHostMalloc(&c.p, c.bytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess) {
@@ -992,11 +1039,16 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
                 best = (int)i;
         if (best >= 0) {
             df->arena = e->arenas[best].p; df->arena_bytes = e->arenas[best].bytes;
+            if (e->arenas[best].free_ev) {                  /* released while passes were in flight: the copy must stay behind them */
+                (void)hipStreamWaitEvent(e->copy_stream, e->arenas[best].free_ev, 0);
+                sync_event_put(e, e->arenas[best].free_ev);
+            }
             e->arenas.erase(e->arenas.begin() + best);
         } else {
             df->arena_bytes = align_up(total, (size_t)1 << 20);
             if (hipMalloc(&df->arena, df->arena_bytes) != hipSuccess) {
-                for (auto &a : e->arenas) (void)hipFree(a.p);          /* the pool may be what is in the way */
+                (void)hipStreamSynchronize(e->stream);
+                for (auto &a : e->arenas) { sync_event_put(e, a.free_ev); (void)hipFree(a.p); }      /* the pool may be what is in the way */
                 e->arenas.clear();
                 if (hipMalloc(&df->arena, df->arena_bytes) != hipSuccess) {
                     df->arena = nullptr;
@@ -1059,10 +1111,18 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
             memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
     /* asynchronous: the caller's arrays are already copied out; the pinned buffer stays busy until `done` */
-    hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, e->stream);
+    hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, e->copy_stream);
     if (hrc == hipSuccess)
-        hrc = hipEventRecord(sg->done, e->stream);
+        hrc = hipEventRecord(sg->done, e->copy_stream);
+    if (hrc == hipSuccess && (df->ready = sync_event_get(e)) == nullptr)
+        hrc = hipErrorOutOfMemory;
+    if (hrc == hipSuccess)
+        hrc = hipEventRecord(df->ready, e->copy_stream);
     if (hrc == hipSuccess && bsi) {                        /* both grids from the maps: once per work list, the maps never change */
+        hrc = hipStreamWaitEvent(e->stream, df->ready, 0);
+        df->waited = true;
+    }
+    if (hrc == hipSuccess && bsi) {
         char *b = (char *)df->arena;
         hrc = hipMemsetAsync(b + seg[s_vbs].off, 0, bs_bytes, e->stream);                   /* the padded tail is read by the deblock pass */
         if (hrc == hipSuccess) hrc = hipMemsetAsync(b + seg[s_hbs].off, 0, bs_bytes, e->stream);
@@ -1125,6 +1185,10 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
         std::vector<Patch> patches;
         for (int i = 0; i < n; i++) {
             OhDevFrame *df = dfs[i];
+            if (!df->waited) {                              /* the list's copy runs on the copy stream */
+                HIPCHK(e, hipStreamWaitEvent(st, df->ready, 0));
+                df->waited = true;
+            }
             Pic *c = get_pic(e, df->cur_pic);
             if (!c || c->gen != df->cur_gen)
                 FAIL(e, OH_E_ARG, "batch: picture %d's cur_pic %d was freed after the upload", i, df->cur_pic);
@@ -1299,7 +1363,24 @@ extern "C" int oh_frame_free(OhEngine *e, OhDevFrame *df)
         return OH_E_ARG;
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (df->ready)
+        HIPCHK(e, hipEventSynchronize(df->ready));          /* never executed: its copy may still be running */
     free_dev_frame(e, df);
+    return OH_OK;
+}
+
+/* stream-ordered release: the arena returns to the pool at once; whoever reuses it fills it with a copy enqueued on the engine
+ * stream, i.e. behind every pass that still reads it.  No host wait (oh_frame_free waits for the stream first). */
+extern "C" int oh_frame_release(OhEngine *e, OhDevFrame *df)
+{
+    if (!e || !df)
+        return OH_E_ARG;
+    if (df->owner != e)
+        FAIL(e, OH_E_ARG, "oh_frame_release: work list of another engine");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!df->waited && df->ready)
+        HIPCHK(e, hipStreamWaitEvent(e->stream, df->ready, 0));      /* never executed: the release still has to stay behind its copy */
+    free_dev_frame(e, df, true);
     return OH_OK;
 }
 
@@ -1322,6 +1403,8 @@ extern "C" int oh_frame_download_bs(OhEngine *e, OhDevFrame *df, uint8_t *vbs, u
     if (df->owner != e || !df->p.deblock_enabled)
         FAIL(e, OH_E_ARG, "oh_frame_download_bs: work list of another engine / without deblocking");
     HIPCHK(e, hipSetDevice(e->device));
+    if (df->ready)
+        HIPCHK(e, hipEventSynchronize(df->ready));          /* the list arrives on the copy stream */
     DevFrame hd;
     HIPCHK(e, hipMemcpyAsync(&hd, df->d, sizeof(hd), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -62,6 +62,7 @@ def lib():
         L.oh_pic_upsample.argtypes = [V, C.c_int, C.c_int, V]
         L.oh_frames_execute.argtypes = [V, C.POINTER(C.c_void_p), C.c_int]
         L.oh_frame_free.argtypes = [V, V]
+        L.oh_frame_release.argtypes = [V, V]
         L.oh_frame_download_bs.argtypes = [V, V, V, V, C.c_size_t]
         L.oh_frame_submit.argtypes = [V, C.POINTER(F.OhFrame)]
         L.oh_engine_profile.argtypes = [V, I]
@@ -198,6 +199,10 @@ class Engine:
 
     def frame_free(self, df):
         self._chk(self.L.oh_frame_free(self.h, df), "oh_frame_free")
+
+    def frame_release(self, df):
+        """stream-ordered free (no host wait): call after the last execute of df was enqueued"""
+        self._chk(self.L.oh_frame_release(self.h, df), "oh_frame_release")
 
     def frame_submit(self, frame):
         self._chk(self.L.oh_frame_submit(self.h, C.byref(frame)), "oh_frame_submit")

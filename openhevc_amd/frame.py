@@ -311,3 +311,70 @@ class HostPic:
 
     def equal(self, other):
         return all(np.array_equal(self.visible(c), other.visible(c)) for c in range(len(self.planes)))
+
+
+class FrameCopy:
+    """Deep copy of a finished work list: every array the OhFrame points at is copied into memory this object owns, so the
+    list outlives the recorder's next picture.  `.frame` is an OhFrame over the copies (cur_pic / ref_pics as recorded)."""
+
+    def __init__(self, f):
+        p = f.p
+        self.keep = []
+        g = OhFrame()
+        C.memmove(C.byref(g), C.byref(f), C.sizeof(OhFrame))
+
+        def dup(ptr, nbytes, ctype):
+            if not ptr or nbytes == 0:
+                return C.cast(None, C.POINTER(ctype))
+            buf = np.frombuffer(C.string_at(ptr, int(nbytes)), dtype=np.uint8).copy()
+            self.keep.append(buf)
+            return C.cast(buf.ctypes.data, C.POINTER(ctype))
+
+        hs, vs = hshift(p, 1), vshift(p, 1)
+        n_ctb = ((p.width + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size) * ((p.height + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size)
+        n_pu = (p.width >> p.log2_min_pu_size) * (p.height >> p.log2_min_pu_size)
+        n_tb = (p.width >> p.log2_min_tb_size) * (p.height >> p.log2_min_tb_size)
+        n_qp = ((p.width >> p.log2_min_cb_size) + 1) * ((p.height >> p.log2_min_cb_size) + 1)
+        g.pu = dup(f.pu, f.n_pu * C.sizeof(OhPu), OhPu)
+        g.wp = dup(f.wp, f.n_wp * C.sizeof(OhWeights), OhWeights)
+        g.tu = dup(f.tu, f.n_tu * C.sizeof(OhTu), OhTu)
+        g.coeffs = dup(f.coeffs, f.n_coeff * 2, C.c_int16)
+        g.intra = dup(f.intra, f.n_intra * C.sizeof(OhIntra), OhIntra)
+        g.ictu = dup(f.ictu, f.n_ictu * C.sizeof(OhIntraCtu), OhIntraCtu)
+        g.sub_start = dup(f.sub_start, (f.n_sub + 1) * 4 if f.n_intra else 0, C.c_uint32)
+        g.level_start = dup(f.level_start, (f.n_levels + 1) * 4 if f.n_intra else 0, C.c_uint32)
+        g.vertical_bs = dup(f.vertical_bs, f.bs_size, C.c_uint8)
+        g.horizontal_bs = dup(f.horizontal_bs, f.bs_size, C.c_uint8)
+        g.qp_y_tab = dup(f.qp_y_tab, n_qp, C.c_int8)
+        g.is_pcm = dup(f.is_pcm, n_pu, C.c_uint8)
+        g.deblock = dup(f.deblock, n_ctb * C.sizeof(OhDeblockCtb), OhDeblockCtb)
+        g.sao = dup(f.sao, n_ctb * C.sizeof(OhSaoCtb), OhSaoCtb)
+        g.is_intra = dup(f.is_intra, n_pu, C.c_uint8)
+        g.sparse = dup(f.sparse, f.n_sparse * 4, C.c_uint32)
+        g.tu_sparse = dup(f.tu_sparse, f.n_tu * 4 if f.sparse else 0, C.c_uint32)
+        g.tu_cross = dup(f.tu_cross, f.n_tu * 4, C.c_uint32)
+        if f.scaling:
+            buf = np.frombuffer(C.string_at(f.scaling, 4 * 6 * 64 + 12), dtype=np.uint8).copy()
+            self.keep.append(buf)
+            g.scaling = buf.ctypes.data
+        if f.bs_in:
+            src = C.cast(f.bs_in, C.POINTER(OhBsInputs)).contents
+            bi = OhBsInputs()
+            for name, n in (("mvf", n_pu * C.sizeof(OhMvField)), ("cbf_luma", n_tb), ("call_log2", n_tb), ("ctb_flags", n_ctb)):
+                buf = np.frombuffer(C.string_at(getattr(src, name), int(n)), dtype=np.uint8).copy()
+                self.keep.append(buf)
+                setattr(bi, name, buf.ctypes.data)
+            bi.loop_filter_across_tiles = src.loop_filter_across_tiles
+            self.keep.append(bi)
+            g.bs_in = C.addressof(bi)
+        self.frame = g
+        self.bytes = sum(b.nbytes for b in self.keep if isinstance(b, np.ndarray))
+
+    def with_ids(self, cur_pic, ref_pics):
+        """header copy whose picture ids are replaced (the arrays are shared)"""
+        g = OhFrame()
+        C.memmove(C.byref(g), C.byref(self.frame), C.sizeof(OhFrame))
+        g.cur_pic = int(cur_pic)
+        for i in range(OH_MAX_REFS):
+            g.ref_pics[i] = int(ref_pics[i]) if i < len(ref_pics) else -1
+        return g

@@ -215,11 +215,31 @@ class PictureStore:
         return out + [p.name for p in self.plan.tail]
 
 
+def host_work_lists(params, plan, knobs=None):
+    """The host side of one GOP: {picture name: frame.FrameCopy} + {name: stats}.  What the reference's CTU loop would have recorded
+    (here: the synthetic generator); picture ids are placeholders, EngineBackend binds them to its own pictures."""
+    from . import frame as F
+    knobs = dict(default_synth_knobs(), **(knobs or {}))
+    rec = F.Recorder(params)
+    lists, stats = {}, {}
+    for pic in plan.pictures():
+        sp = F.synth_params(pic.slice_type, pic.seed, n_refs=max(len(pic.refs), 0), **knobs)
+        f = rec.synth(sp, 0, list(range(1, 1 + len(pic.refs))))
+        stats[pic.name] = frame_stats(f)
+        lists[pic.name] = F.FrameCopy(f)
+    rec.close()
+    return lists, stats
+
+
 class EngineBackend(Backend):
-    def __init__(self, torch, device_index, params, plan, knobs=None, engine=None):
+    def __init__(self, torch, device_index, params, plan, knobs=None, engine=None, host_lists=None, resident=True):
         """engine: share another backend's engine (its stream, picture ids and batches); None = own engine
-        on the current torch stream"""
-        from . import frame as F
+        on the current torch stream.
+        host_lists: (lists, stats) of host_work_lists() to decode (several chains may share one host copy: every chain binds
+        the lists to its OWN pictures); None = generate this plan's.
+        resident: True = every work list is uploaded once, now, and execute() replays it (kernel-only timing);
+        False = every execute() uploads the picture's work list first (validation, list preparation, H2D) and releases it
+        right after the passes are enqueued — what a decoder does per picture."""
         from .engine import Engine
         self.torch, self.params, self.plan = torch, params, plan
         dev = torch.device("cuda", device_index)
@@ -231,26 +251,46 @@ class EngineBackend(Backend):
         for name in self.store.names():
             h0, h1 = self.store.halves(name)
             self.ids[name] = self.engine.pic_wrap(params, h0.data_ptr(), h1.data_ptr(), self.store.half_bytes)
+        lists, self.stats = host_lists if host_lists is not None else host_work_lists(params, plan, knobs)
+        self.host_lists = lists                                   # keeps the arrays alive
+        self.headers = {pic.name: lists[pic.name].with_ids(self.ids[pic.name], [self.ids[r] for r in pic.refs]) for pic in plan.pictures()}
         self.frames: Dict[Tuple, object] = {}
-        self.stats: Dict[Tuple, dict] = {}
-        knobs = dict(default_synth_knobs(), **(knobs or {}))
-        rec = F.Recorder(params)
-        for pic in plan.pictures():
-            sp = F.synth_params(pic.slice_type, pic.seed, n_refs=max(len(pic.refs), 0), **knobs)
-            f = rec.synth(sp, self.ids[pic.name], [self.ids[r] for r in pic.refs])
-            self.stats[pic.name] = frame_stats(f)
-            self.frames[pic.name] = self.engine.frame_upload(f)
-        rec.close()
+        self.resident = False
+        self.upload_s, self.uploads = 0.0, 0                      # host time spent inside oh_frame_upload
+        if resident:
+            self.make_resident()
+
+    def make_resident(self):
+        for name, hdr in self.headers.items():
+            self.frames[name] = self.engine.frame_upload(hdr)
+        self.resident = True
+
+    def drop_resident(self):
+        self.engine.sync()
+        for df in self.frames.values():
+            self.engine.frame_free(df)
+        self.frames = {}
+        self.resident = False
 
     def wave_tensor(self, wave):
         return self.store.waves[wave]
 
     def execute(self, name):
-        self.engine.frame_execute(self.frames[name])
+        self.execute_batch([(self, name)])
 
     def execute_batch(self, items):
         assert all(be.engine is self.engine for be, _ in items), "a batch runs on one engine"
-        self.engine.frames_execute([be.frames[name] for be, name in items])
+        if all(be.resident for be, _ in items):
+            self.engine.frames_execute([be.frames[name] for be, name in items])
+            return
+        import time
+        t0 = time.perf_counter()
+        dfs = [self.engine.frame_upload(be.headers[name]) for be, name in items]
+        self.upload_s += time.perf_counter() - t0
+        self.uploads += len(dfs)
+        self.engine.frames_execute(dfs)
+        for df in dfs:
+            self.engine.frame_release(df)
 
     def final_half(self, name):
         return self.engine.pic_final_half(self.ids[name])
@@ -259,9 +299,7 @@ class EngineBackend(Backend):
         self.engine.pic_set_final_half(self.ids[name], half)
 
     def close(self):
-        self.engine.sync()
-        for df in self.frames.values():
-            self.engine.frame_free(df)
+        self.drop_resident()
         if self.own_engine:
             self.engine.close()
 

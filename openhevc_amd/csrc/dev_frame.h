@@ -101,6 +101,21 @@ struct DevTu { OhTu t; uint32_t sparse_off; };     /* 16 bytes */
 /* cross-component prediction of one chroma block (OH_TUF_CROSS): residual_c += (scale * residual_y) >> 3 */
 struct DevCross { uint16_t x, y; uint8_t c_idx, log2_size, flags; int8_t scale; uint32_t res_c, res_y; };    /* 16 bytes */
 
+/* what the preparation kernels (prep.hip) report back to the host: the first violation found in the work list, and what
+ * sizes the launches (the host reads it — a few hundred bytes, copied to pinned memory behind the kernels — before the first
+ * execute of the list) */
+enum { OH_PE_OK = 0, OH_PE_PU = 1, OH_PE_TU = 2, OH_PE_INTRA = 3, OH_PE_INTRA_TABLES = 4 };
+struct DevLevelStat {                 /* one intra wavefront level: what sizes the launch that runs it */
+    uint32_t n_ctu, max_items, max_sub, max_res, staged, pad;
+    uint64_t sum_items, sum_sub;
+};                                    /* 40 bytes */
+struct DevSummary {
+    uint32_t err, err_item;           /* OH_PE_*, index of the offending item */
+    uint32_t tu_cnt[4], n_cross, n_levels;
+    /* DevLevelStat[n_levels] follows */
+};
+struct OhPrepCounts { uint32_t n_pu, n_mc_luma, n_mc_chroma, n_tu, n_intra, n_sub, n_ictu, n_levels; };
+
 struct DevFrame {
     OhPicParams pp;
     DevPlanes   cur;              /* reconstruction / deblock buffer of the current picture   */
@@ -130,6 +145,23 @@ struct DevFrame {
     const OhSaoCtb  *sao;             /* may be null                                          */
     uint32_t n_pu, n_mc_luma, n_mc_chroma, n_tu, n_intra;
     uint64_t *dbg;                    /* diagnostic builds only (OH_STAMPS), null otherwise       */
+    /* the raw lists as handed over (include/ohevc_frame.h) — inputs of the preparation kernels (prep.hip), which write the
+     * lists above (mc_luma .. lvl_start) — and their scratch */
+    const OhTu       *tu_raw;
+    const OhIntra    *intra_raw;
+    const OhIntraCtu *ictu_raw;
+    const uint32_t   *tu_sparse, *tu_cross;   /* per OhTu, may be null */
+    const uint8_t    *is_intra;               /* min-PU map, constrained intra pred only */
+    uint32_t n_ictu, n_sub, n_levels, n_wp, n_sparse, ref_ok;      /* ref_ok: bit i = reference slot i holds a usable picture */
+    uint32_t coeffs_present;
+    uint64_t n_coeff;
+    uint32_t *pu_off;                 /* [2][n_pu + 1]: first luma / chroma block of every PU     */
+    uint8_t  *tu_keep;                /* [n_tu]: luma block whose residual a cross-component block reads */
+    uint32_t *tu_cursor;              /* [0..3] blocks per size, [4..7] scatter cursors, [8] cross-component blocks, [9] their cursor */
+    uint32_t *intra_perm;             /* [n_intra]: position of block i after the <= 8x8-first partition of its sub-level */
+    uint32_t *sub_small_w;            /* = sub_small, writable */
+    uint32_t *ctu_seen;               /* [CTBs]: a CTU may head one schedule entry only */
+    void     *summary;                /* DevSummary + DevLevelStat[n_levels] */
     /* 16x16 CTBs with horizontally subsampled chroma only (else null): the first chroma column of every CTB on the two rows of
      * every horizontal chroma edge as it was BEFORE the horizontal-edge pass — the reference's CTB driver lets the SAO of the
      * left neighbour read exactly that (deblock.hip: oh_sao_stale_*) */

@@ -51,8 +51,12 @@ struct OhDevFrame {
     uint32_t   ref_gen[OH_MAX_REFS];
     uint8_t    ref_half[OH_MAX_REFS];
     uint16_t   ref_used = 0;      /* bit i: some PU predicts from slot i */
-    hipEvent_t ready = nullptr;   /* recorded on the copy stream behind the work list's H2D copy */
+    hipEvent_t ready = nullptr;   /* recorded on the copy stream behind the work list's H2D copy, preparation kernels and summary */
     bool       waited = false;    /* the engine stream already waits for `ready` */
+    void      *sum_host = nullptr;/* pinned: DevSummary + DevLevelStat[n_levels] as the preparation kernels left them */
+    size_t     sum_bytes = 0;
+    bool       sum_pooled = false, summary_read = false;
+    uint32_t   prep_err = 0, n_levels = 0;
     const struct OhEngine *owner = nullptr;   /* picture ids and arenas belong to one engine */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
@@ -88,6 +92,7 @@ struct OhEngine {
     struct Arena { void *p; size_t bytes; hipEvent_t free_ev; };
     std::vector<Arena> arenas;               /* free device arenas */
     std::vector<hipEvent_t> sync_events;     /* pool of timing-disabled events (ready / free_ev) */
+    std::vector<void *> sum_pool;            /* pinned OH_SUMMARY_BLOCK-byte blocks */
     int16_t    *up_tmp = nullptr;        /* intermediate rows of oh_pic_upsample */
     size_t      up_tmp_elems = 0;
     uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
@@ -113,7 +118,7 @@ struct OhEngine {
     } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-enum { OH_MAX_STAGES = 48 };             /* pinned staging buffers per engine before the host is made to wait */
+enum { OH_MAX_STAGES = 48, OH_SUMMARY_BLOCK = 32768 };             /* pinned staging buffers per engine before the host is made to wait */
 
 static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_ext)
 {
@@ -192,6 +197,10 @@ static void free_dev_frame(OhEngine *e, OhDevFrame *df, bool in_flight = false)
         return;
     if (e && df->ready)
         sync_event_put(e, df->ready);
+    if (df->sum_host) {
+        if (e && df->sum_pooled && e->sum_pool.size() < 4096) e->sum_pool.push_back(df->sum_host);
+        else (void)hipHostFree(df->sum_host);
+    }
     if (df->arena) {
         if (e && e->arenas.size() < 256) {
             hipEvent_t fe = nullptr;
@@ -243,6 +252,7 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &c : e->stages) { (void)hipEventDestroy(c.done); (void)hipHostFree(c.p); }
     for (auto &a : e->arenas) { if (a.free_ev) (void)hipEventDestroy(a.free_ev); (void)hipFree(a.p); }
     for (auto &ev : e->sync_events) (void)hipEventDestroy(ev);
+    for (void *b : e->sum_pool) (void)hipHostFree(b);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->up_tmp)
         (void)hipFree(e->up_tmp);
@@ -571,179 +581,63 @@ static bool same_geometry(const OhPicParams &a, const OhPicParams &b)
     return a.width == b.width && a.height == b.height && a.bit_depth == b.bit_depth && a.chroma_format_idc == b.chroma_format_idc;
 }
 
-/* every index a kernel will follow is checked here: a malformed work list must fail on the host,
- * never fault on the GPU */
-/* cut one plane's rectangle of a PU into the <=8x8 blocks the MC kernel works on */
-static void add_mc_jobs(std::vector<DevMcJob> &jobs, const OhPu &pu, int c, int hs, int vs)
-{
-    DevMcJob j;
-    const int first = pu.ref[0] != OH_NO_REF ? 0 : 1;
-    j.ref[0] = pu.ref[first];
-    j.ref[1] = first == 0 ? pu.ref[1] : (uint8_t)OH_NO_REF;
-    for (int k = 0; k < 2; k++) {
-        j.mv[0][k] = pu.mv[first][k];
-        j.mv[1][k] = pu.mv[1][k];
-    }
-    j.wp = pu.wp;
-    j.c_idx = (uint8_t)c;
-    j.flags = first ? OH_MCF_FROM_L1 : 0;
-    const int x0 = pu.x >> hs, y0 = pu.y >> vs, w = pu.w >> hs, h = pu.h >> vs;
-    for (int oy = 0; oy < h; oy += 8)
-        for (int ox = 0; ox < w; ox += 8) {
-            j.x = (uint16_t)(x0 + ox); j.y = (uint16_t)(y0 + oy);
-            j.w = (uint8_t)(w - ox < 8 ? w - ox : 8);
-            j.h = (uint8_t)(h - oy < 8 ? h - oy : 8);
-            jobs.push_back(j);
-        }
-}
-
-/* a wave runs the second list when any of its four blocks has one: keep bi-predicted blocks together
- * (stable inside groups of 64 so that neighbours in the picture stay neighbours in the list) */
-static void group_by_lists(std::vector<DevMcJob> &jobs)
-{
-    for (size_t i = 0; i < jobs.size(); i += 64) {
-        size_t n = jobs.size() - i < 64 ? jobs.size() - i : 64;
-        std::stable_partition(jobs.begin() + i, jobs.begin() + i + n, [](const DevMcJob &j) { return j.ref[1] != OH_NO_REF; });
-    }
-}
-
-static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<DevMcJob> &mc_luma, std::vector<DevMcJob> &mc_chroma, uint16_t *ref_used)
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Hand-over of a work list.  The host copies the RAW lists (include/ohevc_frame.h, exactly as recorded) into one pinned
+ * buffer, counts what sizes the device arena — blocks per PU, transform blocks per size: two light loops — and enqueues on the
+ * copy stream:   H2D copy  ->  preparation kernels (prep.hip: validation of every index a pass kernel will follow, the
+ * <= 8x8 MC block lists, the transform-size buckets, the intra block descriptors, the per-level launch statistics)  ->
+ * boundary strengths from the motion field when the list carries bs_in (bs.hip)  ->  the summary back to pinned memory  ->
+ * `ready`.  Nothing of it touches samples, so it overlaps the passes of the pictures before.  A malformed list is
+ * reported by the first oh_frame(s)_execute that includes it (OH_E_ARG, before any of its passes is launched).
+ * ------------------------------------------------------------------------------------------------------------------- */
+static int check_host_side(OhEngine *e, const OhFrame *f, const Pic *cur, OhPrepCounts *cnt, uint32_t tu_cnt[4], uint32_t *n_cross,
+                           bool *any_dense, uint16_t *ref_used, uint32_t *ref_ok)
 {
     const OhPicParams &p = f->p;
-    const int nplanes = p.chroma_format_idc ? 3 : 1;
-    bool ref_ok[OH_MAX_REFS];
+    *ref_ok = 0; *ref_used = 0; *n_cross = 0; *any_dense = false;
     for (int i = 0; i < OH_MAX_REFS; i++) {
         Pic *r = get_pic(e, f->ref_pics[i]);
-        ref_ok[i] = r && same_geometry(r->p, p) && r != cur;
+        if (r && same_geometry(r->p, p) && r != cur)
+            *ref_ok |= 1u << i;
     }
-    *ref_used = 0;
-    if (f->n_pu && !f->pu)
-        FAIL(e, OH_E_ARG, "n_pu without pu[]");
-    if ((f->n_wp && !f->wp) || (f->n_tu && !f->tu) || (f->n_intra && !f->intra))
-        FAIL(e, OH_E_ARG, "a non-zero item count comes with a NULL array (wp / tu / intra)");
+    if ((f->n_pu && !f->pu) || (f->n_wp && !f->wp) || (f->n_tu && !f->tu) || (f->n_intra && !f->intra))
+        FAIL(e, OH_E_ARG, "a non-zero item count comes with a NULL array (pu / wp / tu / intra)");
+    /* blocks per PU: sizes the MC block lists (prep_pu_scan repeats the sums on the GPU and validates every PU) */
+    uint64_t nl = 0, nc = 0;
+    const int hs = oh_hshift(&p, 1), vs = oh_vshift(&p, 1), two = p.chroma_format_idc ? 2 : 0;
     for (uint32_t i = 0; i < f->n_pu; i++) {
         const OhPu &pu = f->pu[i];
-        if (pu.w < 4 || pu.h < 4 || pu.w > 64 || pu.h > 64 || (pu.w & 3) || (pu.h & 3) || pu.x + pu.w > p.width || pu.y + pu.h > p.height ||
-            (pu.x & 3) || (pu.y & 3))
-            FAIL(e, OH_E_ARG, "PU %u: bad rectangle", i);
-        if (pu.ref[0] == OH_NO_REF && pu.ref[1] == OH_NO_REF)
-            FAIL(e, OH_E_ARG, "PU %u: no reference list", i);
+        nl += (uint64_t)(((pu.w + 7) >> 3) * ((pu.h + 7) >> 3));
+        nc += (uint64_t)(two * ((((pu.w >> hs) + 7) >> 3) * (((pu.h >> vs) + 7) >> 3)));
         for (int l = 0; l < 2; l++)
-            if (pu.ref[l] != OH_NO_REF) {
-                if (pu.ref[l] >= OH_MAX_REFS || !ref_ok[pu.ref[l]])
-                    FAIL(e, OH_E_ARG, "PU %u: reference slot %d is not a usable picture", i, pu.ref[l]);
-                *ref_used |= (uint16_t)(1u << pu.ref[l]);
-            }
-        if (pu.wp != OH_NO_WP && pu.wp >= f->n_wp)
-            FAIL(e, OH_E_ARG, "PU %u: weight index out of range", i);
-        add_mc_jobs(mc_luma, pu, 0, 0, 0);
-        for (int c = 1; c < nplanes; c++)
-            add_mc_jobs(mc_chroma, pu, c, oh_hshift(&p, c), oh_vshift(&p, c));
+            if (pu.ref[l] < OH_MAX_REFS) *ref_used |= (uint16_t)(1u << pu.ref[l]);
     }
-    group_by_lists(mc_luma);
-    group_by_lists(mc_chroma);
+    if (nl >= (1ull << 31) || nc >= (1ull << 31))
+        FAIL(e, OH_E_ARG, "PU list implies %llu + %llu prediction blocks", (unsigned long long)nl, (unsigned long long)nc);
     for (uint32_t i = 0; i < f->n_wp; i++)
         if (f->wp[i].log2_denom[0] > 7 || f->wp[i].log2_denom[1] > 7)
             FAIL(e, OH_E_ARG, "weights %u: log2 denominator out of range", i);
-    for (uint32_t i = 0; i < f->n_tu; i++) {
+    tu_cnt[0] = tu_cnt[1] = tu_cnt[2] = tu_cnt[3] = 0;
+    for (uint32_t i = 0; i < f->n_tu; i++) {                  /* launch sizes of the residual pass; is any block dense? */
         const OhTu &t = f->tu[i];
-        if (t.c_idx >= nplanes || t.log2_size < 2 || t.log2_size > 5 || t.kind > OH_TU_PCM)
-            FAIL(e, OH_E_ARG, "TU %u: bad plane / size / kind", i);
-        int n = 1 << t.log2_size;
-        if (t.x + n > cur->w[t.c_idx] || t.y + n > cur->h[t.c_idx])
-            FAIL(e, OH_E_ARG, "TU %u: outside the plane", i);
-        if ((uint64_t)t.coeff_off + (uint64_t)n * n > f->n_coeff)
-            FAIL(e, OH_E_ARG, "TU %u: coefficients outside the pool", i);
-        if (!(t.flags & OH_TUF_SPARSE) && !f->coeffs)
-            FAIL(e, OH_E_ARG, "TU %u: dense block but coeffs[] is NULL", i);
-        if ((t.coeff_off & 3) || (t.x & 3) || (t.y & 3))        /* the kernels move 4 elements per access */
-            FAIL(e, OH_E_ARG, "TU %u: position / coefficient offset not a multiple of 4", i);
-        if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
-            FAIL(e, OH_E_ARG, "TU %u: rotation is 4x4 only", i);
-        if (t.flags & OH_TUF_CROSS) {
-            const uint32_t cw = f->tu_cross ? f->tu_cross[i] : OH_NO_COEFF, ty = cw & 0xffffff;
-            if (cw == OH_NO_COEFF || p.chroma_format_idc != 3 || t.c_idx == 0 || ty >= f->n_tu || f->tu[ty].c_idx != 0 ||
-                f->tu[ty].log2_size != t.log2_size || t.kind == OH_TU_PCM)
-                FAIL(e, OH_E_ARG, "TU %u: bad cross-component prediction link", i);
-        }
-        if (t.flags & OH_TUF_SPARSE) {
-            if (!f->sparse || !f->tu_sparse || t.kind == OH_TU_BYPASS || t.kind == OH_TU_PCM)
-                FAIL(e, OH_E_ARG, "TU %u: sparse block without records / of a kind that carries no levels", i);
-            const uint64_t so = f->tu_sparse[i];
-            if (so >= f->n_sparse)
-                FAIL(e, OH_E_ARG, "TU %u: sparse record outside the pool", i);
-            const uint32_t w0 = f->sparse[so], cnt = w0 & 0xffff, qp = (w0 >> 16) & 0xff, mid = w0 >> 24;
-            if (cnt > (uint32_t)(n * n) || so + 1 + cnt > f->n_sparse || qp > 75 || (mid != OH_FLAT_MATRIX && (mid > 5 || !f->scaling)))
-                FAIL(e, OH_E_ARG, "TU %u: bad sparse record (count / QP / matrix)", i);
-            for (uint32_t k = 0; k < cnt; k++)
-                if ((f->sparse[so + 1 + k] & 0xffff) >= (uint32_t)(n * n))
-                    FAIL(e, OH_E_ARG, "TU %u: sparse coefficient outside the block", i);
-        }
+        tu_cnt[(t.log2_size - 2) & 3]++;
+        *n_cross += (t.flags & OH_TUF_CROSS) != 0;
+        *any_dense = *any_dense || !(t.flags & OH_TUF_SPARSE);
     }
+    if (*any_dense && f->n_coeff && !f->coeffs)
+        FAIL(e, OH_E_ARG, "dense transform blocks but coeffs[] is NULL");
+    if (*n_cross && !f->tu_cross)
+        FAIL(e, OH_E_ARG, "cross-component blocks without tu_cross[]");
     if (f->n_intra && p.constrained_intra_pred && !f->is_intra)
         FAIL(e, OH_E_ARG, "constrained_intra_pred without the is_intra map");
     if (f->n_intra) {
-        /* CTU wavefront tables: levels -> ictu[] -> sub_start[] -> intra[] must nest exactly */
+        /* the level table sizes the launches (grid = CTUs of the level): checked here; everything below it on the GPU */
         if (!f->level_start || !f->n_levels || !f->ictu || !f->n_ictu || !f->sub_start || !f->n_sub ||
-            f->level_start[0] != 0 || f->level_start[f->n_levels] != f->n_ictu ||
-            f->sub_start[0] != 0 || f->sub_start[f->n_sub] != f->n_intra)
+            f->level_start[0] != 0 || f->level_start[f->n_levels] != f->n_ictu)
             FAIL(e, OH_E_ARG, "intra wavefront tables inconsistent");
         for (uint32_t l = 0; l < f->n_levels; l++)
             if (f->level_start[l] > f->level_start[l + 1])
                 FAIL(e, OH_E_ARG, "intra level table not monotonic");
-        for (uint32_t s = 0; s < f->n_sub; s++)
-            if (f->sub_start[s] > f->sub_start[s + 1])
-                FAIL(e, OH_E_ARG, "intra sub-level table not monotonic");
-        uint32_t expect = 0;
-        const uint32_t n_ctb = (uint32_t)oh_ctb_width(&p) * (uint32_t)oh_ctb_height(&p);
-        const int lc = p.log2_ctb_size, ctbw = oh_ctb_width(&p);
-        std::vector<uint8_t> seen(n_ctb, 0);                  /* a CTU's intra blocks form ONE entry: its level is one number */
-        for (uint32_t k = 0; k < f->n_ictu; k++) {
-            const OhIntraCtu &ic = f->ictu[k];
-            if (ic.sub_first != expect || !ic.n_sub)
-                FAIL(e, OH_E_ARG, "intra CTU %u: sub-level range not contiguous", k);
-            expect += ic.n_sub;
-            if (expect > f->n_sub)
-                FAIL(e, OH_E_ARG, "intra CTU %u: sub-level range runs past the table", k);
-            if (ic.ctu >= n_ctb || seen[ic.ctu])
-                FAIL(e, OH_E_ARG, "intra CTU %u: CTB address %u out of range or listed twice", k, ic.ctu);
-            seen[ic.ctu] = 1;
-            /* the kernel stages at most OH_MAX_CTU_BLOCKS descriptors / sub-levels of a CTU in LDS and writes the CTU back from
-             * the origin of ic.ctu: more items, or items of another CTB, must not reach it */
-            const uint32_t b0 = f->sub_start[ic.sub_first], b1 = f->sub_start[ic.sub_first + ic.n_sub];
-            if (ic.n_sub > OH_MAX_CTU_BLOCKS || b1 - b0 > OH_MAX_CTU_BLOCKS)
-                FAIL(e, OH_E_ARG, "intra CTU %u: %u blocks in %u sub-levels exceed the per-CTU limit %d", k, b1 - b0, ic.n_sub, OH_MAX_CTU_BLOCKS);
-            for (uint32_t b = b0; b < b1; b++) {
-                const OhIntra &it = f->intra[b];
-                if (it.c_idx >= nplanes)
-                    FAIL(e, OH_E_ARG, "intra %u: bad plane", b);
-                const int X = it.x << oh_hshift(&p, it.c_idx), Y = it.y << oh_vshift(&p, it.c_idx);
-                if ((uint32_t)((Y >> lc) * ctbw + (X >> lc)) != ic.ctu)
-                    FAIL(e, OH_E_ARG, "intra %u: block lies outside CTB %u it is listed under", b, ic.ctu);
-            }
-        }
-        if (expect != f->n_sub)
-            FAIL(e, OH_E_ARG, "intra CTU table does not cover the sub-level table");
-    }
-    for (uint32_t i = 0; i < f->n_intra; i++) {
-        const OhIntra &it = f->intra[i];
-        if (it.c_idx >= nplanes || it.log2_size < 2 || it.log2_size > 5 || it.mode > 34)
-            FAIL(e, OH_E_ARG, "intra %u: bad plane / size / mode", i);
-        int n = 1 << it.log2_size;
-        if (it.x + n > cur->w[it.c_idx] || it.y + n > cur->h[it.c_idx])
-            FAIL(e, OH_E_ARG, "intra %u: outside the plane", i);
-        if (((it.avail & (OH_AV_LEFT | OH_AV_BOTTOM_LEFT | OH_AV_UP_LEFT)) && it.x == 0) ||
-            ((it.avail & (OH_AV_UP | OH_AV_UP_RIGHT | OH_AV_UP_LEFT)) && it.y == 0) ||
-            ((it.avail & OH_AV_UP_RIGHT) && it.x + n >= cur->w[it.c_idx]) ||
-            ((it.avail & OH_AV_BOTTOM_LEFT) && it.y + n >= cur->h[it.c_idx]))
-            FAIL(e, OH_E_ARG, "intra %u: candidate flags point outside the picture", i);
-        if (it.tu != OH_NO_COEFF) {
-            if (it.tu >= f->n_tu)
-                FAIL(e, OH_E_ARG, "intra %u: TU index out of range", i);
-            const OhTu &t = f->tu[it.tu];
-            if (t.c_idx != it.c_idx || t.x != it.x || t.y != it.y || t.log2_size != it.log2_size || (t.flags & OH_TUF_ADD_NOW))
-                FAIL(e, OH_E_ARG, "intra %u: TU does not match the block", i);
-        }
     }
     if (p.deblock_enabled) {
         const OhBsInputs *bi = f->bs_in;                      /* boundary strengths derived on the GPU instead of handed over */
@@ -762,7 +656,19 @@ static int validate(OhEngine *e, const OhFrame *f, const Pic *cur, std::vector<D
     }
     if ((p.pcm_loop_filter_disable || p.transquant_bypass_enable) && !f->is_pcm)
         FAIL(e, OH_E_ARG, "is_pcm map required when pcm loop-filter disable / transquant bypass is on");
+    cnt->n_pu = f->n_pu; cnt->n_mc_luma = (uint32_t)nl; cnt->n_mc_chroma = (uint32_t)nc; cnt->n_tu = f->n_tu;
+    cnt->n_intra = f->n_intra; cnt->n_sub = f->n_intra ? f->n_sub : 0; cnt->n_ictu = f->n_intra ? f->n_ictu : 0;
+    cnt->n_levels = f->n_intra ? f->n_levels : 0;
     return OH_OK;
+}
+
+/* pinned block the summary of one work list lands in */
+static void *summary_block_get(OhEngine *e, size_t bytes, bool *pooled)
+{
+    void *p = nullptr;
+    *pooled = bytes <= OH_SUMMARY_BLOCK;
+    if (*pooled && !e->sum_pool.empty()) { p = e->sum_pool.back(); e->sum_pool.pop_back(); return p; }
+    return hipHostMalloc(&p, *pooled ? (size_t)OH_SUMMARY_BLOCK : bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
 }
 
 extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
@@ -779,11 +685,11 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     static const bool timing = getenv("OHEVC_UPLOAD_TIMING") != nullptr;      /* diagnostic: where the host time of an upload goes */
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto t_begin = tnow();
-    std::vector<DevMcJob> mc_luma, mc_chroma;
-    mc_luma.reserve((size_t)f->n_pu * 4);
-    mc_chroma.reserve((size_t)f->n_pu * 4);
+    OhPrepCounts cnt;
+    uint32_t tu_cnt[4], n_cross = 0, ref_ok = 0;
     uint16_t ref_used = 0;
-    rc = validate(e, f, cur, mc_luma, mc_chroma, &ref_used);
+    bool any_dense = false;
+    rc = check_host_side(e, f, cur, &cnt, tu_cnt, &n_cross, &any_dense, &ref_used, &ref_ok);
     if (rc)
         return rc;
     auto t_valid = tnow();
@@ -795,9 +701,9 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     const bool has_sao = p.sao_enabled && f->sao;
     const bool has_db = p.deblock_enabled != 0;
 
-    /* arena layout: [DevFrame][pu][mc jobs][wp][tu][intra][vbs][hbs][qp][is_pcm][db][sao][coeffs] | [res] */
+    /* arena: [copied: header, raw lists, side arrays, coefficient pool] [device only: prepared lists, scratch, residual pool] */
     struct Seg { const void *src; size_t bytes, off; };
-    Seg seg[32];
+    Seg seg[40];
     int ns = 0;
     size_t total = 0;
     auto add = [&](const void *src, size_t bytes) {
@@ -809,203 +715,18 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     memset(&hd, 0, sizeof(hd));
     int s_hdr = add(&hd, sizeof(DevFrame));
     int s_pu = add(f->pu, (size_t)f->n_pu * sizeof(OhPu));
-    int s_mcl = add(mc_luma.data(), mc_luma.size() * sizeof(DevMcJob));
-    int s_mcc = add(mc_chroma.data(), mc_chroma.size() * sizeof(DevMcJob));
     int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
-    /* transform blocks sorted by size (stable): the residual pass runs one launch per size */
-    std::vector<DevTu> tu_sorted(f->n_tu);
-    bool any_dense = false;
-    std::vector<uint8_t> keep_res(f->tu_cross ? f->n_tu : 0, 0);      /* luma blocks a cross-component block reads */
-    for (uint32_t i = 0; i < f->n_tu && f->tu_cross; i++)
-        if (f->tu[i].flags & OH_TUF_CROSS)
-            keep_res[f->tu_cross[i] & 0xffffff] = 1;
-    uint32_t tu_first[4] = { 0, 0, 0, 0 }, tu_cnt[4] = { 0, 0, 0, 0 };
-    for (uint32_t i = 0; i < f->n_tu; i++) tu_cnt[f->tu[i].log2_size - 2]++;
-    for (int k = 1; k < 4; k++) tu_first[k] = tu_first[k - 1] + tu_cnt[k - 1];
-    {
-        uint32_t cur_[4] = { tu_first[0], tu_first[1], tu_first[2], tu_first[3] };
-        for (uint32_t i = 0; i < f->n_tu; i++) {
-            DevTu &d = tu_sorted[cur_[f->tu[i].log2_size - 2]++];
-            d.t = f->tu[i];
-            if (!keep_res.empty() && keep_res[i]) d.t.flags |= OH_TUF_KEEP_RES;
-            d.sparse_off = (f->tu[i].flags & OH_TUF_SPARSE) ? f->tu_sparse[i] : OH_NO_COEFF;
-            any_dense = any_dense || !(f->tu[i].flags & OH_TUF_SPARSE);
-        }
-    }
-    /* cross-component prediction: the luma blocks it reads keep their residual, the chroma blocks are finished by a
-     * second launch (ohk_cross) once every inverse transform of the picture is done */
-    std::vector<DevCross> cross;
-    if (f->tu_cross)
-        for (uint32_t i = 0; i < f->n_tu; i++)
-            if (f->tu[i].flags & OH_TUF_CROSS) {
-                const OhTu &t = f->tu[i], &ty = f->tu[f->tu_cross[i] & 0xffffff];
-                DevCross d;
-                d.x = t.x; d.y = t.y; d.c_idx = t.c_idx; d.log2_size = t.log2_size; d.flags = t.flags;
-                d.scale = (int8_t)(f->tu_cross[i] >> 24); d.res_c = t.coeff_off; d.res_y = ty.coeff_off;
-                cross.push_back(d);
-            }
-    int s_tu = add(tu_sorted.data(), tu_sorted.size() * sizeof(DevTu));
-    int s_cross = add(cross.data(), cross.size() * sizeof(DevCross));
+    int s_tur = add(f->tu, (size_t)f->n_tu * sizeof(OhTu));
+    int s_tusp = add(f->tu_sparse, f->tu_sparse ? (size_t)f->n_tu * sizeof(uint32_t) : 0);
+    int s_tucr = add(f->tu_cross, f->tu_cross ? (size_t)f->n_tu * sizeof(uint32_t) : 0);
     int s_sparse = add(f->sparse, (size_t)(f->sparse ? f->n_sparse : 0) * sizeof(uint32_t));
     int s_scaling = add(f->scaling, f->scaling ? sizeof(OhScalingList) : 0);
-    /* intra block descriptors: everything that depends only on geometry and mode is resolved here */
-    static const int8_t k_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
-                                        -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };      /* hevcpred_template.c:430-433 */
-    static const int16_t k_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
-    const OhCtuAreas areas = oh_ctu_areas(p.log2_ctb_size, p.chroma_format_idc);
-    std::vector<DevIntra> dintra(f->n_intra);
-    for (uint32_t i = 0; i < f->n_intra; i++) {
-        const OhIntra &it = f->intra[i];
-        DevIntra &d = dintra[i];
-        memset(&d, 0, sizeof(d));
-        const int c = it.c_idx, hs = oh_hshift(&p, c), vs = oh_vshift(&p, c), log2 = it.log2_size, n = 1 << log2, mode = it.mode;
-        const int lc = p.log2_ctb_size, rs = ((1 << lc) >> hs) + 4;
-        const int lx = it.x - ((((it.x << hs) >> lc) << lc) >> hs), ly = it.y - ((((it.y << vs) >> lc) << lc) >> vs);
-        d.x = it.x; d.y = it.y; d.c_idx = it.c_idx; d.log2_size = it.log2_size; d.mode = it.mode; d.avail = it.avail;
-        d.res_off = it.tu == OH_NO_COEFF ? OH_NO_COEFF : f->tu[it.tu].coeff_off;
-        d.rs = (uint16_t)rs;
-        d.cm_off = (uint16_t)(areas.main[c] + ly * rs + lx + 4);
-        d.top_off = (uint16_t)(ly == 0 ? areas.top[c] + lx + 4 : d.cm_off - rs);
-        int tr = (it.x + 2 * n < cur->w[c] ? it.x + 2 * n : cur->w[c]) - (it.x + n);
-        int bl = (it.y + 2 * n < cur->h[c] ? it.y + 2 * n : cur->h[c]) - (it.y + n);
-        d.tr_size = (uint8_t)(tr < 0 ? 0 : tr); d.bl_size = (uint8_t)(bl < 0 ? 0 : bl);
-        int flags = 0, cls;
-        if (!p.intra_smoothing_disabled && (c == 0 || p.chroma_format_idc == 3) && mode != 1 && n != 4) {   /* :288-294 */
-            static const int thresh[3] = { 7, 1, 0 };
-            int d26 = mode > 26 ? mode - 26 : 26 - mode, d10 = mode > 10 ? mode - 10 : 10 - mode;
-            if ((d26 < d10 ? d26 : d10) > thresh[log2 - 3]) {
-                flags |= OH_IF_FILTER;
-                if (p.strong_intra_smoothing && c == 0 && log2 == 5) flags |= OH_IF_STRONG_CAND;
-            }
-        }
-        if (c == 0 && n < 32 && (mode == 1 || mode == 10 || mode == 26)) flags |= OH_IF_EDGE;     /* :410-416, :474-477, :501-508 */
-        if (mode == 0) cls = OH_IC_PLANAR;
-        else if (mode == 1) cls = OH_IC_DC;
-        else if (mode == 26) cls = OH_IC_PURE_V;
-        else if (mode == 10) cls = OH_IC_PURE_H;
-        else cls = mode >= 18 ? OH_IC_ANG_V : OH_IC_ANG_H;
-        if (mode >= 2) {
-            d.angle = k_angle[mode - 2];
-            if (d.angle < 0 && ((n * d.angle) >> 5) < -1) d.inv_angle = k_inv_angle[mode - 11];
-        }
-        if (p.constrained_intra_pred) {
-            /* hevcpred_template.c:116-163: candidates that lie in inter CUs do not count; the kernel's slow path then
-             * patches the gathered edges from the per-group intra masks (:185-249) */
-            const uint8_t *map = f->is_intra;
-            const int lpu = p.log2_min_pu_size, mpw = p.width >> lpu, mph = p.height >> lpu;
-            const int X0 = it.x << hs, Y0 = it.y << vs, sl_h = n << hs, sl_v = n << vs;
-            auto cell = [&](int px, int py) { return px >= 0 && py >= 0 && px < mpw && py < mph && map[px + py * mpw] != 0; };
-            auto isi = [&](int dx, int dy) { return cell((X0 + dx * (1 << hs)) >> lpu, (Y0 + dy * (1 << vs)) >> lpu); };
-            int pu_v = sl_v >> lpu, pu_h = sl_h >> lpu, av = it.avail;
-            const bool on_x = !(X0 & ((1 << lpu) - 1)), on_y = !(Y0 & ((1 << lpu) - 1));
-            if (!pu_h) pu_h++;
-            auto any2 = [&](int px, int py, int dx, int dy, int cnt) { bool r = false; for (int i = 0; i < cnt; i += 2) r |= cell(px + i * dx, py + i * dy); return r; };
-            if ((av & OH_AV_BOTTOM_LEFT) && on_x) {
-                int yb = (Y0 + sl_v) >> lpu;
-                if (!any2((X0 - 1) >> lpu, yb, 0, 1, std::min(pu_v, mph - yb))) av &= ~OH_AV_BOTTOM_LEFT;
-            }
-            if ((av & OH_AV_LEFT) && on_x) {
-                int yl = Y0 >> lpu;
-                if (!any2((X0 - 1) >> lpu, yl, 0, 1, std::min(pu_v, mph - yl))) av &= ~OH_AV_LEFT;
-            }
-            if ((av & OH_AV_UP_LEFT) && !cell((X0 - 1) >> lpu, (Y0 - 1) >> lpu)) av &= ~OH_AV_UP_LEFT;
-            if ((av & OH_AV_UP) && on_y) {
-                int xt = X0 >> lpu;
-                if (!any2(xt, (Y0 - 1) >> lpu, 1, 0, std::min(pu_h, mpw - xt))) av &= ~OH_AV_UP;
-            }
-            if ((av & OH_AV_UP_RIGHT) && on_y) {
-                int xr = (X0 + sl_h) >> lpu;
-                if (!any2(xr, (Y0 - 1) >> lpu, 1, 0, std::min(pu_h, mpw - xr))) av &= ~OH_AV_UP_RIGHT;
-            }
-            d.avail = (uint8_t)av;
-            unsigned lm = 0, tm = 0;
-            for (int k = 0; 4 * k < 2 * n; k++) {
-                if (it.x > 0 && isi(-1, 4 * k)) lm |= 1u << k;
-                if (it.y > 0 && isi(4 * k, -1)) tm |= 1u << k;
-            }
-            d.cip_left = (uint16_t)lm; d.cip_top = (uint16_t)tm;
-            flags |= OH_IF_CIP;
-            if (it.x > 0 && it.y > 0 && isi(-1, -1)) flags |= OH_IF_CIP_CORNER;
-        }
-        d.flags = (uint8_t)(flags | (cls << 4));
-    }
-    int s_intra = add(dintra.data(), dintra.size() * sizeof(DevIntra));
-    /* per CTU: span of the residual pool used by its intra blocks (the recorder appends TUs CTU by
-     * CTU, so the span is at most the CTU's sample count and fits the kernel's LDS buffer) */
-    std::vector<DevIntraCtu> dictu(f->n_intra ? f->n_ictu : 0);
-    for (size_t k = 0; k < dictu.size(); k++) {
-        const OhIntraCtu &c = f->ictu[k];
-        DevIntraCtu &d = dictu[k];
-        d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu;
-        d.item0 = f->sub_start[c.sub_first]; d.n_items = f->sub_start[c.sub_first + c.n_sub] - d.item0;
-        uint64_t lo = UINT64_MAX, hi = 0;
-        int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
-        for (uint32_t b = f->sub_start[c.sub_first]; b < f->sub_start[c.sub_first + c.n_sub]; b++) {
-            const DevIntra &it = dintra[b];
-            {
-                const int hs = oh_hshift(&p, it.c_idx), vs = oh_vshift(&p, it.c_idx), lc = p.log2_ctb_size, n = 1 << it.log2_size;
-                const int lx = it.x - ((((it.x << hs) >> lc) << lc) >> hs), ly = it.y - ((((it.y << vs) >> lc) << lc) >> vs);
-                bx0 = std::min(bx0, (lx - 1) * (1 << hs)); bx1 = std::max(bx1, (lx + 2 * n) << hs);
-                by0 = std::min(by0, (ly - 1) * (1 << vs)); by1 = std::max(by1, (ly + 2 * n) << vs);
-            }
-            if (it.res_off == OH_NO_COEFF)
-                continue;
-            uint64_t e = (uint64_t)it.res_off + (1u << (2 * it.log2_size));
-            if (it.res_off < lo) lo = it.res_off;
-            if (e > hi) hi = e;
-        }
-        d.res_lo = 0; d.res_cnt = 0;
-        d.bx0 = (int16_t)bx0; d.bx1 = (int16_t)bx1; d.by0 = (int16_t)by0; d.by1 = (int16_t)by1;
-        if (hi > lo && (lo & 3) == 0 && hi - lo <= 3u * 64 * 64) {
-            d.res_lo = (uint32_t)lo;
-            d.res_cnt = (uint32_t)((hi - lo + 3) & ~3ull);
-            if ((uint64_t)d.res_lo + d.res_cnt > f->n_coeff) d.res_cnt = (uint32_t)(hi - lo) & ~3u;
-        }
-    }
-    for (size_t k = 0; k < dictu.size(); k++)
-        for (uint32_t b = f->sub_start[dictu[k].sub_first]; b < f->sub_start[dictu[k].sub_first + dictu[k].n_sub]; b++)
-            if (dintra[b].res_off != OH_NO_COEFF && dictu[k].res_cnt)
-                dintra[b].res_lds = dintra[b].res_off - dictu[k].res_lo;
-    /* inside a sub-level the blocks are independent: put the <=8x8 ones first — the kernel runs four of them per wave
-     * (16-lane slots) — and note how many there are (none for constrained intra pred, which needs the one-block path) */
-    std::vector<uint32_t> sub_small(f->n_intra ? f->n_sub : 0, 0);
-    std::vector<DevIntra> big;                              /* scratch of the stable partition (ranges are a handful of blocks) */
-    for (size_t j = 0; j < sub_small.size(); j++) {
-        const uint32_t b0 = f->sub_start[j], b1 = f->sub_start[j + 1];
-        uint32_t w = b0;
-        big.clear();
-        for (uint32_t b = b0; b < b1; b++) {
-            if (dintra[b].log2_size <= 3) { if (w != b) dintra[w] = dintra[b]; w++; }
-            else big.push_back(dintra[b]);
-        }
-        for (size_t k = 0; k < big.size(); k++) dintra[w + k] = big[k];
-        static const char *smin = getenv("OHEVC_INTRA_SLOT_MIN");      /* experiments: sub-levels of up to this many blocks go one block per wave */
-        sub_small[j] = p.constrained_intra_pred || (smin && b1 - b0 <= (uint32_t)atoi(smin)) ? 0u : w - b0;
-    }
-    std::vector<OhDevFrame::Level> levels(f->n_intra ? f->n_levels : 0);
-    for (size_t l = 0; l < levels.size(); l++) {
-        OhDevFrame::Level &L = levels[l];
-        L.n_ctu = f->level_start[l + 1] - f->level_start[l];
-        L.max_items = 1; L.max_sub = 1; L.max_res = 0; L.sum_items = 0; L.sum_sub = 0; L.staged = true;
-        for (uint32_t k = f->level_start[l]; k < f->level_start[l + 1]; k++) {
-            const uint32_t b0 = f->sub_start[dictu[k].sub_first], b1 = f->sub_start[dictu[k].sub_first + dictu[k].n_sub];
-            bool any_res = false;
-            for (uint32_t b = b0; b < b1 && !any_res; b++)
-                any_res = dintra[b].res_off != OH_NO_COEFF;
-            if (any_res && !dictu[k].res_cnt)
-                L.staged = false;
-            L.max_items = std::max(L.max_items, std::min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
-            L.max_sub = std::max(L.max_sub, std::min((uint32_t)dictu[k].n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
-            L.max_res = std::max(L.max_res, dictu[k].res_cnt);
-            for (uint32_t j = dictu[k].sub_first; j < dictu[k].sub_first + dictu[k].n_sub; j++)      /* wave passes: slot groups + big blocks */
-                L.sum_items += (sub_small[j] + 3) / 4 + (f->sub_start[j + 1] - f->sub_start[j] - sub_small[j]);
-            L.sum_sub += dictu[k].n_sub;
-        }
-    }
-    int s_ictu = add(dictu.data(), dictu.size() * sizeof(DevIntraCtu));
-    int s_lvl = add(levels.empty() ? nullptr : f->level_start, levels.empty() ? 0 : (levels.size() + 1) * sizeof(uint32_t));
-    int s_sub = add(f->n_intra ? f->sub_start : nullptr, f->n_intra ? ((size_t)f->n_sub + 1) * sizeof(uint32_t) : 0);
-    int s_small = add(sub_small.data(), sub_small.size() * sizeof(uint32_t));
+    int s_inr = add(f->intra, (size_t)f->n_intra * sizeof(OhIntra));
+    int s_ictur = add(cnt.n_ictu ? f->ictu : nullptr, (size_t)cnt.n_ictu * sizeof(OhIntraCtu));
+    int s_lvl = add(cnt.n_levels ? f->level_start : nullptr, cnt.n_levels ? ((size_t)cnt.n_levels + 1) * sizeof(uint32_t) : 0);
+    int s_sub = add(cnt.n_sub ? f->sub_start : nullptr, cnt.n_sub ? ((size_t)cnt.n_sub + 1) * sizeof(uint32_t) : 0);
+    const bool cip = p.constrained_intra_pred && f->is_intra;
+    int s_isin = add(cip ? f->is_intra : nullptr, cip ? n_pcm : 0);
     const OhBsInputs *bsi = has_db ? f->bs_in : nullptr;
     const size_t bs_bytes = bsi ? oh_bs_size(&p) : f->bs_size;
     int s_vbs = add(has_db && !bsi ? f->vertical_bs : nullptr, has_db ? bs_bytes : 0);     /* with bs_in: written by bs_kernel after the copy */
@@ -1020,8 +741,25 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_db = add(has_db ? f->deblock : nullptr, has_db ? n_ctb * sizeof(OhDeblockCtb) : 0);
     int s_sao = add(has_sao ? f->sao : nullptr, has_sao ? n_ctb * sizeof(OhSaoCtb) : 0);
     int s_coef = add(f->coeffs, (size_t)f->n_coeff * sizeof(int16_t));
-    /* the dense pool is the last uploaded segment: when every block came as levels nothing of it crosses PCIe */
+    /* the dense pool is the last copied segment: when every block came as levels nothing of it crosses PCIe */
     const size_t copy_bytes = any_dense || !f->n_tu ? total : seg[s_coef].off;
+    /* device only.  The first four are cleared before the preparation kernels run. */
+    const size_t sum_bytes = sizeof(DevSummary) + (size_t)cnt.n_levels * sizeof(DevLevelStat);
+    const size_t zero_off = total;
+    int s_cursor = add(nullptr, 16 * sizeof(uint32_t));
+    int s_sum = add(nullptr, sum_bytes);
+    int s_seen = add(nullptr, cnt.n_intra ? n_ctb * sizeof(uint32_t) : 0);
+    int s_keep = add(nullptr, f->n_tu);
+    const size_t zero_bytes = total - zero_off;
+    int s_mcl = add(nullptr, (size_t)cnt.n_mc_luma * sizeof(DevMcJob));
+    int s_mcc = add(nullptr, (size_t)cnt.n_mc_chroma * sizeof(DevMcJob));
+    int s_puoff = add(nullptr, 2 * ((size_t)f->n_pu + 1) * sizeof(uint32_t));
+    int s_tu = add(nullptr, (size_t)f->n_tu * sizeof(DevTu));
+    int s_cross = add(nullptr, (size_t)n_cross * sizeof(DevCross));
+    int s_intra = add(nullptr, (size_t)f->n_intra * sizeof(DevIntra));
+    int s_ictu = add(nullptr, (size_t)cnt.n_ictu * sizeof(DevIntraCtu));
+    int s_small = add(nullptr, (size_t)cnt.n_sub * sizeof(uint32_t));
+    int s_perm = add(nullptr, (size_t)f->n_intra * sizeof(uint32_t));
     const size_t res_off = total;
     total += align_up((size_t)(f->n_coeff ? f->n_coeff : 1) * sizeof(int16_t), 256);
     const bool stale_cfg = has_db && has_sao && oh_sao_stale_config(&p);       /* see DevFrame.sao_stale */
@@ -1065,44 +803,53 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     for (int i = 0; i < OH_MAX_REFS; i++) {
         Pic *r = get_pic(e, f->ref_pics[i]);
         df->ref_id[i] = -1; df->ref_gen[i] = 0; df->ref_half[i] = 0;
-        if (r && same_geometry(r->p, p) && r != cur) {
+        if (ref_ok >> i & 1) {
             fill_planes(&hd.refs[i], r, r->final_b);
             df->ref_id[i] = f->ref_pics[i]; df->ref_gen[i] = r->gen; df->ref_half[i] = r->final_b ? 1 : 0;
         }
     }
     df->ref_used = ref_used;
     df->cur_gen = cur->gen;
-    hd.pu = (const OhPu *)(base + seg[s_pu].off);
-    hd.mc_luma = (const DevMcJob *)(base + seg[s_mcl].off);
-    hd.mc_chroma = (const DevMcJob *)(base + seg[s_mcc].off);
-    hd.wp = (const OhWeights *)(base + seg[s_wp].off);
-    hd.tu = (const DevTu *)(base + seg[s_tu].off);
-    hd.sparse = f->sparse ? (const uint32_t *)(base + seg[s_sparse].off) : nullptr;
-    hd.cross = (const DevCross *)(base + seg[s_cross].off); hd.n_cross = (uint32_t)cross.size();
-    hd.scaling = f->scaling ? (const OhScalingList *)(base + seg[s_scaling].off) : nullptr;
-    hd.coeffs = (const int16_t *)(base + seg[s_coef].off);
+#define AT(T, s) ((T)(base + seg[s].off))
+    hd.pu = AT(const OhPu *, s_pu);
+    hd.mc_luma = AT(const DevMcJob *, s_mcl); hd.mc_chroma = AT(const DevMcJob *, s_mcc);
+    hd.wp = AT(const OhWeights *, s_wp);
+    hd.tu = AT(const DevTu *, s_tu); hd.tu_raw = AT(const OhTu *, s_tur);
+    hd.tu_sparse = f->tu_sparse ? AT(const uint32_t *, s_tusp) : nullptr;
+    hd.tu_cross = f->tu_cross ? AT(const uint32_t *, s_tucr) : nullptr;
+    hd.sparse = f->sparse ? AT(const uint32_t *, s_sparse) : nullptr;
+    hd.cross = AT(const DevCross *, s_cross);
+    hd.scaling = f->scaling ? AT(const OhScalingList *, s_scaling) : nullptr;
+    hd.coeffs = AT(const int16_t *, s_coef);
+    hd.coeffs_present = f->coeffs != nullptr;
     hd.res = (int16_t *)(base + res_off);
     hd.sao_stale = stale_cfg ? (uint16_t *)(base + stale_off) : nullptr;
-    hd.intra = (const DevIntra *)(base + seg[s_intra].off);
-    hd.ictu = (const DevIntraCtu *)(base + seg[s_ictu].off);
-    hd.sub_start = (const uint32_t *)(base + seg[s_sub].off);
-    hd.sub_small = (const uint32_t *)(base + seg[s_small].off);
-    hd.lvl_start = (const uint32_t *)(base + seg[s_lvl].off);
-    hd.vbs = (const uint8_t *)(base + seg[s_vbs].off);
-    hd.hbs = (const uint8_t *)(base + seg[s_hbs].off);
-    hd.qp = (const int8_t *)(base + seg[s_qp].off);
-    hd.is_pcm = f->is_pcm ? (const uint8_t *)(base + seg[s_pcm].off) : nullptr;
-    hd.db = (const OhDeblockCtb *)(base + seg[s_db].off);
-    hd.sao = has_sao ? (const OhSaoCtb *)(base + seg[s_sao].off) : nullptr;
-    hd.n_pu = f->n_pu; hd.n_mc_luma = (uint32_t)mc_luma.size(); hd.n_mc_chroma = (uint32_t)mc_chroma.size(); hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
-    for (int k = 0; k < 4; k++) { hd.tu_first[k] = tu_first[k]; hd.tu_cnt[k] = tu_cnt[k]; }
+    hd.intra = AT(const DevIntra *, s_intra); hd.intra_raw = AT(const OhIntra *, s_inr);
+    hd.ictu = AT(const DevIntraCtu *, s_ictu); hd.ictu_raw = AT(const OhIntraCtu *, s_ictur);
+    hd.sub_start = AT(const uint32_t *, s_sub);
+    hd.sub_small = AT(const uint32_t *, s_small); hd.sub_small_w = AT(uint32_t *, s_small);
+    hd.lvl_start = AT(const uint32_t *, s_lvl);
+    hd.is_intra = cip ? AT(const uint8_t *, s_isin) : nullptr;
+    hd.vbs = AT(const uint8_t *, s_vbs); hd.hbs = AT(const uint8_t *, s_hbs);
+    hd.qp = AT(const int8_t *, s_qp);
+    hd.is_pcm = f->is_pcm ? AT(const uint8_t *, s_pcm) : nullptr;
+    hd.db = AT(const OhDeblockCtb *, s_db);
+    hd.sao = has_sao ? AT(const OhSaoCtb *, s_sao) : nullptr;
+    hd.pu_off = AT(uint32_t *, s_puoff); hd.tu_keep = AT(uint8_t *, s_keep); hd.tu_cursor = AT(uint32_t *, s_cursor);
+    hd.intra_perm = AT(uint32_t *, s_perm); hd.ctu_seen = AT(uint32_t *, s_seen); hd.summary = AT(void *, s_sum);
+#undef AT
+    hd.n_pu = f->n_pu; hd.n_mc_luma = cnt.n_mc_luma; hd.n_mc_chroma = cnt.n_mc_chroma; hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
+    hd.n_ictu = cnt.n_ictu; hd.n_sub = cnt.n_sub; hd.n_levels = cnt.n_levels; hd.n_wp = f->n_wp; hd.n_sparse = f->sparse ? f->n_sparse : 0;
+    hd.ref_ok = ref_ok; hd.n_coeff = f->n_coeff;
     hd.dbg = e->dbg;
     (void)s_hdr;
 
     /* stage everything in one host buffer -> one H2D copy */
     auto t_alloc = tnow();
     OhEngine::Stage *sg = stage_acquire(e, copy_bytes);   /* a pinned buffer whose previous copy has completed */
-    if (!sg) {
+    df->sum_host = summary_block_get(e, sum_bytes, &df->sum_pooled);
+    df->sum_bytes = sum_bytes;
+    if (!sg || !df->sum_host) {
         free_dev_frame(e, df);
         FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
     }
@@ -1111,48 +858,78 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
             memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
     /* asynchronous: the caller's arrays are already copied out; the pinned buffer stays busy until `done` */
-    hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, e->copy_stream);
+    hipStream_t cs = e->copy_stream;
+    hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, cs);
     if (hrc == hipSuccess)
-        hrc = hipEventRecord(sg->done, e->copy_stream);
+        hrc = hipEventRecord(sg->done, cs);
+    sg->busy = hrc == hipSuccess;
+    if (hrc == hipSuccess)
+        hrc = hipMemsetAsync(base + zero_off, 0, zero_bytes, cs);
+    if (hrc == hipSuccess) {
+        ohk_prepare((const DevFrame *)base, &cnt, cs);
+        hrc = hipGetLastError();
+    }
+    if (hrc == hipSuccess && bsi) {                        /* both grids from the maps: once per work list, the maps never change */
+        hrc = hipMemsetAsync(base + seg[s_vbs].off, 0, bs_bytes, cs);                        /* the padded tail is read by the deblock pass */
+        if (hrc == hipSuccess) hrc = hipMemsetAsync(base + seg[s_hbs].off, 0, bs_bytes, cs);
+        if (hrc == hipSuccess)
+            ohk_bs_derive(&p, base + seg[s_mvf].off, base + seg[s_cbf].off, base + seg[s_call].off, base + seg[s_bsf].off, bsi->loop_filter_across_tiles,
+                          base + seg[s_vbs].off, base + seg[s_hbs].off, cs);
+    }
+    if (hrc == hipSuccess)
+        hrc = hipMemcpyAsync(df->sum_host, base + seg[s_sum].off, sum_bytes, hipMemcpyDeviceToHost, cs);
     if (hrc == hipSuccess && (df->ready = sync_event_get(e)) == nullptr)
         hrc = hipErrorOutOfMemory;
     if (hrc == hipSuccess)
-        hrc = hipEventRecord(df->ready, e->copy_stream);
-    if (hrc == hipSuccess && bsi) {                        /* both grids from the maps: once per work list, the maps never change */
-        hrc = hipStreamWaitEvent(e->stream, df->ready, 0);
-        df->waited = true;
-    }
-    if (hrc == hipSuccess && bsi) {
-        char *b = (char *)df->arena;
-        hrc = hipMemsetAsync(b + seg[s_vbs].off, 0, bs_bytes, e->stream);                   /* the padded tail is read by the deblock pass */
-        if (hrc == hipSuccess) hrc = hipMemsetAsync(b + seg[s_hbs].off, 0, bs_bytes, e->stream);
-        if (hrc == hipSuccess)
-            ohk_bs_derive(&p, b + seg[s_mvf].off, b + seg[s_cbf].off, b + seg[s_call].off, b + seg[s_bsf].off, bsi->loop_filter_across_tiles,
-                          b + seg[s_vbs].off, b + seg[s_hbs].off, e->stream);
-    }
-    sg->busy = hrc == hipSuccess;
+        hrc = hipEventRecord(df->ready, cs);
     if (hrc != hipSuccess) {
+        (void)hipStreamSynchronize(cs);
         free_dev_frame(e, df);
         FAIL(e, OH_E_HIP, "work-list upload failed: %s", hipGetErrorString(hrc));
     }
     if (timing) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         auto t_end = tnow();
-        fprintf(stderr, "oh_frame_upload: validate + MC jobs %.2f ms, descriptors / levels %.2f ms, arena %.2f ms, staging copy + enqueue %.2f ms (%zu bytes)\n",
+        fprintf(stderr, "oh_frame_upload: host checks + counting %.3f ms, layout %.3f ms, arena %.3f ms, staging copy + enqueue %.3f ms (%zu bytes)\n",
                 ms(t_begin, t_valid), ms(t_valid, t_lists), ms(t_lists, t_alloc), ms(t_alloc, t_end), copy_bytes);
     }
     df->d = (DevFrame *)base;
     df->p = p;
-    df->n_mc_luma = hd.n_mc_luma; df->n_mc_chroma = hd.n_mc_chroma; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
+    df->n_mc_luma = cnt.n_mc_luma; df->n_mc_chroma = cnt.n_mc_chroma; df->n_tu = f->n_tu; df->n_intra = f->n_intra;
     for (int k = 0; k < 4; k++) df->tu_cnt[k] = tu_cnt[k];
-    df->n_cross = hd.n_cross;
+    df->n_cross = n_cross;
     df->has_sao = has_sao;
-    if (f->n_intra) {
-        df->levels = levels;
-    }
+    df->n_levels = cnt.n_levels;
     df->cur_pic = f->cur_pic;                  /* which half of cur_pic is final changes when the list is EXECUTED, not here */
     df->owner = e;
     *out = df;
+    return OH_OK;
+}
+
+/* the summary the preparation kernels left (prep.hip): waits for the list's `ready` event the first time */
+static int read_summary(OhEngine *e, OhDevFrame *df, int index)
+{
+    if (df->summary_read)
+        return df->prep_err ? OH_E_ARG : OH_OK;
+    HIPCHK(e, hipEventSynchronize(df->ready));
+    const DevSummary *s = (const DevSummary *)df->sum_host;
+    df->summary_read = true;
+    df->prep_err = s->err;
+    if (s->err) {
+        static const char *what[] = { "", "prediction unit", "transform block", "intra block", "intra schedule entry" };
+        FAIL(e, OH_E_ARG, "work list %d: %s %u is malformed (rectangle / reference / index out of range); nothing of it was executed",
+             index, what[s->err <= 4 ? s->err : 0], s->err_item);
+    }
+    for (int k = 0; k < 4; k++)
+        if (s->tu_cnt[k] != df->tu_cnt[k])
+            FAIL(e, OH_E_ARG, "work list %d: transform block counts changed between hand-over and preparation", index);
+    const DevLevelStat *ls = (const DevLevelStat *)(s + 1);
+    df->levels.resize(df->n_levels);
+    for (uint32_t l = 0; l < df->n_levels; l++) {
+        OhDevFrame::Level &L = df->levels[l];
+        L.n_ctu = ls[l].n_ctu; L.max_items = ls[l].max_items; L.max_sub = ls[l].max_sub; L.max_res = ls[l].max_res;
+        L.staged = ls[l].staged != 0; L.sum_items = ls[l].sum_items; L.sum_sub = ls[l].sum_sub;
+    }
     return OH_OK;
 }
 
@@ -1165,11 +942,15 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
         return OH_E_ARG;
     if (n == 0)
         return OH_OK;                                       /* an empty batch is a no-op */
+    HIPCHK(e, hipSetDevice(e->device));
     for (int i = 0; i < n; i++) {
         if (!dfs[i])
             return OH_E_ARG;
         if (dfs[i]->owner != e)
             FAIL(e, OH_E_ARG, "batch: picture %d was uploaded to another engine", i);
+        int src = read_summary(e, dfs[i], i);               /* a malformed list stops the batch before anything is launched */
+        if (src)
+            return src;
         const OhPicParams &a = dfs[0]->p, &b = dfs[i]->p;
         if (memcmp(&a, &b, sizeof(a)) != 0)
             FAIL(e, OH_E_ARG, "batch: picture %d has other parameters than picture 0", i);

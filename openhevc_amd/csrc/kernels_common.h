@@ -24,10 +24,11 @@ static __device__ __forceinline__ T gload(const T *p)
     static_assert(sizeof(T) % 4 == 0, "dword-sized structs only");
     T out;
     const GLOBAL uint32_t *s = (const GLOBAL uint32_t *)p;
-    uint32_t *d = (uint32_t *)&out;
+    uint32_t w[sizeof(T) / 4];
 #pragma unroll
     for (unsigned i = 0; i < sizeof(T) / 4; i++)
-        d[i] = s[i];
+        w[i] = s[i];
+    __builtin_memcpy(&out, w, sizeof(T));                     /* not through a uint32_t alias of `out`: its members have other types */
     return out;
 }
 

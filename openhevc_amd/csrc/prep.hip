@@ -1,0 +1,556 @@
+/*
+ * prep.hip — work-list preparation on the GPU: the raw lists a decoder hands over (OhPu / OhTu / OhIntra ... exactly as
+ * include/ohevc_frame.h defines them) are validated and turned into what the pass kernels consume, right behind the H2D copy
+ * on the engine's copy stream.  The host side of a hand-over is a memcpy and a few counting loops; nothing here depends on
+ * sample values, so it overlaps the passes of earlier pictures.
+ *
+ *   raw list                   kernel                 product (dev_frame.h)
+ *   OhPu[]                     prep_pu_scan           job offsets per PU (exclusive scan; one workgroup per picture)
+ *                              prep_pu_expand         DevMcJob lists: every plane rectangle of a PU cut into <= 8x8 blocks
+ *                              prep_mc_group          bi-predicted blocks first inside every run of 64 (a wave runs the second
+ *                                                     list when any of its four blocks has one)
+ *   OhTu[], tu_sparse, tu_cross prep_tu_count / _scatter  DevTu buckets by transform size, DevCross list, KEEP_RES marks
+ *   OhIntra[], sub_start       prep_intra_sub         <= 8x8 blocks first inside a sub-level (four of them share a wave)
+ *                              prep_intra_items       DevIntra: LDS offsets, edge sizes, filter / class flags, angles, the
+ *                                                     constrained-intra masks (hevcpred_template.c:116-163)
+ *   OhIntraCtu[], level_start  prep_intra_levels      DevIntraCtu (residual span, staged rectangle) and the per-level launch
+ *                                                     statistics the host sizes the intra launches with (DevSummary)
+ *
+ * Every index a pass kernel will follow is checked HERE (what engine.hip's host loop used to do): the first violation is
+ * latched in DevSummary.err, the remaining preparation kernels and — because oh_frames_execute reads the summary before it
+ * launches anything — all passes are skipped for that work list, so a malformed list never faults the GPU.
+ */
+#include <string.h>
+#include "kernels_common.h"
+
+static __device__ __forceinline__ DevSummary *summary_of(const DevFrame *f) { return (DevSummary *)f->summary; }
+static __device__ __forceinline__ bool failed(const DevFrame *f) { return *(volatile uint32_t *)&summary_of(f)->err != 0; }
+static __device__ __noinline__ void fail(const DevFrame *f, uint32_t code, uint32_t item)
+{
+    DevSummary *s = summary_of(f);
+    if (atomicCAS(&s->err, 0u, code) == 0u)
+        s->err_item = item;
+}
+
+/* ---------------------------------------------------------------- prediction units ---- */
+static __device__ __forceinline__ bool pu_ok(const DevFrame *f, const OhPu &pu)
+{
+    const OhPicParams &p = f->pp;
+    if (pu.w < 4 || pu.h < 4 || pu.w > 64 || pu.h > 64 || (pu.w & 3) || (pu.h & 3) || pu.x + pu.w > p.width || pu.y + pu.h > p.height ||
+        (pu.x & 3) || (pu.y & 3))
+        return false;
+    if (pu.ref[0] == OH_NO_REF && pu.ref[1] == OH_NO_REF)
+        return false;
+    for (int l = 0; l < 2; l++)
+        if (pu.ref[l] != OH_NO_REF && (pu.ref[l] >= OH_MAX_REFS || !((f->ref_ok >> pu.ref[l]) & 1)))
+            return false;
+    return pu.wp == OH_NO_WP || pu.wp < f->n_wp;
+}
+static __device__ __forceinline__ void pu_jobs(const DevFrame *f, const OhPu &pu, uint32_t &nl, uint32_t &nc)
+{
+    const OhPicParams &p = f->pp;
+    const int hs = hsh(p, 1), vs = vsh(p, 1);
+    nl = (uint32_t)(((pu.w + 7) >> 3) * ((pu.h + 7) >> 3));
+    nc = p.chroma_format_idc ? 2u * (uint32_t)((((pu.w >> hs) + 7) >> 3) * (((pu.h >> vs) + 7) >> 3)) : 0u;
+}
+
+/* exclusive scan of the per-PU block counts: one workgroup per picture walks the list in chunks of its size */
+__global__ __launch_bounds__(1024) void prep_pu_scan(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.x];
+    if (failed(f))
+        return;
+    __shared__ uint32_t wsum[2][16], carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (tid < 2) carry[tid] = 0;
+    __syncthreads();
+    uint32_t *__restrict__ offl = f->pu_off, *__restrict__ offc = f->pu_off + (f->n_pu + 1);
+    for (uint32_t base = 0; base < f->n_pu; base += blockDim.x) {
+        const uint32_t i = base + tid;
+        uint32_t nl = 0, nc = 0;
+        if (i < f->n_pu) {
+            const OhPu pu = gload(f->pu + i);
+            if (pu_ok(f, pu)) pu_jobs(f, pu, nl, nc);
+            else fail(f, OH_PE_PU, i);
+        }
+        uint32_t sl = nl, sc = nc;                              /* inclusive scan inside the wave */
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t a = __shfl_up(sl, d), b = __shfl_up(sc, d);
+            if (lane >= d) { sl += a; sc += b; }
+        }
+        if (lane == 63) { wsum[0][wave] = sl; wsum[1][wave] = sc; }
+        __syncthreads();
+        uint32_t bl = carry[0], bc = carry[1];
+        for (int w = 0; w < wave; w++) { bl += wsum[0][w]; bc += wsum[1][w]; }
+        if (i < f->n_pu) { offl[i] = bl + sl - nl; offc[i] = bc + sc - nc; }
+        __syncthreads();
+        if (tid == blockDim.x - 1) { carry[0] = bl + sl; carry[1] = bc + sc; }
+        (void)nw;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        offl[f->n_pu] = carry[0]; offc[f->n_pu] = carry[1];
+        if (carry[0] != f->n_mc_luma || carry[1] != f->n_mc_chroma)       /* the host sized the lists with the same arithmetic */
+            fail(f, OH_PE_PU, f->n_pu);
+    }
+}
+
+/* one plane's rectangle of a PU cut into the <= 8x8 blocks the MC kernel works on; a DevMcJob is written as its five dwords
+ * (x | y, w | h | ref[0] | ref[1], mv[0], mv[1], wp | c_idx | flags) */
+static __device__ __forceinline__ uint32_t emit_jobs(DevMcJob *__restrict__ out, uint32_t o, const OhPu &pu, int c, int hs, int vs)
+{
+    static_assert(sizeof(DevMcJob) == 20, "DevMcJob layout");
+    const int first = pu.ref[0] != OH_NO_REF ? 0 : 1;
+    const uint32_t ref0 = pu.ref[first], ref1 = first == 0 ? pu.ref[1] : (uint32_t)OH_NO_REF;
+    const uint32_t w2 = (uint32_t)(uint16_t)pu.mv[first][0] | ((uint32_t)(uint16_t)pu.mv[first][1] << 16);
+    const uint32_t w3 = (uint32_t)(uint16_t)pu.mv[1][0] | ((uint32_t)(uint16_t)pu.mv[1][1] << 16);
+    const uint32_t w4 = (uint32_t)pu.wp | ((uint32_t)c << 16) | ((first ? (uint32_t)OH_MCF_FROM_L1 : 0u) << 24);
+    const int x0 = pu.x >> hs, y0 = pu.y >> vs, w = pu.w >> hs, h = pu.h >> vs;
+    for (int oy = 0; oy < h; oy += 8)
+        for (int ox = 0; ox < w; ox += 8) {
+            const uint32_t bw = (uint32_t)(w - ox < 8 ? w - ox : 8), bh = (uint32_t)(h - oy < 8 ? h - oy : 8);
+            GLOBAL uint32_t *d = (GLOBAL uint32_t *)(out + o++);
+            d[0] = (uint32_t)(x0 + ox) | ((uint32_t)(y0 + oy) << 16);
+            d[1] = bw | (bh << 8) | (ref0 << 16) | (ref1 << 24);
+            d[2] = w2; d[3] = w3; d[4] = w4;
+        }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void prep_pu_expand(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f->n_pu || failed(f))
+        return;
+    const OhPu pu = gload(f->pu + i);
+    const OhPicParams &p = f->pp;
+    emit_jobs((DevMcJob *)f->mc_luma, f->pu_off[i], pu, 0, 0, 0);
+    if (p.chroma_format_idc) {
+        uint32_t o = f->pu_off[f->n_pu + 1 + i];
+        o = emit_jobs((DevMcJob *)f->mc_chroma, o, pu, 1, hsh(p, 1), vsh(p, 1));
+        emit_jobs((DevMcJob *)f->mc_chroma, o, pu, 2, hsh(p, 1), vsh(p, 1));
+    }
+}
+
+/* stable partition of every run of 64 blocks: the bi-predicted ones first.  A wave loads its run, then stores it permuted
+ * (all loads of the wave precede its stores in program order, so the run is rearranged in place). */
+__global__ __launch_bounds__(64) void prep_mc_group(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    if (failed(f))
+        return;
+    const uint32_t runs_l = (f->n_mc_luma + 63) >> 6;
+    const bool luma = blockIdx.x < runs_l;
+    const uint32_t run = luma ? blockIdx.x : blockIdx.x - runs_l, n = luma ? f->n_mc_luma : f->n_mc_chroma;
+    if ((uint64_t)run * 64 >= n)
+        return;
+    DevMcJob *__restrict__ jobs = (DevMcJob *)(luma ? f->mc_luma : f->mc_chroma) + (size_t)run * 64;
+    const int lane = threadIdx.x, cnt = (int)min(64u, n - run * 64);
+    const bool live = lane < cnt;
+    uint32_t w[5] = { 0, 0, 0, 0, 0 };
+    if (live) {
+        const GLOBAL uint32_t *s = (const GLOBAL uint32_t *)(jobs + lane);
+#pragma unroll
+        for (int q = 0; q < 5; q++) w[q] = s[q];
+    }
+    const bool bi = live && ((w[1] >> 24) & 0xff) != OH_NO_REF;          /* DevMcJob.ref[1]: byte 7 */
+    const unsigned long long mb = __builtin_amdgcn_ballot_w64(bi), ml = __builtin_amdgcn_ballot_w64(live && !bi);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int dst = bi ? __builtin_popcountll(mb & below) : __builtin_popcountll(mb) + __builtin_popcountll(ml & below);
+    __builtin_amdgcn_s_waitcnt(0);
+    if (live) {
+        GLOBAL uint32_t *d = (GLOBAL uint32_t *)(jobs + dst);
+#pragma unroll
+        for (int q = 0; q < 5; q++) d[q] = w[q];
+    }
+}
+
+/* ---------------------------------------------------------------- transform blocks ---- */
+static __device__ __forceinline__ bool tu_ok(const DevFrame *f, const OhTu &t, uint32_t i)
+{
+    const OhPicParams &p = f->pp;
+    const int nplanes = p.chroma_format_idc ? 3 : 1;
+    if (t.c_idx >= nplanes || t.log2_size < 2 || t.log2_size > 5 || t.kind > OH_TU_PCM)
+        return false;
+    const int n = 1 << t.log2_size;
+    if (t.x + n > f->cur.w[t.c_idx] || t.y + n > f->cur.h[t.c_idx])
+        return false;
+    if ((uint64_t)t.coeff_off + (uint64_t)n * n > f->n_coeff || (t.coeff_off & 3) || (t.x & 3) || (t.y & 3))
+        return false;
+    if ((t.flags & OH_TUF_ROTATE) && t.log2_size != 2)
+        return false;
+    if (t.flags & OH_TUF_CROSS) {
+        const uint32_t cw = f->tu_cross ? f->tu_cross[i] : OH_NO_COEFF, ty = cw & 0xffffff;
+        if (cw == OH_NO_COEFF || p.chroma_format_idc != 3 || t.c_idx == 0 || ty >= f->n_tu || t.kind == OH_TU_PCM)
+            return false;
+        const OhTu y = gload(f->tu_raw + ty);
+        if (y.c_idx != 0 || y.log2_size != t.log2_size)
+            return false;
+    }
+    if (t.flags & OH_TUF_SPARSE) {
+        if (!f->sparse || !f->tu_sparse || t.kind == OH_TU_BYPASS || t.kind == OH_TU_PCM)
+            return false;
+        const uint64_t so = f->tu_sparse[i];
+        if (so >= f->n_sparse)
+            return false;
+        const uint32_t w0 = f->sparse[so], cnt = w0 & 0xffff, qp = (w0 >> 16) & 0xff, mid = w0 >> 24;
+        if (cnt > (uint32_t)(n * n) || so + 1 + cnt > f->n_sparse || qp > 75 || (mid != OH_FLAT_MATRIX && (mid > 5 || !f->scaling)))
+            return false;
+        for (uint32_t k = 0; k < cnt; k++)
+            if ((f->sparse[so + 1 + k] & 0xffff) >= (uint32_t)(n * n))
+                return false;
+    } else if (!f->coeffs_present) {
+        return false;                                               /* dense block, but no pool came with the list */
+    }
+    return true;
+}
+
+/* pass 1 over the list: validation, the per-size counts (one atomic per wave and size), the luma blocks cross-component blocks read */
+__global__ __launch_bounds__(256) void prep_tu_count(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (failed(f))
+        return;
+    const bool live = i < f->n_tu;
+    int k = -1;
+    if (live) {
+        const OhTu t = gload(f->tu_raw + i);
+        if (tu_ok(f, t, i)) {
+            k = t.log2_size - 2;
+            if (t.flags & OH_TUF_CROSS) {
+                ((uint8_t *)f->tu_keep)[f->tu_cross[i] & 0xffffff] = 1;
+                atomicAdd(&f->tu_cursor[8], 1u);
+            }
+        } else {
+            fail(f, OH_PE_TU, i);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(k == s);
+        if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m))
+            atomicAdd(&f->tu_cursor[s], (uint32_t)__builtin_popcountll(m));
+    }
+}
+
+/* pass 2: every block goes to its size bucket (a wave's blocks of one size stay together and in order) */
+__global__ __launch_bounds__(256) void prep_tu_scatter(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (failed(f))
+        return;
+    const bool live = i < f->n_tu;
+    OhTu t;
+    int k = -1;
+    if (live) { t = gload(f->tu_raw + i); k = t.log2_size - 2; }
+    uint32_t first[4] = { 0, 0, 0, 0 };
+    for (int s = 1; s < 4; s++) first[s] = first[s - 1] + f->tu_cursor[s - 1];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(k == s);
+        if (!m)
+            continue;
+        uint32_t base = 0;
+        const int leader = __builtin_ctzll(m);
+        if (lane == leader)
+            base = atomicAdd(&f->tu_cursor[4 + s], (uint32_t)__builtin_popcountll(m));
+        base = __shfl(base, leader);
+        if (k == s) {
+            alignas(16) DevTu d;
+            d.t = t;
+            if (f->tu_keep[i]) d.t.flags |= OH_TUF_KEEP_RES;
+            d.sparse_off = (t.flags & OH_TUF_SPARSE) ? f->tu_sparse[i] : OH_NO_COEFF;
+            GLOBAL uint4v *o = (GLOBAL uint4v *)((DevTu *)f->tu + first[s] + base + (uint32_t)__builtin_popcountll(m & below));
+            uint4v q;
+            __builtin_memcpy(&q, &d, 16);
+            *o = q;
+        }
+    }
+    if (live && (t.flags & OH_TUF_CROSS)) {
+        /* cross-component prediction: the chroma block is finished by cross_kernel once every inverse transform of the picture is done */
+        const uint32_t cw = f->tu_cross[i];
+        const OhTu ty = gload(f->tu_raw + (cw & 0xffffff));
+        alignas(16) DevCross d;
+        d.x = t.x; d.y = t.y; d.c_idx = t.c_idx; d.log2_size = t.log2_size; d.flags = t.flags;
+        d.scale = (int8_t)(cw >> 24); d.res_c = t.coeff_off; d.res_y = ty.coeff_off;
+        const uint32_t o = atomicAdd(&f->tu_cursor[9], 1u);
+        uint4v q;
+        __builtin_memcpy(&q, &d, 16);
+        *(GLOBAL uint4v *)((DevCross *)f->cross + o) = q;
+    }
+}
+
+/* ---------------------------------------------------------------- intra blocks ---- */
+/* inside a sub-level the blocks are independent: the <= 8x8 ones go first — the intra kernel runs four of them per wave —
+ * and sub_small says how many there are (none with constrained intra pred, which needs the one-block path) */
+__global__ __launch_bounds__(256) void prep_intra_sub(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= f->n_sub || failed(f))
+        return;
+    const uint32_t b0 = f->sub_start[j], b1 = f->sub_start[j + 1];
+    if (b0 > b1 || b1 > f->n_intra || (j == 0 && b0 != 0) || (j + 1 == f->n_sub && b1 != f->n_intra)) {
+        fail(f, OH_PE_INTRA_TABLES, j);
+        return;
+    }
+    uint32_t ns = 0;
+    for (uint32_t b = b0; b < b1; b++)
+        ns += gload(f->intra_raw + b).log2_size <= 3;
+    uint32_t ws = b0, wb = b0 + ns;
+    for (uint32_t b = b0; b < b1; b++)
+        f->intra_perm[b] = gload(f->intra_raw + b).log2_size <= 3 ? ws++ : wb++;
+    f->sub_small_w[j] = f->pp.constrained_intra_pred ? 0u : ns;
+}
+
+__constant__ int8_t c_angle[33] = { 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                                    -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };      /* intraPredAngle, H.265 table 8-4 */
+__constant__ int16_t c_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+
+/* one block: OhIntra -> DevIntra, everything that depends only on geometry and mode resolved (what intra_pred() derives per call,
+ * hevcpred_template.c:73-163, 288-294) */
+__global__ __launch_bounds__(256) void prep_intra_items(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f->n_intra || failed(f))
+        return;
+    const OhPicParams &p = f->pp;
+    const OhIntra it = gload(f->intra_raw + i);
+    const int nplanes = p.chroma_format_idc ? 3 : 1;
+    if (it.c_idx >= nplanes || it.log2_size < 2 || it.log2_size > 5 || it.mode > 34) { fail(f, OH_PE_INTRA, i); return; }
+    const int c = it.c_idx, hs = hsh(p, c), vs = vsh(p, c), log2 = it.log2_size, n = 1 << log2, mode = it.mode;
+    const int pw = f->cur.w[c], ph = f->cur.h[c];
+    if (it.x + n > pw || it.y + n > ph ||
+        ((it.avail & (OH_AV_LEFT | OH_AV_BOTTOM_LEFT | OH_AV_UP_LEFT)) && it.x == 0) ||
+        ((it.avail & (OH_AV_UP | OH_AV_UP_RIGHT | OH_AV_UP_LEFT)) && it.y == 0) ||
+        ((it.avail & OH_AV_UP_RIGHT) && it.x + n >= pw) || ((it.avail & OH_AV_BOTTOM_LEFT) && it.y + n >= ph)) { fail(f, OH_PE_INTRA, i); return; }
+    alignas(16) DevIntra d;
+    __builtin_memset(&d, 0, sizeof(d));
+    d.res_off = OH_NO_COEFF;
+    if (it.tu != OH_NO_COEFF) {
+        if (it.tu >= f->n_tu) { fail(f, OH_PE_INTRA, i); return; }
+        const OhTu t = gload(f->tu_raw + it.tu);
+        if (t.c_idx != it.c_idx || t.x != it.x || t.y != it.y || t.log2_size != it.log2_size || (t.flags & OH_TUF_ADD_NOW)) { fail(f, OH_PE_INTRA, i); return; }
+        d.res_off = t.coeff_off;
+    }
+    const int lc = p.log2_ctb_size, rs = ((1 << lc) >> hs) + 4;
+    const OhCtuAreas areas = oh_ctu_areas(lc, p.chroma_format_idc);
+    const int lx = it.x - ((((it.x << hs) >> lc) << lc) >> hs), ly = it.y - ((((it.y << vs) >> lc) << lc) >> vs);
+    const uint32_t a_main = c == 0 ? areas.main[0] : c == 1 ? areas.main[1] : areas.main[2];
+    const uint32_t a_top = c == 0 ? areas.top[0] : c == 1 ? areas.top[1] : areas.top[2];
+    d.x = it.x; d.y = it.y; d.c_idx = it.c_idx; d.log2_size = it.log2_size; d.mode = it.mode; d.avail = it.avail;
+    d.rs = (uint16_t)rs;
+    d.cm_off = (uint16_t)(a_main + ly * rs + lx + 4);
+    d.top_off = (uint16_t)(ly == 0 ? a_top + lx + 4 : d.cm_off - rs);
+    const int tr = (it.x + 2 * n < pw ? it.x + 2 * n : pw) - (it.x + n);
+    const int bl = (it.y + 2 * n < ph ? it.y + 2 * n : ph) - (it.y + n);
+    d.tr_size = (uint8_t)(tr < 0 ? 0 : tr); d.bl_size = (uint8_t)(bl < 0 ? 0 : bl);
+    int flags = 0, cls;
+    if (!p.intra_smoothing_disabled && (c == 0 || p.chroma_format_idc == 3) && mode != 1 && n != 4) {   /* :288-294 */
+        const int d26 = mode > 26 ? mode - 26 : 26 - mode, d10 = mode > 10 ? mode - 10 : 10 - mode;
+        const int thresh = log2 == 3 ? 7 : log2 == 4 ? 1 : 0;
+        if ((d26 < d10 ? d26 : d10) > thresh) {
+            flags |= OH_IF_FILTER;
+            if (p.strong_intra_smoothing && c == 0 && log2 == 5) flags |= OH_IF_STRONG_CAND;
+        }
+    }
+    if (c == 0 && n < 32 && (mode == 1 || mode == 10 || mode == 26)) flags |= OH_IF_EDGE;     /* :410-416, :474-477, :501-508 */
+    if (mode == 0) cls = OH_IC_PLANAR;
+    else if (mode == 1) cls = OH_IC_DC;
+    else if (mode == 26) cls = OH_IC_PURE_V;
+    else if (mode == 10) cls = OH_IC_PURE_H;
+    else cls = mode >= 18 ? OH_IC_ANG_V : OH_IC_ANG_H;
+    if (mode >= 2) {
+        d.angle = c_angle[mode - 2];
+        if (d.angle < 0 && ((n * d.angle) >> 5) < -1) d.inv_angle = c_inv_angle[mode - 11];
+    }
+    if (p.constrained_intra_pred) {
+        /* hevcpred_template.c:116-163: candidates that lie in inter CUs do not count; the kernel's slow path then
+         * patches the gathered edges from the per-group intra masks (:185-249) */
+        const GLOBAL uint8_t *map = G_CONST(uint8_t, f->is_intra);
+        const int lpu = p.log2_min_pu_size, mpw = p.width >> lpu, mph = p.height >> lpu;
+        const int X0 = it.x << hs, Y0 = it.y << vs, sl_h = n << hs, sl_v = n << vs;
+        auto cell = [&](int px, int py) { return px >= 0 && py >= 0 && px < mpw && py < mph && map[px + py * mpw] != 0; };
+        auto isi = [&](int dx, int dy) { return cell((X0 + dx * (1 << hs)) >> lpu, (Y0 + dy * (1 << vs)) >> lpu); };
+        int pu_v = sl_v >> lpu, pu_h = sl_h >> lpu, av = it.avail;
+        const bool on_x = !(X0 & ((1 << lpu) - 1)), on_y = !(Y0 & ((1 << lpu) - 1));
+        if (!pu_h) pu_h++;
+        auto any2 = [&](int px, int py, int dx, int dy, int cnt) { bool r = false; for (int q = 0; q < cnt; q += 2) r |= cell(px + q * dx, py + q * dy); return r; };
+        if ((av & OH_AV_BOTTOM_LEFT) && on_x) {
+            const int yb = (Y0 + sl_v) >> lpu;
+            if (!any2((X0 - 1) >> lpu, yb, 0, 1, min(pu_v, mph - yb))) av &= ~OH_AV_BOTTOM_LEFT;
+        }
+        if ((av & OH_AV_LEFT) && on_x) {
+            const int yl = Y0 >> lpu;
+            if (!any2((X0 - 1) >> lpu, yl, 0, 1, min(pu_v, mph - yl))) av &= ~OH_AV_LEFT;
+        }
+        if ((av & OH_AV_UP_LEFT) && !cell((X0 - 1) >> lpu, (Y0 - 1) >> lpu)) av &= ~OH_AV_UP_LEFT;
+        if ((av & OH_AV_UP) && on_y) {
+            const int xt = X0 >> lpu;
+            if (!any2(xt, (Y0 - 1) >> lpu, 1, 0, min(pu_h, mpw - xt))) av &= ~OH_AV_UP;
+        }
+        if ((av & OH_AV_UP_RIGHT) && on_y) {
+            const int xr = (X0 + sl_h) >> lpu;
+            if (!any2(xr, (Y0 - 1) >> lpu, 1, 0, min(pu_h, mpw - xr))) av &= ~OH_AV_UP_RIGHT;
+        }
+        d.avail = (uint8_t)av;
+        unsigned lm = 0, tm = 0;
+        for (int k = 0; 4 * k < 2 * n; k++) {
+            if (it.x > 0 && isi(-1, 4 * k)) lm |= 1u << k;
+            if (it.y > 0 && isi(4 * k, -1)) tm |= 1u << k;
+        }
+        d.cip_left = (uint16_t)lm; d.cip_top = (uint16_t)tm;
+        flags |= OH_IF_CIP;
+        if (it.x > 0 && it.y > 0 && isi(-1, -1)) flags |= OH_IF_CIP_CORNER;
+    }
+    d.flags = (uint8_t)(flags | (cls << 4));
+    GLOBAL uint4v *o = (GLOBAL uint4v *)((DevIntra *)f->intra + f->intra_perm[i]);
+    uint4v q[2];
+    static_assert(sizeof(DevIntra) == 32, "DevIntra layout");
+    __builtin_memcpy(q, &d, 32);
+    o[0] = q[0]; o[1] = q[1];
+}
+
+/* One workgroup per wavefront level, one lane per CTU of it: the CTU's entry of the schedule is checked (the level ->
+ * ictu[] -> sub_start[] -> intra[] nesting the intra kernel follows blindly), its residual span and staged rectangle
+ * are derived, and the level's launch statistics are reduced into the summary. */
+__global__ __launch_bounds__(64) void prep_intra_levels(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t l = blockIdx.x;
+    if (l >= f->n_levels || failed(f))
+        return;
+    const OhPicParams &p = f->pp;
+    const int lc = p.log2_ctb_size, ctbw = (p.width + (1 << lc) - 1) >> lc, ctbh = (p.height + (1 << lc) - 1) >> lc;
+    const uint32_t k0 = f->lvl_start[l], k1 = f->lvl_start[l + 1];         /* the host checked the level table (it needs it) */
+    uint32_t max_items = 1, max_sub = 1, max_res = 0, staged = 1;
+    unsigned long long sum_items = 0, sum_sub = 0;
+    DevIntra *__restrict__ di = (DevIntra *)f->intra;
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += 64) {
+        const OhIntraCtu c = gload(f->ictu_raw + k);
+        const uint32_t expect = k ? gload(f->ictu_raw + k - 1).sub_first + gload(f->ictu_raw + k - 1).n_sub : 0u;
+        if (c.sub_first != expect || !c.n_sub || (uint64_t)c.sub_first + c.n_sub > f->n_sub || (k + 1 == f->n_ictu && c.sub_first + c.n_sub != f->n_sub) ||
+            c.ctu >= (uint32_t)(ctbw * ctbh) || c.n_sub > OH_MAX_CTU_BLOCKS) { fail(f, OH_PE_INTRA_TABLES, k); continue; }
+        const uint32_t b0 = f->sub_start[c.sub_first], b1 = f->sub_start[c.sub_first + c.n_sub];
+        if (b1 - b0 > OH_MAX_CTU_BLOCKS || atomicExch(&f->ctu_seen[c.ctu], 1u) != 0u) { fail(f, OH_PE_INTRA_TABLES, k); continue; }
+        alignas(16) DevIntraCtu d;
+        d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu; d.item0 = b0; d.n_items = b1 - b0;
+        unsigned long long lo = ~0ull, hi = 0;
+        int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
+        bool any_res = false, bad = false;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint4v q0 = *(const GLOBAL uint4v *)(di + b), q1 = *((const GLOBAL uint4v *)(di + b) + 1);
+            const int x = q0[0] & 0xffff, y = q0[0] >> 16, ci = q0[1] & 0xff, log2 = (q0[1] >> 8) & 0xff, n = 1 << log2;
+            const uint32_t res_off = q0[2];
+            const int hs = hsh(p, ci), vs = vsh(p, ci);
+            if ((uint32_t)((((y << vs) >> lc) * ctbw) + ((x << hs) >> lc)) != c.ctu) bad = true;       /* the CTU is written back from c.ctu's origin */
+            const int lx = x - ((((x << hs) >> lc) << lc) >> hs), ly = y - ((((y << vs) >> lc) << lc) >> vs);
+            bx0 = min(bx0, (lx - 1) * (1 << hs)); bx1 = max(bx1, (lx + 2 * n) << hs);
+            by0 = min(by0, (ly - 1) * (1 << vs)); by1 = max(by1, (ly + 2 * n) << vs);
+            (void)q1;
+            if (res_off == OH_NO_COEFF)
+                continue;
+            any_res = true;
+            const unsigned long long e = (unsigned long long)res_off + (1u << (2 * log2));
+            lo = min(lo, (unsigned long long)res_off); hi = max(hi, e);
+        }
+        if (bad) { fail(f, OH_PE_INTRA_TABLES, k); continue; }
+        d.res_lo = 0; d.res_cnt = 0;
+        d.bx0 = (int16_t)bx0; d.bx1 = (int16_t)bx1; d.by0 = (int16_t)by0; d.by1 = (int16_t)by1;
+        if (hi > lo && (lo & 3) == 0 && hi - lo <= 3u * 64 * 64) {
+            /* the CTU's residual blocks lie together in the pool (a recorder appends them CTU by CTU): stageable in LDS */
+            d.res_lo = (uint32_t)lo;
+            d.res_cnt = (uint32_t)((hi - lo + 3) & ~3ull);
+            if ((unsigned long long)d.res_lo + d.res_cnt > f->n_coeff) d.res_cnt = (uint32_t)(hi - lo) & ~3u;
+        }
+        if (d.res_cnt)
+            for (uint32_t b = b0; b < b1; b++) {
+                const uint32_t ro = *((const GLOBAL uint32_t *)(di + b) + 2);
+                if (ro != OH_NO_COEFF) *((GLOBAL uint32_t *)(di + b) + 6) = ro - d.res_lo;       /* DevIntra.res_lds */
+            }
+        {
+            GLOBAL uint4v *o = (GLOBAL uint4v *)((DevIntraCtu *)f->ictu + k);
+            uint4v q[2];
+            static_assert(sizeof(DevIntraCtu) == 32, "DevIntraCtu layout");
+            __builtin_memcpy(q, &d, 32);
+            o[0] = q[0]; o[1] = q[1];
+        }
+        if (any_res && !d.res_cnt) staged = 0;
+        max_items = max(max_items, min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
+        max_sub = max(max_sub, min((uint32_t)c.n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
+        max_res = max(max_res, d.res_cnt);
+        for (uint32_t j = c.sub_first; j < c.sub_first + c.n_sub; j++) {                         /* wave passes: slot groups + big blocks */
+            const uint32_t sm = f->sub_small_w[j];
+            sum_items += (sm + 3) / 4 + (f->sub_start[j + 1] - f->sub_start[j] - sm);
+        }
+        sum_sub += c.n_sub;
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) {
+        max_items = max(max_items, (uint32_t)__shfl_xor((int)max_items, d));
+        max_sub = max(max_sub, (uint32_t)__shfl_xor((int)max_sub, d));
+        max_res = max(max_res, (uint32_t)__shfl_xor((int)max_res, d));
+        staged = min(staged, (uint32_t)__shfl_xor((int)staged, d));
+        sum_items += __shfl_xor(sum_items, d);
+        sum_sub += __shfl_xor(sum_sub, d);
+    }
+    if (threadIdx.x == 0) {
+        DevLevelStat s;
+        s.n_ctu = k1 - k0; s.max_items = max_items; s.max_sub = max_sub; s.max_res = max_res; s.staged = staged; s.pad = 0;
+        s.sum_items = sum_items; s.sum_sub = sum_sub;
+        DevLevelStat *o = (DevLevelStat *)(summary_of(f) + 1) + l;
+        *o = s;
+    }
+}
+
+/* last: the bucket ranges the residual launches read, the counts the host compares with its own */
+__global__ void prep_finish(const OhBatch B)
+{
+    DevFrame *f = (DevFrame *)B.f[blockIdx.x];
+    if (threadIdx.x || failed(f))
+        return;
+    DevSummary *s = summary_of(f);
+    uint32_t first = 0;
+    for (int k = 0; k < 4; k++) {
+        f->tu_first[k] = first; f->tu_cnt[k] = f->tu_cursor[k];
+        first += f->tu_cursor[k];
+        s->tu_cnt[k] = f->tu_cursor[k];
+        if (f->tu_cursor[4 + k] != f->tu_cursor[k]) fail(f, OH_PE_TU, 0xffffffffu);
+    }
+    f->n_cross = f->tu_cursor[8];
+    s->n_cross = f->tu_cursor[8];
+    if (first != f->n_tu || f->tu_cursor[9] != f->tu_cursor[8]) fail(f, OH_PE_TU, 0xffffffffu);
+}
+
+/* =========================================================================================
+ * launcher: everything for ONE work list, enqueued on `st` (the engine's copy stream, behind the list's H2D copy)
+ * ======================================================================================= */
+extern "C" void ohk_prepare(const DevFrame *dev, const OhPrepCounts *n, hipStream_t st)
+{
+    OhBatch B;
+    memset(&B, 0, sizeof(B));
+    B.f[0] = dev;
+    if (n->n_pu) {
+        hipLaunchKernelGGL(prep_pu_scan, dim3(1), dim3(1024), 0, st, B);
+        hipLaunchKernelGGL(prep_pu_expand, dim3((n->n_pu + 255) / 256, 1), dim3(256), 0, st, B);
+        const uint32_t runs = ((n->n_mc_luma + 63) >> 6) + ((n->n_mc_chroma + 63) >> 6);
+        if (runs) hipLaunchKernelGGL(prep_mc_group, dim3(runs, 1), dim3(64), 0, st, B);
+    }
+    if (n->n_tu) {
+        hipLaunchKernelGGL(prep_tu_count, dim3((n->n_tu + 255) / 256, 1), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(prep_tu_scatter, dim3((n->n_tu + 255) / 256, 1), dim3(256), 0, st, B);
+    }
+    if (n->n_intra) {
+        hipLaunchKernelGGL(prep_intra_sub, dim3((n->n_sub + 255) / 256, 1), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(prep_intra_items, dim3((n->n_intra + 255) / 256, 1), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(prep_intra_levels, dim3(n->n_levels, 1), dim3(64), 0, st, B);
+    }
+    hipLaunchKernelGGL(prep_finish, dim3(1), dim3(64), 0, st, B);
+}

@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
     ap.add_argument("--chains", type=int, default=None, help="closed GOPs (steps) in flight per GPU (default: 96; 24 for the 8K workloads, whose pictures are 100-200 MB)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
     ap.add_argument("--mode", default="decode", choices=["decode", "kernel_only"],
@@ -207,10 +207,12 @@ def main():
         for eng in engines:
             eng.pass_times(reset=True)
             eng.intra_launch_times(reset=True)
+            eng.host_times(reset=True)
+            eng.upload_bytes(reset=True)
             eng.n_batches = 0
             eng.profile(0 if args.no_profile else 2)      # events between passes and around every intra launch
         for _, be_k, _, _ in chains:
-            be_k.upload_s, be_k.uploads = 0.0, 0
+            be_k.upload_s, be_k.uploads, be_k.execute_s, be_k.release_s = 0.0, 0, 0.0, 0.0
         barrier()
         t0 = time.perf_counter()
         run(n_steps)
@@ -284,8 +286,20 @@ def main():
         dt, dt_enq = timed(args.warmup, args.steps)
         up_s = sum(be_k.upload_s for _, be_k, _, _ in chains)
         n_up = sum(be_k.uploads for _, be_k, _, _ in chains)
-        decode = dict(dt=dt, dt_enqueue=dt_enq, roofline=collect(dt, args.steps) if rank == 0 else None,
-                      upload_ms_per_picture=round(up_s * 1e3 / max(n_up, 1), 4))
+        ex_s = sum(getattr(be_k, "execute_s", 0.0) for _, be_k, _, _ in chains)
+        rl_s = sum(getattr(be_k, "release_s", 0.0) for _, be_k, _, _ in chains)
+        ht = {}
+        for eng in engines:
+            for k, (ms, calls) in eng.host_times().items():
+                ht[k] = ht.get(k, 0.0) + ms
+        host_profile = {k: round(v / max(n_up, 1), 4) for k, v in ht.items()}       # ms per picture, summed over the host threads
+        up_bytes = sum(eng.upload_bytes() for eng in engines)
+        host_profile["MB_over_pcie_per_picture"] = round(up_bytes / max(n_up, 1) / 1e6, 3)
+        host_profile["pcie_GBps_in_region"] = round(up_bytes / dt / 1e9, 2)
+        decode = dict(dt=dt, dt_enqueue=dt_enq, roofline=collect(dt, args.steps) if rank == 0 else None, host_profile=host_profile,
+                      upload_ms_per_picture=round(up_s * 1e3 / max(n_up, 1), 4),
+                      host_ms_per_picture=dict(upload=round(up_s * 1e3 / max(n_up, 1), 4), execute_enqueue_incl_wait_for_preparation=round(ex_s * 1e3 / max(n_up, 1), 4),
+                                               release=round(rl_s * 1e3 / max(n_up, 1), 4)))
     # resident work lists: the same passes without the hand-over
     k_steps = args.steps if args.mode == "kernel_only" else max(2, args.steps // 2)
     k_warm = args.warmup if args.mode == "kernel_only" else 1
@@ -323,6 +337,8 @@ def main():
                      "passes, stream-ordered release)" if decode is not None else "kernel_only: resident work lists replayed"),
             "host_threads": host_threads,
             "upload_ms_per_picture": decode["upload_ms_per_picture"] if decode is not None else None,
+            "host_ms_per_picture": decode["host_ms_per_picture"] if decode is not None else None,
+            "host_profile_ms_per_picture": decode["host_profile"] if decode is not None else None,
             "kernel_only": {"value": round(kv * luma_px / kernel_only["dt"] / 1e6, 2), "fps": round(kv / kernel_only["dt"], 2), "steps": k_steps,
                             "ms_per_step": round(kernel_only["dt"] / k_steps * 1e3, 4),
                             "host_enqueue_ms_per_step": round(kernel_only["dt_enqueue"] / k_steps * 1e3, 4),

@@ -97,6 +97,9 @@ int oh_pic_upsample(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u);
  * execute enqueues passes 1-5 on the engine stream and may be called repeatedly on the same
  * device frame (the coefficient pool is never modified). */
 int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out);
+/* n work lists at once: the host part and the copy per list, ONE set of preparation launches for all of them (what a batch of
+ * independent pictures that will run as one oh_frames_execute should use).  All or nothing: on error no list stays uploaded. */
+int oh_frames_upload(OhEngine *e, const OhFrame *const *fs, int n, OhDevFrame **out);
 int oh_frame_execute(OhEngine *e, OhDevFrame *df);
 /* n mutually independent pictures (none is a reference of another one; same OhPicParams): every pass
  * is ONE launch over all of them, which is how pictures of independent sequences / GOPs (the reference's
@@ -121,6 +124,13 @@ int oh_engine_pass_times(OhEngine *e, double *ms, uint64_t *executes, int reset)
 /* the intra pass is one launch per CTU-wavefront level: summed per-launch device time and launch
  * count (events bracket every launch in profile mode); read after oh_engine_pass_times() */
 int oh_engine_intra_launch_times(OhEngine *e, double *ms, uint64_t *launches, int reset);
+
+/* where the HOST time of the hand-over path went since the last reset: accumulated wall milliseconds and calls per OH_HT_* slot
+ * (nested: OH_HT_UPLOAD contains the OH_HT_UPLOAD_* parts, OH_HT_EXECUTE contains OH_HT_EXECUTE_WAIT_PREP) */
+enum OhHostTime { OH_HT_UPLOAD = 0, OH_HT_UPLOAD_COUNT, OH_HT_UPLOAD_ARENA, OH_HT_UPLOAD_STAGE_WAIT, OH_HT_UPLOAD_MEMCPY, OH_HT_UPLOAD_ENQUEUE,
+                  OH_HT_EXECUTE, OH_HT_EXECUTE_WAIT_PREP, OH_HT_RELEASE, OH_N_HOST_TIMES };
+int oh_engine_host_times(OhEngine *e, double *ms, uint64_t *calls, int n, int reset);
+uint64_t oh_engine_upload_bytes(OhEngine *e, int reset);      /* bytes of work lists copied host -> device since the last reset */
 
 /* the stream everything is enqueued on (hipStream_t as void*), for callers that need to order
  * their own work (RCCL broadcasts of reference pictures) against the engine */

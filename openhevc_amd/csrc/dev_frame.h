@@ -155,13 +155,16 @@ struct DevFrame {
     uint32_t n_ictu, n_sub, n_levels, n_wp, n_sparse, ref_ok;      /* ref_ok: bit i = reference slot i holds a usable picture */
     uint32_t coeffs_present;
     uint64_t n_coeff;
-    uint32_t *pu_off;                 /* [2][n_pu + 1]: first luma / chroma block of every PU     */
+    const uint32_t *pu_off;           /* [2][n_pu + 1]: first luma / chroma block of every PU (counted by the host while sizing the lists) */
     uint8_t  *tu_keep;                /* [n_tu]: luma block whose residual a cross-component block reads */
     uint32_t *tu_cursor;              /* [0..3] blocks per size, [4..7] scatter cursors, [8] cross-component blocks, [9] their cursor */
     uint32_t *intra_perm;             /* [n_intra]: position of block i after the <= 8x8-first partition of its sub-level */
     uint32_t *sub_small_w;            /* = sub_small, writable */
     uint32_t *ctu_seen;               /* [CTBs]: a CTU may head one schedule entry only */
+    uint32_t *ctu_aux;                /* [n_ictu]: wave passes of the entry | its residual is not stageable << 31 */
     void     *summary;                /* DevSummary + DevLevelStat[n_levels] */
+    void     *summary_host;           /* pinned host copy, written by prep_finish (no D2H copy on the stream) */
+    uint32_t *zero_ptr; uint32_t zero_words;      /* scratch the preparation starts from cleared (prep_clear) */
     /* 16x16 CTBs with horizontally subsampled chroma only (else null): the first chroma column of every CTB on the two rows of
      * every horizontal chroma edge as it was BEFORE the horizontal-edge pass — the reference's CTB driver lets the SAO of the
      * left neighbour read exactly that (deblock.hip: oh_sao_stale_*) */

@@ -56,6 +56,8 @@ struct OhDevFrame {
     void      *sum_host = nullptr;/* pinned: DevSummary + DevLevelStat[n_levels] as the preparation kernels left them */
     size_t     sum_bytes = 0;
     bool       sum_pooled = false, summary_read = false;
+    void      *sum_dev = nullptr; /* the summary in the arena */
+    OhPrepCounts cnt{};           /* sizes of the preparation launches */
     uint32_t   prep_err = 0, n_levels = 0;
     const struct OhEngine *owner = nullptr;   /* picture ids and arenas belong to one engine */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
@@ -93,6 +95,9 @@ struct OhEngine {
     std::vector<Arena> arenas;               /* free device arenas */
     std::vector<hipEvent_t> sync_events;     /* pool of timing-disabled events (ready / free_ev) */
     std::vector<void *> sum_pool;            /* pinned OH_SUMMARY_BLOCK-byte blocks */
+    double      host_ms[OH_N_HOST_TIMES] = {};   /* where the host time of the hand-over path goes (oh_engine_host_times) */
+    uint64_t    host_calls[OH_N_HOST_TIMES] = {};
+    uint64_t    up_bytes = 0;                    /* bytes of work lists sent over PCIe since the last reset */
     int16_t    *up_tmp = nullptr;        /* intermediate rows of oh_pic_upsample */
     size_t      up_tmp_elems = 0;
     uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
@@ -118,7 +123,41 @@ struct OhEngine {
     } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct HostTimer {                       /* adds the scope's wall time to one slot of OhEngine::host_ms */
+    OhEngine *e; int slot; std::chrono::steady_clock::time_point t0;
+    HostTimer(OhEngine *e_, int slot_);
+    ~HostTimer();
+};
 enum { OH_MAX_STAGES = 48, OH_SUMMARY_BLOCK = 32768 };             /* pinned staging buffers per engine before the host is made to wait */
+
+HostTimer::HostTimer(OhEngine *e_, int slot_) : e(e_), slot(slot_), t0(std::chrono::steady_clock::now()) {}
+HostTimer::~HostTimer()
+{
+    e->host_ms[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    e->host_calls[slot]++;
+}
+
+extern "C" uint64_t oh_engine_upload_bytes(OhEngine *e, int reset)
+{
+    if (!e)
+        return 0;
+    const uint64_t v = e->up_bytes;
+    if (reset) e->up_bytes = 0;
+    return v;
+}
+
+extern "C" int oh_engine_host_times(OhEngine *e, double *ms, uint64_t *calls, int n, int reset)
+{
+    if (!e || n < 0)
+        return OH_E_ARG;
+    for (int i = 0; i < n && i < OH_N_HOST_TIMES; i++) {
+        if (ms) ms[i] = e->host_ms[i];
+        if (calls) calls[i] = e->host_calls[i];
+    }
+    if (reset)
+        for (int i = 0; i < OH_N_HOST_TIMES; i++) { e->host_ms[i] = 0; e->host_calls[i] = 0; }
+    return OH_OK;
+}
 
 static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_ext)
 {
@@ -202,7 +241,7 @@ static void free_dev_frame(OhEngine *e, OhDevFrame *df, bool in_flight = false)
         else (void)hipHostFree(df->sum_host);
     }
     if (df->arena) {
-        if (e && e->arenas.size() < 256) {
+        if (e && e->arenas.size() < 1024) {
             hipEvent_t fe = nullptr;
             if (in_flight && (fe = sync_event_get(e)) != nullptr && hipEventRecord(fe, e->stream) != hipSuccess) {
                 sync_event_put(e, fe);
@@ -591,7 +630,7 @@ static bool same_geometry(const OhPicParams &a, const OhPicParams &b)
  * reported by the first oh_frame(s)_execute that includes it (OH_E_ARG, before any of its passes is launched).
  * ------------------------------------------------------------------------------------------------------------------- */
 static int check_host_side(OhEngine *e, const OhFrame *f, const Pic *cur, OhPrepCounts *cnt, uint32_t tu_cnt[4], uint32_t *n_cross,
-                           bool *any_dense, uint16_t *ref_used, uint32_t *ref_ok)
+                           bool *any_dense, uint16_t *ref_used, uint32_t *ref_ok, std::vector<uint32_t> &pu_off)
 {
     const OhPicParams &p = f->p;
     *ref_ok = 0; *ref_used = 0; *n_cross = 0; *any_dense = false;
@@ -605,15 +644,19 @@ static int check_host_side(OhEngine *e, const OhFrame *f, const Pic *cur, OhPrep
     /* blocks per PU: sizes the MC block lists (prep_pu_scan repeats the sums on the GPU and validates every PU) */
     uint64_t nl = 0, nc = 0;
     const int hs = oh_hshift(&p, 1), vs = oh_vshift(&p, 1), two = p.chroma_format_idc ? 2 : 0;
+    if ((uint64_t)f->n_pu * 2048 >= (1ull << 31))
+        FAIL(e, OH_E_ARG, "PU list too long");
+    pu_off.resize(2 * ((size_t)f->n_pu + 1));
+    uint32_t *ol = pu_off.data(), *oc = ol + f->n_pu + 1;       /* running sums: where every PU's blocks start in the two lists */
     for (uint32_t i = 0; i < f->n_pu; i++) {
         const OhPu &pu = f->pu[i];
+        ol[i] = (uint32_t)nl; oc[i] = (uint32_t)nc;
         nl += (uint64_t)(((pu.w + 7) >> 3) * ((pu.h + 7) >> 3));
         nc += (uint64_t)(two * ((((pu.w >> hs) + 7) >> 3) * (((pu.h >> vs) + 7) >> 3)));
         for (int l = 0; l < 2; l++)
             if (pu.ref[l] < OH_MAX_REFS) *ref_used |= (uint16_t)(1u << pu.ref[l]);
     }
-    if (nl >= (1ull << 31) || nc >= (1ull << 31))
-        FAIL(e, OH_E_ARG, "PU list implies %llu + %llu prediction blocks", (unsigned long long)nl, (unsigned long long)nc);
+    ol[f->n_pu] = (uint32_t)nl; oc[f->n_pu] = (uint32_t)nc;
     for (uint32_t i = 0; i < f->n_wp; i++)
         if (f->wp[i].log2_denom[0] > 7 || f->wp[i].log2_denom[1] > 7)
             FAIL(e, OH_E_ARG, "weights %u: log2 denominator out of range", i);
@@ -671,10 +714,9 @@ static void *summary_block_get(OhEngine *e, size_t bytes, bool *pooled)
     return hipHostMalloc(&p, *pooled ? (size_t)OH_SUMMARY_BLOCK : bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
 }
 
-extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
+/* the host part of one hand-over and its H2D copy; finish_uploads() enqueues the preparation kernels behind it */
+static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
 {
-    if (!e || !f || !out)
-        return OH_E_ARG;
     *out = nullptr;
     int rc = check_params(e, &f->p);
     if (rc)
@@ -689,7 +731,11 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     uint32_t tu_cnt[4], n_cross = 0, ref_ok = 0;
     uint16_t ref_used = 0;
     bool any_dense = false;
-    rc = check_host_side(e, f, cur, &cnt, tu_cnt, &n_cross, &any_dense, &ref_used, &ref_ok);
+    static thread_local std::vector<uint32_t> pu_off;
+    HostTimer t_all(e, OH_HT_UPLOAD);
+    { HostTimer t(e, OH_HT_UPLOAD_COUNT);
+    rc = check_host_side(e, f, cur, &cnt, tu_cnt, &n_cross, &any_dense, &ref_used, &ref_ok, pu_off);
+    }
     if (rc)
         return rc;
     auto t_valid = tnow();
@@ -715,6 +761,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     memset(&hd, 0, sizeof(hd));
     int s_hdr = add(&hd, sizeof(DevFrame));
     int s_pu = add(f->pu, (size_t)f->n_pu * sizeof(OhPu));
+    int s_puoff = add(pu_off.data(), 2 * ((size_t)f->n_pu + 1) * sizeof(uint32_t));
     int s_wp = add(f->wp, (size_t)f->n_wp * sizeof(OhWeights));
     int s_tur = add(f->tu, (size_t)f->n_tu * sizeof(OhTu));
     int s_tusp = add(f->tu_sparse, f->tu_sparse ? (size_t)f->n_tu * sizeof(uint32_t) : 0);
@@ -753,7 +800,7 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     const size_t zero_bytes = total - zero_off;
     int s_mcl = add(nullptr, (size_t)cnt.n_mc_luma * sizeof(DevMcJob));
     int s_mcc = add(nullptr, (size_t)cnt.n_mc_chroma * sizeof(DevMcJob));
-    int s_puoff = add(nullptr, 2 * ((size_t)f->n_pu + 1) * sizeof(uint32_t));
+    int s_aux = add(nullptr, (size_t)cnt.n_ictu * sizeof(uint32_t));
     int s_tu = add(nullptr, (size_t)f->n_tu * sizeof(DevTu));
     int s_cross = add(nullptr, (size_t)n_cross * sizeof(DevCross));
     int s_intra = add(nullptr, (size_t)f->n_intra * sizeof(DevIntra));
@@ -769,12 +816,17 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
 
     auto t_lists = tnow();
     OhDevFrame *df = new OhDevFrame();
-    {   /* smallest pooled arena that fits (within 2x), else a new one rounded up to 1 MiB */
+    {   /* a pooled arena that fits (within 2x), else a new one rounded up to 1 MiB */
+        HostTimer t(e, OH_HT_UPLOAD_ARENA);
+        /* oldest first (the pool is in release order): an arena released long ago has no pass left that reads it, so the copy
+         * need not wait for the engine stream; the most recently released one would stall the copy stream behind the passes
+         * of the batch that just let go of it */
         int best = -1;
-        for (size_t i = 0; i < e->arenas.size(); i++)
-            if (e->arenas[i].bytes >= total && e->arenas[i].bytes <= 2 * total + (1u << 20) &&
-                (best < 0 || e->arenas[i].bytes < e->arenas[best].bytes))
+        for (size_t i = 0; i < e->arenas.size() && best < 0; i++)
+            if (e->arenas[i].bytes >= total && e->arenas[i].bytes <= 2 * total + (1u << 20))
                 best = (int)i;
+        if (best >= 0 && e->arenas[best].free_ev && hipEventQuery(e->arenas[best].free_ev) != hipSuccess && e->arenas.size() < 512)
+            best = -1;                                      /* even the oldest fit is still in flight: a new arena beats a stall */
         if (best >= 0) {
             df->arena = e->arenas[best].p; df->arena_bytes = e->arenas[best].bytes;
             if (e->arenas[best].free_ev) {                  /* released while passes were in flight: the copy must stay behind them */
@@ -835,40 +887,45 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.is_pcm = f->is_pcm ? AT(const uint8_t *, s_pcm) : nullptr;
     hd.db = AT(const OhDeblockCtb *, s_db);
     hd.sao = has_sao ? AT(const OhSaoCtb *, s_sao) : nullptr;
-    hd.pu_off = AT(uint32_t *, s_puoff); hd.tu_keep = AT(uint8_t *, s_keep); hd.tu_cursor = AT(uint32_t *, s_cursor);
+    hd.pu_off = AT(const uint32_t *, s_puoff); hd.ctu_aux = AT(uint32_t *, s_aux); hd.tu_keep = AT(uint8_t *, s_keep); hd.tu_cursor = AT(uint32_t *, s_cursor);
     hd.intra_perm = AT(uint32_t *, s_perm); hd.ctu_seen = AT(uint32_t *, s_seen); hd.summary = AT(void *, s_sum);
 #undef AT
     hd.n_pu = f->n_pu; hd.n_mc_luma = cnt.n_mc_luma; hd.n_mc_chroma = cnt.n_mc_chroma; hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
     hd.n_ictu = cnt.n_ictu; hd.n_sub = cnt.n_sub; hd.n_levels = cnt.n_levels; hd.n_wp = f->n_wp; hd.n_sparse = f->sparse ? f->n_sparse : 0;
     hd.ref_ok = ref_ok; hd.n_coeff = f->n_coeff;
+    hd.n_cross = n_cross;
+    hd.zero_ptr = (uint32_t *)(base + zero_off); hd.zero_words = (uint32_t)(zero_bytes / 4);
+    for (int k = 0, first = 0; k < 4; k++) { hd.tu_first[k] = (uint32_t)first; hd.tu_cnt[k] = tu_cnt[k]; first += (int)tu_cnt[k]; }
     hd.dbg = e->dbg;
     (void)s_hdr;
 
     /* stage everything in one host buffer -> one H2D copy */
     auto t_alloc = tnow();
-    OhEngine::Stage *sg = stage_acquire(e, copy_bytes);   /* a pinned buffer whose previous copy has completed */
+    OhEngine::Stage *sg;
+    { HostTimer t(e, OH_HT_UPLOAD_STAGE_WAIT);
+    sg = stage_acquire(e, copy_bytes);   /* a pinned buffer whose previous copy has completed */
+    }
     df->sum_host = summary_block_get(e, sum_bytes, &df->sum_pooled);
     df->sum_bytes = sum_bytes;
+    hd.summary_host = df->sum_host;                        /* pinned, device-accessible: prep_finish stores the summary there */
     if (!sg || !df->sum_host) {
         free_dev_frame(e, df);
         FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
     }
     void *stage = sg->p;
+    { HostTimer t(e, OH_HT_UPLOAD_MEMCPY);
     for (int i = 0; i < ns; i++)
         if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
             memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
+    }
     /* asynchronous: the caller's arrays are already copied out; the pinned buffer stays busy until `done` */
+    HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
     hipStream_t cs = e->copy_stream;
     hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, cs);
     if (hrc == hipSuccess)
         hrc = hipEventRecord(sg->done, cs);
     sg->busy = hrc == hipSuccess;
-    if (hrc == hipSuccess)
-        hrc = hipMemsetAsync(base + zero_off, 0, zero_bytes, cs);
-    if (hrc == hipSuccess) {
-        ohk_prepare((const DevFrame *)base, &cnt, cs);
-        hrc = hipGetLastError();
-    }
+    e->up_bytes += copy_bytes;
     if (hrc == hipSuccess && bsi) {                        /* both grids from the maps: once per work list, the maps never change */
         hrc = hipMemsetAsync(base + seg[s_vbs].off, 0, bs_bytes, cs);                        /* the padded tail is read by the deblock pass */
         if (hrc == hipSuccess) hrc = hipMemsetAsync(base + seg[s_hbs].off, 0, bs_bytes, cs);
@@ -876,12 +933,8 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             ohk_bs_derive(&p, base + seg[s_mvf].off, base + seg[s_cbf].off, base + seg[s_call].off, base + seg[s_bsf].off, bsi->loop_filter_across_tiles,
                           base + seg[s_vbs].off, base + seg[s_hbs].off, cs);
     }
-    if (hrc == hipSuccess)
-        hrc = hipMemcpyAsync(df->sum_host, base + seg[s_sum].off, sum_bytes, hipMemcpyDeviceToHost, cs);
-    if (hrc == hipSuccess && (df->ready = sync_event_get(e)) == nullptr)
-        hrc = hipErrorOutOfMemory;
-    if (hrc == hipSuccess)
-        hrc = hipEventRecord(df->ready, cs);
+    df->sum_dev = base + seg[s_sum].off;
+    df->cnt = cnt;
     if (hrc != hipSuccess) {
         (void)hipStreamSynchronize(cs);
         free_dev_frame(e, df);
@@ -906,12 +959,74 @@ extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     return OH_OK;
 }
 
+/* preparation kernels of n freshly copied work lists (one set of launches per 32 of them: the kernels pick the list with a grid
+ * dimension, like the passes), their summaries back to pinned memory, their `ready` events */
+static int finish_uploads(OhEngine *e, OhDevFrame *const *dfs, int n)
+{
+    HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
+    hipStream_t cs = e->copy_stream;
+    for (int c0 = 0; c0 < n; c0 += OH_MAX_BATCH) {
+        const int nb = n - c0 < OH_MAX_BATCH ? n - c0 : OH_MAX_BATCH;
+        OhBatch B;
+        memset(&B, 0, sizeof(B));
+        OhPrepCounts mx;
+        memset(&mx, 0, sizeof(mx));
+        uint32_t max_cross = 0, max_runs = 0;
+        for (int i = 0; i < nb; i++) {
+            const OhDevFrame *df = dfs[c0 + i];
+            B.f[i] = df->d;
+            mx.n_pu = std::max(mx.n_pu, df->cnt.n_pu); mx.n_tu = std::max(mx.n_tu, df->cnt.n_tu);
+            mx.n_intra = std::max(mx.n_intra, df->cnt.n_intra); mx.n_sub = std::max(mx.n_sub, df->cnt.n_sub);
+            mx.n_ictu = std::max(mx.n_ictu, df->cnt.n_ictu); mx.n_levels = std::max(mx.n_levels, df->cnt.n_levels);
+            max_runs = std::max(max_runs, ((df->cnt.n_mc_luma + 63) >> 6) + ((df->cnt.n_mc_chroma + 63) >> 6));
+            max_cross = std::max(max_cross, df->n_cross);
+        }
+        ohk_prepare(&B, nb, &mx, max_runs, max_cross, cs);
+        HIPCHK(e, hipGetLastError());
+    }
+    /* one point in the copy stream makes all of them ready: an event per list, recorded back to back */
+    for (int i = 0; i < n; i++) {
+        OhDevFrame *df = dfs[i];
+        if ((df->ready = sync_event_get(e)) == nullptr)
+            FAIL(e, OH_E_NOMEM, "no event for the work list");
+        HIPCHK(e, hipEventRecord(df->ready, cs));
+    }
+    return OH_OK;
+}
+
+extern "C" int oh_frames_upload(OhEngine *e, const OhFrame *const *fs, int n, OhDevFrame **out)
+{
+    if (!e || n < 0 || (n && (!fs || !out)))
+        return OH_E_ARG;
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    int rc = OH_OK;
+    int done = 0;
+    for (; done < n && rc == OH_OK; done++)
+        rc = fs[done] ? upload_one(e, fs[done], &out[done]) : OH_E_ARG;
+    if (rc == OH_OK)
+        rc = finish_uploads(e, out, n);
+    if (rc != OH_OK) {                                     /* all or nothing */
+        (void)hipStreamSynchronize(e->copy_stream);
+        for (int i = 0; i < n; i++) { free_dev_frame(e, out[i]); out[i] = nullptr; }
+    }
+    return rc;
+}
+
+extern "C" int oh_frame_upload(OhEngine *e, const OhFrame *f, OhDevFrame **out)
+{
+    if (!e || !f || !out)
+        return OH_E_ARG;
+    return oh_frames_upload(e, &f, 1, out);
+}
+
 /* the summary the preparation kernels left (prep.hip): waits for the list's `ready` event the first time */
 static int read_summary(OhEngine *e, OhDevFrame *df, int index)
 {
     if (df->summary_read)
         return df->prep_err ? OH_E_ARG : OH_OK;
+    { HostTimer t(e, OH_HT_EXECUTE_WAIT_PREP);
     HIPCHK(e, hipEventSynchronize(df->ready));
+    }
     const DevSummary *s = (const DevSummary *)df->sum_host;
     df->summary_read = true;
     df->prep_err = s->err;
@@ -942,6 +1057,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
         return OH_E_ARG;
     if (n == 0)
         return OH_OK;                                       /* an empty batch is a no-op */
+    HostTimer t_all(e, OH_HT_EXECUTE);
     HIPCHK(e, hipSetDevice(e->device));
     for (int i = 0; i < n; i++) {
         if (!dfs[i])
@@ -1158,6 +1274,7 @@ extern "C" int oh_frame_release(OhEngine *e, OhDevFrame *df)
         return OH_E_ARG;
     if (df->owner != e)
         FAIL(e, OH_E_ARG, "oh_frame_release: work list of another engine");
+    HostTimer t_all(e, OH_HT_RELEASE);
     HIPCHK(e, hipSetDevice(e->device));
     if (!df->waited && df->ready)
         HIPCHK(e, hipStreamWaitEvent(e->stream, df->ready, 0));      /* never executed: the release still has to stay behind its copy */

@@ -5,15 +5,14 @@
  * sample values, so it overlaps the passes of earlier pictures.
  *
  *   raw list                   kernel                 product (dev_frame.h)
- *   OhPu[]                     prep_pu_scan           job offsets per PU (exclusive scan; one workgroup per picture)
- *                              prep_pu_expand         DevMcJob lists: every plane rectangle of a PU cut into <= 8x8 blocks
+ *   OhPu[] (+ the host's running block counts)  prep_pu_expand   DevMcJob lists: every plane rectangle of a PU cut into <= 8x8 blocks
  *                              prep_mc_group          bi-predicted blocks first inside every run of 64 (a wave runs the second
  *                                                     list when any of its four blocks has one)
- *   OhTu[], tu_sparse, tu_cross prep_tu_count / _scatter  DevTu buckets by transform size, DevCross list, KEEP_RES marks
+ *   OhTu[], tu_sparse, tu_cross prep_tu_mark / _scatter  DevTu buckets by transform size, DevCross list, KEEP_RES marks
  *   OhIntra[], sub_start       prep_intra_sub         <= 8x8 blocks first inside a sub-level (four of them share a wave)
  *                              prep_intra_items       DevIntra: LDS offsets, edge sizes, filter / class flags, angles, the
  *                                                     constrained-intra masks (hevcpred_template.c:116-163)
- *   OhIntraCtu[], level_start  prep_intra_levels      DevIntraCtu (residual span, staged rectangle) and the per-level launch
+ *   OhIntraCtu[], level_start  prep_intra_ctu / _levels  DevIntraCtu (residual span, staged rectangle); the per-level launch
  *                                                     statistics the host sizes the intra launches with (DevSummary)
  *
  * Every index a pass kernel will follow is checked HERE (what engine.hip's host loop used to do): the first violation is
@@ -30,6 +29,15 @@ static __device__ __noinline__ void fail(const DevFrame *f, uint32_t code, uint3
     DevSummary *s = summary_of(f);
     if (atomicCAS(&s->err, 0u, code) == 0u)
         s->err_item = item;
+}
+
+/* cursors, marks and the summary start from zero (one launch for the whole batch instead of a fill per list between the copies) */
+__global__ __launch_bounds__(256) void prep_clear(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    GLOBAL uint4v *z = (GLOBAL uint4v *)f->zero_ptr;           /* 256-byte aligned, a multiple of 256 bytes long */
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < f->zero_words / 4; i += gridDim.x * blockDim.x)
+        z[i] = uint4v{ 0, 0, 0, 0 };
 }
 
 /* ---------------------------------------------------------------- prediction units ---- */
@@ -52,48 +60,6 @@ static __device__ __forceinline__ void pu_jobs(const DevFrame *f, const OhPu &pu
     const int hs = hsh(p, 1), vs = vsh(p, 1);
     nl = (uint32_t)(((pu.w + 7) >> 3) * ((pu.h + 7) >> 3));
     nc = p.chroma_format_idc ? 2u * (uint32_t)((((pu.w >> hs) + 7) >> 3) * (((pu.h >> vs) + 7) >> 3)) : 0u;
-}
-
-/* exclusive scan of the per-PU block counts: one workgroup per picture walks the list in chunks of its size */
-__global__ __launch_bounds__(1024) void prep_pu_scan(const OhBatch B)
-{
-    const DevFrame *__restrict__ f = B.f[blockIdx.x];
-    if (failed(f))
-        return;
-    __shared__ uint32_t wsum[2][16], carry[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    if (tid < 2) carry[tid] = 0;
-    __syncthreads();
-    uint32_t *__restrict__ offl = f->pu_off, *__restrict__ offc = f->pu_off + (f->n_pu + 1);
-    for (uint32_t base = 0; base < f->n_pu; base += blockDim.x) {
-        const uint32_t i = base + tid;
-        uint32_t nl = 0, nc = 0;
-        if (i < f->n_pu) {
-            const OhPu pu = gload(f->pu + i);
-            if (pu_ok(f, pu)) pu_jobs(f, pu, nl, nc);
-            else fail(f, OH_PE_PU, i);
-        }
-        uint32_t sl = nl, sc = nc;                              /* inclusive scan inside the wave */
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t a = __shfl_up(sl, d), b = __shfl_up(sc, d);
-            if (lane >= d) { sl += a; sc += b; }
-        }
-        if (lane == 63) { wsum[0][wave] = sl; wsum[1][wave] = sc; }
-        __syncthreads();
-        uint32_t bl = carry[0], bc = carry[1];
-        for (int w = 0; w < wave; w++) { bl += wsum[0][w]; bc += wsum[1][w]; }
-        if (i < f->n_pu) { offl[i] = bl + sl - nl; offc[i] = bc + sc - nc; }
-        __syncthreads();
-        if (tid == blockDim.x - 1) { carry[0] = bl + sl; carry[1] = bc + sc; }
-        (void)nw;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        offl[f->n_pu] = carry[0]; offc[f->n_pu] = carry[1];
-        if (carry[0] != f->n_mc_luma || carry[1] != f->n_mc_chroma)       /* the host sized the lists with the same arithmetic */
-            fail(f, OH_PE_PU, f->n_pu);
-    }
 }
 
 /* one plane's rectangle of a PU cut into the <= 8x8 blocks the MC kernel works on; a DevMcJob is written as its five dwords
@@ -126,6 +92,15 @@ __global__ __launch_bounds__(256) void prep_pu_expand(const OhBatch B)
         return;
     const OhPu pu = gload(f->pu + i);
     const OhPicParams &p = f->pp;
+    /* the host counted the blocks of every PU with pu_jobs()' arithmetic while sizing the lists and hands the running sums
+     * over (pu_off): a PU writes inside its own range whatever its fields hold, and an invalid one writes nothing */
+    uint32_t nl, nc;
+    pu_jobs(f, pu, nl, nc);
+    if (!pu_ok(f, pu) || f->pu_off[i + 1] - f->pu_off[i] != nl || f->pu_off[f->n_pu + 2 + i] - f->pu_off[f->n_pu + 1 + i] != nc ||
+        f->pu_off[i + 1] > f->n_mc_luma || f->pu_off[f->n_pu + 2 + i] > f->n_mc_chroma) {
+        fail(f, OH_PE_PU, i);
+        return;
+    }
     emit_jobs((DevMcJob *)f->mc_luma, f->pu_off[i], pu, 0, 0, 0);
     if (p.chroma_format_idc) {
         uint32_t o = f->pu_off[f->n_pu + 1 + i];
@@ -168,7 +143,8 @@ __global__ __launch_bounds__(64) void prep_mc_group(const OhBatch B)
 }
 
 /* ---------------------------------------------------------------- transform blocks ---- */
-static __device__ __forceinline__ bool tu_ok(const DevFrame *f, const OhTu &t, uint32_t i)
+/* everything about one transform block except the positions inside its sparse record (sparse_ok_*) */
+static __device__ __forceinline__ bool tu_ok(const DevFrame *f, const OhTu &t, uint32_t i, uint32_t *rec_first = nullptr, uint32_t *rec_cnt = nullptr)
 {
     const OhPicParams &p = f->pp;
     const int nplanes = p.chroma_format_idc ? 3 : 1;
@@ -198,90 +174,103 @@ static __device__ __forceinline__ bool tu_ok(const DevFrame *f, const OhTu &t, u
         const uint32_t w0 = f->sparse[so], cnt = w0 & 0xffff, qp = (w0 >> 16) & 0xff, mid = w0 >> 24;
         if (cnt > (uint32_t)(n * n) || so + 1 + cnt > f->n_sparse || qp > 75 || (mid != OH_FLAT_MATRIX && (mid > 5 || !f->scaling)))
             return false;
-        for (uint32_t k = 0; k < cnt; k++)
-            if ((f->sparse[so + 1 + k] & 0xffff) >= (uint32_t)(n * n))
-                return false;
+        if (rec_first) { *rec_first = (uint32_t)so + 1; *rec_cnt = cnt; }
     } else if (!f->coeffs_present) {
         return false;                                               /* dense block, but no pool came with the list */
     }
     return true;
 }
 
-/* pass 1 over the list: validation, the per-size counts (one atomic per wave and size), the luma blocks cross-component blocks read */
-__global__ __launch_bounds__(256) void prep_tu_count(const OhBatch B)
+/* only for pictures with cross-component prediction (4:4:4 range extension): the luma blocks those chroma blocks read keep
+ * their residual — marked before the buckets are written */
+__global__ __launch_bounds__(256) void prep_tu_mark(const OhBatch B)
 {
     const DevFrame *__restrict__ f = B.f[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (failed(f))
+    if (i >= f->n_tu || failed(f))
         return;
-    const bool live = i < f->n_tu;
-    int k = -1;
-    if (live) {
-        const OhTu t = gload(f->tu_raw + i);
-        if (tu_ok(f, t, i)) {
-            k = t.log2_size - 2;
-            if (t.flags & OH_TUF_CROSS) {
-                ((uint8_t *)f->tu_keep)[f->tu_cross[i] & 0xffffff] = 1;
-                atomicAdd(&f->tu_cursor[8], 1u);
-            }
-        } else {
-            fail(f, OH_PE_TU, i);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(k == s);
-        if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m))
-            atomicAdd(&f->tu_cursor[s], (uint32_t)__builtin_popcountll(m));
-    }
+    const OhTu t = gload(f->tu_raw + i);
+    if (!(t.flags & OH_TUF_CROSS))
+        return;
+    if (tu_ok(f, t, i)) ((uint8_t *)f->tu_keep)[f->tu_cross[i] & 0xffffff] = 1;
+    else fail(f, OH_PE_TU, i);
 }
 
-/* pass 2: every block goes to its size bucket (a wave's blocks of one size stay together and in order) */
+/* every block is validated and goes to its size bucket.  The bucket ranges are known (the host counted the sizes while it
+ * looked for dense blocks; prep_finish compares); a workgroup reserves its share of each bucket with ONE atomic per size, its
+ * waves take theirs in order, so blocks stay in list order inside a workgroup's share. */
 __global__ __launch_bounds__(256) void prep_tu_scatter(const OhBatch B)
 {
     const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    __shared__ uint32_t wcnt[4][4], wbase[4];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (failed(f))
-        return;
-    const bool live = i < f->n_tu;
+    const bool live = i < f->n_tu && !failed(f);               /* no early return: every wave reaches the two barriers */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     OhTu t;
     int k = -1;
-    if (live) { t = gload(f->tu_raw + i); k = t.log2_size - 2; }
-    uint32_t first[4] = { 0, 0, 0, 0 };
-    for (int s = 1; s < 4; s++) first[s] = first[s - 1] + f->tu_cursor[s - 1];
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t rec = 0, cnt = 0;
+    if (live) {
+        t = gload(f->tu_raw + i);
+        if (tu_ok(f, t, i, &rec, &cnt)) k = t.log2_size - 2;
+        else fail(f, OH_PE_TU, i);
+    }
+    /* positions of the sparse records (every one must lie inside its block: residual_kernel scatters to them).  A lane checks a
+     * short record itself, loads issued back to back; the long ones (up to n * n entries) are taken by the whole wave, one at a time */
+    {
+        const GLOBAL uint32_t *__restrict__ sp = G_CONST(uint32_t, f->sparse);
+        const uint32_t n2 = k >= 0 ? 16u << (2 * k) : 0u;
+        uint32_t bad = 0;
+        if (k >= 0 && cnt <= 16)
+            for (uint32_t q = 0; q < cnt; q++) bad |= (sp[rec + q] & 0xffff) >= n2;
+        unsigned long long big = __builtin_amdgcn_ballot_w64(k >= 0 && cnt > 16);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t r0 = __shfl(rec, src), rc = __shfl(cnt, src), rn2 = __shfl(n2, src);
+            uint32_t b = 0;
+            for (uint32_t q = lane; q < rc; q += 64) b |= (sp[r0 + q] & 0xffff) >= rn2;
+            if (__builtin_amdgcn_ballot_w64(b != 0) && lane == src) bad = 1;
+        }
+        if (bad) { fail(f, OH_PE_TU, i); k = -1; }
+    }
+    unsigned long long m[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(k == s);
-        if (!m)
-            continue;
-        uint32_t base = 0;
-        const int leader = __builtin_ctzll(m);
-        if (lane == leader)
-            base = atomicAdd(&f->tu_cursor[4 + s], (uint32_t)__builtin_popcountll(m));
-        base = __shfl(base, leader);
-        if (k == s) {
-            alignas(16) DevTu d;
-            d.t = t;
-            if (f->tu_keep[i]) d.t.flags |= OH_TUF_KEEP_RES;
-            d.sparse_off = (t.flags & OH_TUF_SPARSE) ? f->tu_sparse[i] : OH_NO_COEFF;
-            GLOBAL uint4v *o = (GLOBAL uint4v *)((DevTu *)f->tu + first[s] + base + (uint32_t)__builtin_popcountll(m & below));
-            uint4v q;
-            __builtin_memcpy(&q, &d, 16);
-            *o = q;
-        }
+        m[s] = __builtin_amdgcn_ballot_w64(k == s);
+        if (lane == 0) wcnt[s][wave] = (uint32_t)__builtin_popcountll(m[s]);
     }
-    if (live && (t.flags & OH_TUF_CROSS)) {
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint32_t tot = 0;
+        for (int w = 0; w < nw; w++) tot += wcnt[threadIdx.x][w];
+        wbase[threadIdx.x] = tot ? atomicAdd(&f->tu_cursor[threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+    if (k < 0)
+        return;
+    uint32_t pos = f->tu_first[k] + wbase[k];
+    for (int w = 0; w < wave; w++) pos += wcnt[k][w];
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const unsigned long long mk = k == 0 ? m[0] : k == 1 ? m[1] : k == 2 ? m[2] : m[3];
+    pos += (uint32_t)__builtin_popcountll(mk & below);
+    if (pos >= f->n_tu) { fail(f, OH_PE_TU, i); return; }                     /* more blocks of a size than the host counted */
+    alignas(16) DevTu d;
+    d.t = t;
+    if (f->tu_keep[i]) d.t.flags |= OH_TUF_KEEP_RES;
+    d.sparse_off = (t.flags & OH_TUF_SPARSE) ? f->tu_sparse[i] : OH_NO_COEFF;
+    uint4v q;
+    __builtin_memcpy(&q, &d, 16);
+    *(GLOBAL uint4v *)((DevTu *)f->tu + pos) = q;
+    if (t.flags & OH_TUF_CROSS) {
         /* cross-component prediction: the chroma block is finished by cross_kernel once every inverse transform of the picture is done */
         const uint32_t cw = f->tu_cross[i];
         const OhTu ty = gload(f->tu_raw + (cw & 0xffffff));
-        alignas(16) DevCross d;
-        d.x = t.x; d.y = t.y; d.c_idx = t.c_idx; d.log2_size = t.log2_size; d.flags = t.flags;
-        d.scale = (int8_t)(cw >> 24); d.res_c = t.coeff_off; d.res_y = ty.coeff_off;
+        alignas(16) DevCross dc;
+        dc.x = t.x; dc.y = t.y; dc.c_idx = t.c_idx; dc.log2_size = t.log2_size; dc.flags = t.flags;
+        dc.scale = (int8_t)(cw >> 24); dc.res_c = t.coeff_off; dc.res_y = ty.coeff_off;
         const uint32_t o = atomicAdd(&f->tu_cursor[9], 1u);
-        uint4v q;
-        __builtin_memcpy(&q, &d, 16);
+        if (o >= f->n_cross) { fail(f, OH_PE_TU, i); return; }
+        __builtin_memcpy(&q, &dc, 16);
         *(GLOBAL uint4v *)((DevCross *)f->cross + o) = q;
     }
 }
@@ -418,79 +407,103 @@ __global__ __launch_bounds__(256) void prep_intra_items(const OhBatch B)
     o[0] = q[0]; o[1] = q[1];
 }
 
-/* One workgroup per wavefront level, one lane per CTU of it: the CTU's entry of the schedule is checked (the level ->
- * ictu[] -> sub_start[] -> intra[] nesting the intra kernel follows blindly), its residual span and staged rectangle
- * are derived, and the level's launch statistics are reduced into the summary. */
+/* One wave per entry of the schedule (a CTU that holds intra blocks): the entry is checked (the level -> ictu[] -> sub_start[]
+ * -> intra[] nesting the intra kernel follows blindly), its residual span and the rectangle to stage are reduced over its
+ * blocks, lanes taking the blocks in turn; ctu_aux[k] keeps what the level statistics need of it. */
+__global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t k = blockIdx.x;
+    if (k >= f->n_ictu || failed(f))
+        return;
+    const OhPicParams &p = f->pp;
+    const int lane = threadIdx.x;
+    const int lc = p.log2_ctb_size, ctbw = (p.width + (1 << lc) - 1) >> lc, ctbh = (p.height + (1 << lc) - 1) >> lc;
+    DevIntra *__restrict__ di = (DevIntra *)f->intra;
+    const OhIntraCtu c = gload(f->ictu_raw + k);
+    uint32_t expect = 0;
+    if (k) { const OhIntraCtu pc = gload(f->ictu_raw + k - 1); expect = pc.sub_first + pc.n_sub; }
+    if (c.sub_first != expect || !c.n_sub || (uint64_t)c.sub_first + c.n_sub > f->n_sub || (k + 1 == f->n_ictu && c.sub_first + c.n_sub != f->n_sub) ||
+        c.ctu >= (uint32_t)(ctbw * ctbh) || c.n_sub > OH_MAX_CTU_BLOCKS) { if (!lane) fail(f, OH_PE_INTRA_TABLES, k); return; }
+    const uint32_t b0 = f->sub_start[c.sub_first], b1 = f->sub_start[c.sub_first + c.n_sub];
+    if (b1 < b0 || b1 - b0 > OH_MAX_CTU_BLOCKS) { if (!lane) fail(f, OH_PE_INTRA_TABLES, k); return; }
+    if (!lane && atomicExch(&f->ctu_seen[c.ctu], 1u) != 0u) fail(f, OH_PE_INTRA_TABLES, k);      /* a CTU heads ONE entry: its level is one number */
+    unsigned long long lo = ~0ull, hi = 0;
+    int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
+    int any_res = 0, bad = 0;
+    for (uint32_t b = b0 + lane; b < b1; b += 64) {
+        const uint4v q0 = *(const GLOBAL uint4v *)(di + b);
+        const int x = q0[0] & 0xffff, y = q0[0] >> 16, ci = q0[1] & 0xff, log2 = (q0[1] >> 8) & 0xff, n = 1 << log2;
+        const uint32_t res_off = q0[2];
+        const int hs = hsh(p, ci), vs = vsh(p, ci);
+        if ((uint32_t)((((y << vs) >> lc) * ctbw) + ((x << hs) >> lc)) != c.ctu) bad = 1;       /* the CTU is written back from c.ctu's origin */
+        const int lx = x - ((((x << hs) >> lc) << lc) >> hs), ly = y - ((((y << vs) >> lc) << lc) >> vs);
+        bx0 = min(bx0, (lx - 1) * (1 << hs)); bx1 = max(bx1, (lx + 2 * n) << hs);
+        by0 = min(by0, (ly - 1) * (1 << vs)); by1 = max(by1, (ly + 2 * n) << vs);
+        if (res_off == OH_NO_COEFF)
+            continue;
+        any_res = 1;
+        lo = min(lo, (unsigned long long)res_off); hi = max(hi, (unsigned long long)res_off + (1u << (2 * log2)));
+    }
+    uint32_t slot_passes = 0;                                  /* wave passes of the CTU: groups of four <= 8x8 blocks + the bigger blocks */
+    for (uint32_t j = c.sub_first + lane; j < c.sub_first + c.n_sub; j += 64) {
+        const uint32_t sm = f->sub_small_w[j];
+        slot_passes += (sm + 3) / 4 + (f->sub_start[j + 1] - f->sub_start[j] - sm);
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) {
+        lo = min(lo, (unsigned long long)__shfl_xor(lo, d)); hi = max(hi, (unsigned long long)__shfl_xor(hi, d));
+        bx0 = min(bx0, __shfl_xor(bx0, d)); bx1 = max(bx1, __shfl_xor(bx1, d));
+        by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
+        any_res |= __shfl_xor(any_res, d); bad |= __shfl_xor(bad, d);
+        slot_passes += __shfl_xor((int)slot_passes, d);
+    }
+    if (bad) { if (!lane) fail(f, OH_PE_INTRA_TABLES, k); return; }
+    uint32_t res_lo = 0, res_cnt = 0;
+    if (hi > lo && (lo & 3) == 0 && hi - lo <= 3u * 64 * 64) {
+        /* the CTU's residual blocks lie together in the pool (a recorder appends them CTU by CTU): stageable in LDS */
+        res_lo = (uint32_t)lo;
+        res_cnt = (uint32_t)((hi - lo + 3) & ~3ull);
+        if ((unsigned long long)res_lo + res_cnt > f->n_coeff) res_cnt = (uint32_t)(hi - lo) & ~3u;
+    }
+    if (res_cnt)
+        for (uint32_t b = b0 + lane; b < b1; b += 64) {
+            const uint32_t ro = *((const GLOBAL uint32_t *)(di + b) + 2);
+            if (ro != OH_NO_COEFF) *((GLOBAL uint32_t *)(di + b) + 6) = ro - res_lo;       /* DevIntra.res_lds */
+        }
+    if (!lane) {
+        alignas(16) DevIntraCtu d;
+        d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu; d.item0 = b0; d.n_items = b1 - b0;
+        d.res_lo = res_lo; d.res_cnt = res_cnt;
+        d.bx0 = (int16_t)bx0; d.bx1 = (int16_t)bx1; d.by0 = (int16_t)by0; d.by1 = (int16_t)by1;
+        uint4v q[2];
+        static_assert(sizeof(DevIntraCtu) == 32, "DevIntraCtu layout");
+        __builtin_memcpy(q, &d, 32);
+        GLOBAL uint4v *o = (GLOBAL uint4v *)((DevIntraCtu *)f->ictu + k);
+        o[0] = q[0]; o[1] = q[1];
+        f->ctu_aux[k] = slot_passes | (any_res && !res_cnt ? 0x80000000u : 0u);
+    }
+}
+
+/* one wave per wavefront level: the launch statistics of the level, reduced over its CTUs into the summary */
 __global__ __launch_bounds__(64) void prep_intra_levels(const OhBatch B)
 {
     const DevFrame *__restrict__ f = B.f[blockIdx.y];
     const uint32_t l = blockIdx.x;
     if (l >= f->n_levels || failed(f))
         return;
-    const OhPicParams &p = f->pp;
-    const int lc = p.log2_ctb_size, ctbw = (p.width + (1 << lc) - 1) >> lc, ctbh = (p.height + (1 << lc) - 1) >> lc;
     const uint32_t k0 = f->lvl_start[l], k1 = f->lvl_start[l + 1];         /* the host checked the level table (it needs it) */
     uint32_t max_items = 1, max_sub = 1, max_res = 0, staged = 1;
     unsigned long long sum_items = 0, sum_sub = 0;
-    DevIntra *__restrict__ di = (DevIntra *)f->intra;
     for (uint32_t k = k0 + threadIdx.x; k < k1; k += 64) {
-        const OhIntraCtu c = gload(f->ictu_raw + k);
-        const uint32_t expect = k ? gload(f->ictu_raw + k - 1).sub_first + gload(f->ictu_raw + k - 1).n_sub : 0u;
-        if (c.sub_first != expect || !c.n_sub || (uint64_t)c.sub_first + c.n_sub > f->n_sub || (k + 1 == f->n_ictu && c.sub_first + c.n_sub != f->n_sub) ||
-            c.ctu >= (uint32_t)(ctbw * ctbh) || c.n_sub > OH_MAX_CTU_BLOCKS) { fail(f, OH_PE_INTRA_TABLES, k); continue; }
-        const uint32_t b0 = f->sub_start[c.sub_first], b1 = f->sub_start[c.sub_first + c.n_sub];
-        if (b1 - b0 > OH_MAX_CTU_BLOCKS || atomicExch(&f->ctu_seen[c.ctu], 1u) != 0u) { fail(f, OH_PE_INTRA_TABLES, k); continue; }
-        alignas(16) DevIntraCtu d;
-        d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu; d.item0 = b0; d.n_items = b1 - b0;
-        unsigned long long lo = ~0ull, hi = 0;
-        int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
-        bool any_res = false, bad = false;
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint4v q0 = *(const GLOBAL uint4v *)(di + b), q1 = *((const GLOBAL uint4v *)(di + b) + 1);
-            const int x = q0[0] & 0xffff, y = q0[0] >> 16, ci = q0[1] & 0xff, log2 = (q0[1] >> 8) & 0xff, n = 1 << log2;
-            const uint32_t res_off = q0[2];
-            const int hs = hsh(p, ci), vs = vsh(p, ci);
-            if ((uint32_t)((((y << vs) >> lc) * ctbw) + ((x << hs) >> lc)) != c.ctu) bad = true;       /* the CTU is written back from c.ctu's origin */
-            const int lx = x - ((((x << hs) >> lc) << lc) >> hs), ly = y - ((((y << vs) >> lc) << lc) >> vs);
-            bx0 = min(bx0, (lx - 1) * (1 << hs)); bx1 = max(bx1, (lx + 2 * n) << hs);
-            by0 = min(by0, (ly - 1) * (1 << vs)); by1 = max(by1, (ly + 2 * n) << vs);
-            (void)q1;
-            if (res_off == OH_NO_COEFF)
-                continue;
-            any_res = true;
-            const unsigned long long e = (unsigned long long)res_off + (1u << (2 * log2));
-            lo = min(lo, (unsigned long long)res_off); hi = max(hi, e);
-        }
-        if (bad) { fail(f, OH_PE_INTRA_TABLES, k); continue; }
-        d.res_lo = 0; d.res_cnt = 0;
-        d.bx0 = (int16_t)bx0; d.bx1 = (int16_t)bx1; d.by0 = (int16_t)by0; d.by1 = (int16_t)by1;
-        if (hi > lo && (lo & 3) == 0 && hi - lo <= 3u * 64 * 64) {
-            /* the CTU's residual blocks lie together in the pool (a recorder appends them CTU by CTU): stageable in LDS */
-            d.res_lo = (uint32_t)lo;
-            d.res_cnt = (uint32_t)((hi - lo + 3) & ~3ull);
-            if ((unsigned long long)d.res_lo + d.res_cnt > f->n_coeff) d.res_cnt = (uint32_t)(hi - lo) & ~3u;
-        }
-        if (d.res_cnt)
-            for (uint32_t b = b0; b < b1; b++) {
-                const uint32_t ro = *((const GLOBAL uint32_t *)(di + b) + 2);
-                if (ro != OH_NO_COEFF) *((GLOBAL uint32_t *)(di + b) + 6) = ro - d.res_lo;       /* DevIntra.res_lds */
-            }
-        {
-            GLOBAL uint4v *o = (GLOBAL uint4v *)((DevIntraCtu *)f->ictu + k);
-            uint4v q[2];
-            static_assert(sizeof(DevIntraCtu) == 32, "DevIntraCtu layout");
-            __builtin_memcpy(q, &d, 32);
-            o[0] = q[0]; o[1] = q[1];
-        }
-        if (any_res && !d.res_cnt) staged = 0;
-        max_items = max(max_items, min(b1 - b0, (uint32_t)OH_MAX_CTU_BLOCKS));
-        max_sub = max(max_sub, min((uint32_t)c.n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
+        const DevIntraCtu d = gload(f->ictu + k);
+        const uint32_t aux = f->ctu_aux[k];
+        if (aux & 0x80000000u) staged = 0;
+        max_items = max(max_items, min(d.n_items, (uint32_t)OH_MAX_CTU_BLOCKS));
+        max_sub = max(max_sub, min((uint32_t)d.n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
         max_res = max(max_res, d.res_cnt);
-        for (uint32_t j = c.sub_first; j < c.sub_first + c.n_sub; j++) {                         /* wave passes: slot groups + big blocks */
-            const uint32_t sm = f->sub_small_w[j];
-            sum_items += (sm + 3) / 4 + (f->sub_start[j + 1] - f->sub_start[j] - sm);
-        }
-        sum_sub += c.n_sub;
+        sum_items += aux & 0x7fffffffu;
+        sum_sub += d.n_sub;
     }
 #pragma unroll
     for (int d = 32; d; d >>= 1) {
@@ -505,52 +518,53 @@ __global__ __launch_bounds__(64) void prep_intra_levels(const OhBatch B)
         DevLevelStat s;
         s.n_ctu = k1 - k0; s.max_items = max_items; s.max_sub = max_sub; s.max_res = max_res; s.staged = staged; s.pad = 0;
         s.sum_items = sum_items; s.sum_sub = sum_sub;
-        DevLevelStat *o = (DevLevelStat *)(summary_of(f) + 1) + l;
-        *o = s;
+        *((DevLevelStat *)(summary_of(f) + 1) + l) = s;
     }
 }
 
-/* last: the bucket ranges the residual launches read, the counts the host compares with its own */
-__global__ void prep_finish(const OhBatch B)
+/* last: the counts are compared with the host's (the bucket ranges were laid out for them) and the summary — error, counts,
+ * level statistics — goes to the list's pinned host block with plain stores: visible to the host once the event behind this
+ * kernel has completed */
+__global__ __launch_bounds__(64) void prep_finish(const OhBatch B)
 {
     DevFrame *f = (DevFrame *)B.f[blockIdx.x];
-    if (threadIdx.x || failed(f))
-        return;
     DevSummary *s = summary_of(f);
-    uint32_t first = 0;
-    for (int k = 0; k < 4; k++) {
-        f->tu_first[k] = first; f->tu_cnt[k] = f->tu_cursor[k];
-        first += f->tu_cursor[k];
-        s->tu_cnt[k] = f->tu_cursor[k];
-        if (f->tu_cursor[4 + k] != f->tu_cursor[k]) fail(f, OH_PE_TU, 0xffffffffu);
+    if (threadIdx.x == 0 && !failed(f)) {
+        for (int k = 0; k < 4; k++) {
+            s->tu_cnt[k] = f->tu_cursor[k];
+            if (f->tu_cursor[k] != f->tu_cnt[k]) fail(f, OH_PE_TU, 0xffffffffu);
+        }
+        s->n_cross = f->tu_cursor[9];
+        if (f->tu_cursor[9] != f->n_cross) fail(f, OH_PE_TU, 0xffffffffu);
     }
-    f->n_cross = f->tu_cursor[8];
-    s->n_cross = f->tu_cursor[8];
-    if (first != f->n_tu || f->tu_cursor[9] != f->tu_cursor[8]) fail(f, OH_PE_TU, 0xffffffffu);
+    __syncthreads();
+    const uint32_t words = (uint32_t)((sizeof(DevSummary) + (size_t)f->n_levels * sizeof(DevLevelStat)) / 4);
+    const uint32_t *src = (const uint32_t *)s;
+    uint32_t *dst = (uint32_t *)f->summary_host;
+    for (uint32_t i = threadIdx.x; i < words; i += 64)
+        dst[i] = *(volatile const uint32_t *)(src + i);
 }
 
 /* =========================================================================================
  * launcher: everything for ONE work list, enqueued on `st` (the engine's copy stream, behind the list's H2D copy)
  * ======================================================================================= */
-extern "C" void ohk_prepare(const DevFrame *dev, const OhPrepCounts *n, hipStream_t st)
+extern "C" void ohk_prepare(const OhBatch *B, int nb, const OhPrepCounts *n, uint32_t max_mc_runs, uint32_t max_cross, hipStream_t st)
 {
-    OhBatch B;
-    memset(&B, 0, sizeof(B));
-    B.f[0] = dev;
+    /* n: the LARGEST count of the batch per kind (every kernel bounds its index by the list's own count) */
+    hipLaunchKernelGGL(prep_clear, dim3(16, nb), dim3(256), 0, st, *B);
     if (n->n_pu) {
-        hipLaunchKernelGGL(prep_pu_scan, dim3(1), dim3(1024), 0, st, B);
-        hipLaunchKernelGGL(prep_pu_expand, dim3((n->n_pu + 255) / 256, 1), dim3(256), 0, st, B);
-        const uint32_t runs = ((n->n_mc_luma + 63) >> 6) + ((n->n_mc_chroma + 63) >> 6);
-        if (runs) hipLaunchKernelGGL(prep_mc_group, dim3(runs, 1), dim3(64), 0, st, B);
+        hipLaunchKernelGGL(prep_pu_expand, dim3((n->n_pu + 255) / 256, nb), dim3(256), 0, st, *B);
+        if (max_mc_runs) hipLaunchKernelGGL(prep_mc_group, dim3(max_mc_runs, nb), dim3(64), 0, st, *B);
     }
     if (n->n_tu) {
-        hipLaunchKernelGGL(prep_tu_count, dim3((n->n_tu + 255) / 256, 1), dim3(256), 0, st, B);
-        hipLaunchKernelGGL(prep_tu_scatter, dim3((n->n_tu + 255) / 256, 1), dim3(256), 0, st, B);
+        if (max_cross) hipLaunchKernelGGL(prep_tu_mark, dim3((n->n_tu + 255) / 256, nb), dim3(256), 0, st, *B);
+        hipLaunchKernelGGL(prep_tu_scatter, dim3((n->n_tu + 255) / 256, nb), dim3(256), 0, st, *B);
     }
     if (n->n_intra) {
-        hipLaunchKernelGGL(prep_intra_sub, dim3((n->n_sub + 255) / 256, 1), dim3(256), 0, st, B);
-        hipLaunchKernelGGL(prep_intra_items, dim3((n->n_intra + 255) / 256, 1), dim3(256), 0, st, B);
-        hipLaunchKernelGGL(prep_intra_levels, dim3(n->n_levels, 1), dim3(64), 0, st, B);
+        hipLaunchKernelGGL(prep_intra_sub, dim3((n->n_sub + 255) / 256, nb), dim3(256), 0, st, *B);
+        hipLaunchKernelGGL(prep_intra_items, dim3((n->n_intra + 255) / 256, nb), dim3(256), 0, st, *B);
+        hipLaunchKernelGGL(prep_intra_ctu, dim3(n->n_ictu, nb), dim3(64), 0, st, *B);
+        hipLaunchKernelGGL(prep_intra_levels, dim3(n->n_levels, nb), dim3(64), 0, st, *B);
     }
-    hipLaunchKernelGGL(prep_finish, dim3(1), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(prep_finish, dim3(nb), dim3(64), 0, st, *B);
 }

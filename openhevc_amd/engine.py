@@ -58,6 +58,7 @@ def lib():
         L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download_window.argtypes = [V, I, C.POINTER(OhWindow), C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
+        L.oh_frames_upload.argtypes = [V, C.POINTER(C.POINTER(F.OhFrame)), I, PP]
         L.oh_frame_execute.argtypes = [V, V]
         L.oh_pic_upsample.argtypes = [V, C.c_int, C.c_int, V]
         L.oh_frames_execute.argtypes = [V, C.POINTER(C.c_void_p), C.c_int]
@@ -68,6 +69,9 @@ def lib():
         L.oh_engine_profile.argtypes = [V, I]
         L.oh_engine_pass_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
         L.oh_engine_intra_launch_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
+        L.oh_engine_host_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I, I]
+        L.oh_engine_upload_bytes.argtypes = [V, I]
+        L.oh_engine_upload_bytes.restype = C.c_uint64
         L.oh_engine_stream.argtypes = [V]
         L.oh_engine_stream.restype = V
         L.oh_pic_device_planes.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -180,6 +184,14 @@ class Engine:
         self._chk(self.L.oh_frame_upload(self.h, C.byref(frame), C.byref(df)), "oh_frame_upload")
         return df
 
+    def frames_upload(self, frames):
+        """n work lists, one set of preparation launches (oh_frames_upload); returns the device frames"""
+        n = len(frames)
+        fs = (C.POINTER(F.OhFrame) * n)(*[C.pointer(f) for f in frames])
+        out = (C.c_void_p * n)()
+        self._chk(self.L.oh_frames_upload(self.h, fs, n, out), "oh_frames_upload")
+        return [C.c_void_p(out[i]) for i in range(n)]
+
     def frame_execute(self, df):
         self._chk(self.L.oh_frame_execute(self.h, df), "oh_frame_execute")
         self.n_batches = getattr(self, "n_batches", 0) + 1
@@ -221,6 +233,19 @@ class Engine:
         ms, n = C.c_double(), C.c_uint64()
         self._chk(self.L.oh_engine_intra_launch_times(self.h, C.byref(ms), C.byref(n), int(reset)), "oh_engine_intra_launch_times")
         return ms.value, n.value
+
+    HOST_TIME_NAMES = ("upload", "upload_count_loops", "upload_arena", "upload_wait_for_staging_buffer", "upload_memcpy_to_pinned",
+                       "upload_enqueue", "execute", "execute_wait_for_preparation", "release")
+
+    def host_times(self, reset=False):
+        """{slot: (milliseconds, calls)} of host wall time inside the hand-over path (include/ohevc_hip.h: OhHostTime)"""
+        n = len(self.HOST_TIME_NAMES)
+        ms, calls = (C.c_double * n)(), (C.c_uint64 * n)()
+        self._chk(self.L.oh_engine_host_times(self.h, ms, calls, n, int(reset)), "oh_engine_host_times")
+        return {k: (ms[i], calls[i]) for i, k in enumerate(self.HOST_TIME_NAMES)}
+
+    def upload_bytes(self, reset=False):
+        return int(self.L.oh_engine_upload_bytes(self.h, int(reset)))
 
     def stream(self):
         return self.L.oh_engine_stream(self.h)

@@ -284,13 +284,18 @@ class EngineBackend(Backend):
             self.engine.frames_execute([be.frames[name] for be, name in items])
             return
         import time
-        t0 = time.perf_counter()
-        dfs = [self.engine.frame_upload(be.headers[name]) for be, name in items]
-        self.upload_s += time.perf_counter() - t0
-        self.uploads += len(dfs)
-        self.engine.frames_execute(dfs)
-        for df in dfs:
-            self.engine.frame_release(df)
+        for c0 in range(0, len(items), 32):                   # one launch per pass covers at most 32 pictures: hand over that many, run them, let go
+            t0 = time.perf_counter()
+            dfs = self.engine.frames_upload([be.headers[name] for be, name in items[c0:c0 + 32]])
+            t1 = time.perf_counter()
+            self.upload_s += t1 - t0
+            self.uploads += len(dfs)
+            self.engine.frames_execute(dfs)
+            t2 = time.perf_counter()
+            for df in dfs:
+                self.engine.frame_release(df)
+            self.execute_s = getattr(self, "execute_s", 0.0) + (t2 - t1)
+            self.release_s = getattr(self, "release_s", 0.0) + (time.perf_counter() - t2)
 
     def final_half(self, name):
         return self.engine.pic_final_half(self.ids[name])

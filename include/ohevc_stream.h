@@ -1,0 +1,80 @@
+/*
+ * ohevc_stream.h — synthetic HEVC Annex-B stream writer (C ABI, host only; part of libohevc_host.so).
+ *
+ * No HEVC encoder or conformance stream exists in the build environment (SURVEY.md §7 "hard parts", §8c).  This writer
+ * produces LEGAL bitstreams from scratch: parameter sets (VPS / SPS / PPS), slice headers, and CABAC-coded slice data
+ * whose syntax elements are drawn at random inside what H.265 allows — coding quadtrees, skip / merge / AMVP prediction
+ * units with random motion-vector differences, intra modes through the most-probable-mode syntax, transform trees,
+ * residual blocks, PCM and transquant-bypass coding units, SAO parameters, several slices per picture, tiles, wavefront
+ * entry points.  There is no rate control and no search: what the pictures look like is whatever the DECODER derives
+ * from the syntax, which is the point — the reference decoder (oracle/_ref, built from /root/reference) decodes these
+ * streams and is the checker for everything downstream of entropy decoding (tests/test_streams.py).
+ *
+ * Scope: Main / Main 10 (4:2:0, 8 or 10 bit), one layer.  Written from the H.265 syntax (7.3) and CABAC (9.3) clauses.
+ */
+#ifndef OHEVC_STREAM_H
+#define OHEVC_STREAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OhStreamParams {
+    uint64_t seed;
+    int32_t width, height;              /* luma samples, multiples of the minimum CB size (8) */
+    int32_t bit_depth;                  /* 8 or 10 */
+    int32_t log2_ctb_size;              /* 4..6 */
+    int32_t log2_min_tb_size, log2_max_tb_size;   /* 2..5 */
+    int32_t max_th_depth_intra, max_th_depth_inter;   /* max_transform_hierarchy_depth_* */
+    int32_t n_pictures;
+    int32_t gop;                        /* 0 all intra, 1 low-delay P, 2 low-delay B (both lists from past pictures) */
+    int32_t n_refs;                     /* reference pictures kept (1..4) */
+    int32_t idr_period;                 /* > 0: an IDR picture every so many pictures */
+    int32_t qp;                         /* slice QP */
+    /* tools (0 / 1) */
+    int32_t amp, sao, pcm, transquant_bypass, transform_skip, cu_qp_delta, tmvp, strong_intra_smoothing, constrained_intra_pred,
+            scaling_list, weighted_pred, sign_data_hiding, cabac_init_present, deblocking_override;
+    /* picture structure */
+    int32_t n_slices;                   /* slices per picture (>= 1), at random CTB addresses (whole tiles when tiles are on) */
+    int32_t tile_cols, tile_rows;       /* > 1: uniformly spaced tiles */
+    int32_t wpp;                        /* entropy_coding_sync_enabled_flag */
+    int32_t dependent_slices;           /* some slices become dependent slice segments */
+    int32_t lf_across_slices, lf_across_tiles;    /* the two loop_filter_across_* flags */
+    /* content knobs, per cent */
+    int32_t split_pct, intra_pct, skip_pct, merge_pct, bi_pct, cbf_pct, pcm_pct, bypass_pct, tskip_pct, sao_pct;
+    int32_t mvd_range;                  /* |mvd| bound in quarter samples; occasionally far larger */
+    int32_t coeff_density;              /* 1..100: how many coefficients a coded block gets */
+    int32_t trace;                      /* 1: keep the list of syntax elements written (oh_stream_trace) */
+    int32_t reserved[7];
+} OhStreamParams;
+
+/* syntax elements of the slice data as (id, value) pairs in coding order — the writer's side of tests/test_streams.py; the ids are
+ * shared with oracle/ref_trace_unit.c, which logs what the reference decoder parsed */
+enum { OH_SE_SAO_MERGE = 1, OH_SE_SAO_TYPE, OH_SE_SAO_OFFSET_ABS, OH_SE_SAO_OFFSET_SIGN, OH_SE_SAO_BAND_POS, OH_SE_SAO_EO_CLASS, OH_SE_END_OF_SLICE,
+       OH_SE_SPLIT_CU, OH_SE_BYPASS_FLAG, OH_SE_SKIP, OH_SE_PRED_MODE, OH_SE_PART_MODE, OH_SE_PCM_FLAG, OH_SE_PREV_INTRA, OH_SE_MPM_IDX,
+       OH_SE_REM_INTRA, OH_SE_CHROMA_MODE, OH_SE_MERGE_FLAG, OH_SE_MERGE_IDX, OH_SE_INTER_DIR, OH_SE_REF_IDX, OH_SE_MVD_X, OH_SE_MVD_Y, OH_SE_MVP,
+       OH_SE_ROOT_CBF, OH_SE_SPLIT_TU, OH_SE_CBF_LUMA, OH_SE_CBF_CHROMA, OH_SE_QP_DELTA_ABS, OH_SE_QP_DELTA_SIGN, OH_SE_RESIDUAL };
+size_t oh_stream_trace(const int32_t **recs);            /* of the last oh_stream_write with trace = 1; pairs (id, value) */
+
+typedef struct OhStream {
+    uint8_t *data;                      /* Annex-B byte stream (start codes included) */
+    size_t   size;
+    int32_t  n_pictures;
+    size_t  *au_offset;                 /* n_pictures + 1 offsets: access unit i is data[au_offset[i] .. au_offset[i+1]) */
+} OhStream;
+
+void oh_stream_defaults(OhStreamParams *p, int width, int height, uint64_t seed);
+/* returns 0, or a negative value when the parameters are outside what the writer covers */
+int  oh_stream_write(const OhStreamParams *p, OhStream *out);
+/* the same stream with a decoded-picture-hash SEI (MD5, payload type 132, suffix SEI NAL) behind every picture;
+ * md5[i * 48 ..]: the three plane digests of picture i in decode order */
+int  oh_stream_add_md5(const OhStream *in, const uint8_t *md5, OhStream *out);
+void oh_stream_free(OhStream *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -134,6 +134,9 @@ void oh_tables_set_intra_accessor(oh_intra_accessor fn);
 /* flush the PU being assembled; returns the number of slot calls that could not be translated
  * (unknown pointers, unsupported slots) since oh_tables_bind() */
 int  oh_tables_finish(void);
+/* diagnostics: the untranslated calls since oh_tables_bind() by slot family — 0 transform_add, 1 put_pcm, 2 intra without accessor,
+ * 3 intra refused by the recorder, 4 edge emulation, 5 luma interpolation, 6 list-0 half of a bi-predicted block, 7 PU refused */
+void oh_tables_untranslated_by_family(int out[8]);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ typedef struct Tables {
     Planes cur, refs[OH_MAX_REFS];
     oh_intra_accessor intra_fn;
     int untranslated;
+    int why[8];                       /* untranslated calls by slot family: 0 transform_add, 1 put_pcm, 2 intra (no accessor), 3 intra (recorder), 4 edge emulation, 5 luma MC, 6 list-0 half, 7 PU record */
     /* residual: transform remembered for a coefficient buffer until its transform_add */
     const int16_t *tr_coeffs; int tr_kind, tr_flags;
     /* last intra block, waiting for its residual */
@@ -41,7 +42,10 @@ static int resolve(const Planes *pl, int plane, const uint8_t *ptr, int bpp, int
     ptrdiff_t d = ptr - pl->data[plane], ls = pl->linesize[plane];
     ptrdiff_t yy = d >= 0 ? d / ls : -((-d + ls - 1) / ls);
     ptrdiff_t xx = (d - yy * ls) / bpp;
-    if (xx >= ls / bpp - 128) { xx -= ls / bpp; yy += 1; }   /* a position left of column 0 shows up at the end of the row above */
+    /* a position left of column 0 shows up at the end of the row above: the row's padding (everything beyond the plane's width)
+     * is split in the middle between "right of the picture" and "left of the next row" */
+    const ptrdiff_t pw = T.p.width >> oh_hshift(&T.p, plane), row = ls / bpp;
+    if (xx >= pw + (row - pw) / 2) { xx -= row; yy += 1; }
     *x = (int)xx; *y = (int)yy;
     return 1;
 }
@@ -90,8 +94,9 @@ static void flush_pu(void)
     if (!T.pu.valid || !T.rec)
         return;
     if (oh_rec_pu(T.rec, T.pu.x, T.pu.y, T.pu.w, T.pu.h, T.pu.ref[0], T.pu.mv[0][0], T.pu.mv[0][1],
-                  T.pu.ref[1], T.pu.mv[1][0], T.pu.mv[1][1], T.pu.weighted ? &T.pu.wp : NULL) != 0)
-        T.untranslated++;
+                  T.pu.ref[1], T.pu.mv[1][0], T.pu.mv[1][1], T.pu.weighted ? &T.pu.wp : NULL) != 0) {
+        T.untranslated++; T.why[7]++;
+    }
     T.pu.valid = 0;
 }
 
@@ -124,6 +129,11 @@ int oh_tables_finish(void)
     return T.untranslated;
 }
 
+void oh_tables_untranslated_by_family(int out[8])
+{
+    for (int i = 0; i < 8; i++) out[i] = T.why[i];
+}
+
 /* ---- residual slots (hevc_cabac.c:1868-1949) ---- */
 static void note_transform(const int16_t *coeffs, int kind, int flags)
 {
@@ -142,7 +152,7 @@ static void transform_add_n(uint8_t *dst, int16_t *coeffs, ptrdiff_t stride, int
 {
     int c, x, y;
     flush_pu();
-    if (!T.rec || !resolve_dst(dst, stride, &c, &x, &y)) { T.untranslated++; return; }
+    if (!T.rec || !resolve_dst(dst, stride, &c, &x, &y)) { T.untranslated++; T.why[0]++; return; }
     int kind = OH_TU_BYPASS, flags = 0;
     if (T.tr_coeffs == coeffs) { kind = T.tr_kind; flags = T.tr_flags; }
     T.tr_coeffs = NULL;
@@ -173,7 +183,7 @@ static void s_put_pcm(uint8_t *dst, ptrdiff_t stride, int width, int height, str
     flush_pu();
     if (!T.rec || !gb || width < 4 || height < 4 || width > 32 || height > 32 || (width & (width - 1)) || (height & (height - 1)) ||
         !resolve_dst(dst, stride, &c, &x, &y)) {
-        T.untranslated++;
+        T.untranslated++; T.why[1]++;
         return;
     }
     int16_t rect[32 * 32], blk[32 * 32];
@@ -195,11 +205,11 @@ static void intra_pred_n(struct HEVCContext *s, int x0, int y0, int c_idx, int l
 {
     int mode = 1, avail = 0;
     flush_pu();
-    if (!T.rec || !T.intra_fn) { T.untranslated++; return; }
+    if (!T.rec || !T.intra_fn) { T.untranslated++; T.why[2]++; return; }
     T.intra_fn(s, x0, y0, c_idx, log2, &mode, &avail);
     int x = x0 >> oh_hshift(&T.p, c_idx), y = y0 >> oh_vshift(&T.p, c_idx);   /* x0,y0 are luma units, hevcpred_template.c:86-87 */
     uint32_t idx = oh_rec_n_intra(T.rec);
-    if (oh_rec_intra(T.rec, c_idx, x, y, log2, mode, avail, OH_NO_COEFF) != 0) { T.untranslated++; return; }
+    if (oh_rec_intra(T.rec, c_idx, x, y, log2, mode, avail, OH_NO_COEFF) != 0) { T.untranslated++; T.why[3]++; return; }
     T.li_valid = 1; T.li_c = c_idx; T.li_x = x; T.li_y = y; T.li_log2 = log2; T.li_index = idx;
 }
 static void s_intra_pred2(struct HEVCContext *s, int x0, int y0, int c) { intra_pred_n(s, x0, y0, c, 2); }
@@ -229,7 +239,7 @@ static void s_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_l
     else if (T.emu[1].valid && T.emu[1].buf == buf) e = 1;
     else { e = T.emu_next; T.emu_next ^= 1; }
     T.emu[e].valid = slot >= 0;
-    if (slot < 0) { T.untranslated++; return; }
+    if (slot < 0) { T.untranslated++; T.why[4]++; return; }
     T.emu[e].buf = buf; T.emu[e].linesize = buf_linesize; T.emu[e].slot = slot; T.emu[e].plane = plane;
     T.emu[e].src_x = src_x; T.emu[e].src_y = src_y; T.emu[e].bw = block_w; T.emu[e].bh = block_h;
 }
@@ -241,7 +251,7 @@ static void mc_luma(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdi
     int c, x, y, slot, sx, sy;
     flush_pu();
     if (!T.rec || !resolve_dst(dst, dststride, &c, &x, &y) || c != 0 || !resolve_src(src, srcstride, 0, &slot, &sx, &sy)) {
-        T.untranslated++;
+        T.untranslated++; T.why[5]++;
         return;
     }
     int mvx = ((sx - x) << 2) + mx, mvy = ((sy - y) << 2) + my;
@@ -249,7 +259,7 @@ static void mc_luma(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdi
     T.pu.valid = 1; T.pu.x = x; T.pu.y = y; T.pu.w = w; T.pu.h = h;
     T.pu.ref[0] = T.pu.ref[1] = -1;
     if (src2) {                                          /* second half of a bi-predicted block */
-        if (!T.l0.valid || T.l0.tmp != src2) { T.untranslated++; T.pu.valid = 0; return; }
+        if (!T.l0.valid || T.l0.tmp != src2) { T.untranslated++; T.why[6]++; T.pu.valid = 0; return; }
         T.pu.ref[0] = T.l0.slot; T.pu.mv[0][0] = T.l0.mvx; T.pu.mv[0][1] = T.l0.mvy;
         T.pu.ref[1] = slot; T.pu.mv[1][0] = mvx; T.pu.mv[1][1] = mvy;
         T.l0.valid = 0;
@@ -274,7 +284,7 @@ static void mc_luma_put(int16_t *dst, const uint8_t *src, ptrdiff_t srcstride, i
      * the SOURCE position and turn it into an MV when the bi call names the destination */
     int slot, sx, sy;
     flush_pu();
-    if (!resolve_src(src, srcstride, 0, &slot, &sx, &sy)) { T.untranslated++; T.l0.valid = 0; return; }
+    if (!resolve_src(src, srcstride, 0, &slot, &sx, &sy)) { T.untranslated++; T.why[6]++; T.l0.valid = 0; return; }
     T.l0.tmp = dst; T.l0.slot = slot; T.l0.mvx = (sx << 2) + mx; T.l0.mvy = (sy << 2) + my; T.l0.valid = 2;   /* absolute, fixed up below */
 }
 

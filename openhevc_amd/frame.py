@@ -378,3 +378,62 @@ class FrameCopy:
         for i in range(OH_MAX_REFS):
             g.ref_pics[i] = int(ref_pics[i]) if i < len(ref_pics) else -1
         return g
+
+
+# ---- work lists as files (fixtures recorded where the reference decoder is available, replayed where it is not) ----
+_FRAME_ARRAYS = (("pu", "n_pu", OhPu), ("wp", "n_wp", OhWeights), ("tu", "n_tu", OhTu), ("intra", "n_intra", OhIntra), ("ictu", "n_ictu", OhIntraCtu))
+
+
+def frame_to_arrays(f):
+    """{name: numpy uint8 array} holding everything an OhFrame points at plus its scalar fields (dense work lists: no sparse records,
+    no cross-component links, no bs_in)"""
+    assert not f.sparse and not f.tu_cross and not f.bs_in and not f.scaling, "only the dense hand-over is stored"
+    p = f.p
+    n_ctb = ((p.width + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size) * ((p.height + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size)
+    n_pu = (p.width >> p.log2_min_pu_size) * (p.height >> p.log2_min_pu_size)
+    n_qp = ((p.width >> p.log2_min_cb_size) + 1) * ((p.height >> p.log2_min_cb_size) + 1)
+
+    def grab(ptr, nbytes):
+        return np.frombuffer(C.string_at(ptr, int(nbytes)), dtype=np.uint8).copy() if ptr and nbytes else np.zeros(0, np.uint8)
+    out = {"params": np.frombuffer(bytes(p), dtype=np.uint8).copy(),
+           "ids": np.array([f.cur_pic] + [f.ref_pics[i] for i in range(OH_MAX_REFS)], np.int32),
+           "counts": np.array([f.n_pu, f.n_wp, f.n_tu, f.n_coeff, f.n_intra, f.n_ictu, f.n_sub, f.n_levels, f.bs_size], np.int64)}
+    for name, cnt, typ in _FRAME_ARRAYS:
+        out[name] = grab(getattr(f, name), getattr(f, cnt) * C.sizeof(typ))
+    out["coeffs"] = np.frombuffer(C.string_at(f.coeffs, int(f.n_coeff) * 2), dtype=np.int16).copy() if f.n_coeff else np.zeros(0, np.int16)
+    out["sub_start"] = grab(f.sub_start, (f.n_sub + 1) * 4 if f.n_intra else 0)
+    out["level_start"] = grab(f.level_start, (f.n_levels + 1) * 4 if f.n_intra else 0)
+    out["vertical_bs"] = grab(f.vertical_bs, f.bs_size)
+    out["horizontal_bs"] = grab(f.horizontal_bs, f.bs_size)
+    out["qp_y_tab"] = grab(f.qp_y_tab, n_qp)
+    out["is_pcm"] = grab(f.is_pcm, n_pu)
+    out["is_intra"] = grab(f.is_intra, n_pu)
+    out["deblock"] = grab(f.deblock, n_ctb * C.sizeof(OhDeblockCtb))
+    out["sao"] = grab(f.sao, n_ctb * C.sizeof(OhSaoCtb))
+    return out
+
+
+class FrameFromArrays:
+    """an OhFrame over arrays produced by frame_to_arrays (kept alive by this object)"""
+
+    def __init__(self, a):
+        self.a = {k: np.ascontiguousarray(v) for k, v in a.items()}
+        f = OhFrame()
+        C.memmove(C.byref(f.p), self.a["params"].ctypes.data, C.sizeof(OhPicParams))
+        ids, cnt = self.a["ids"], self.a["counts"]
+        f.cur_pic = int(ids[0])
+        for i in range(OH_MAX_REFS):
+            f.ref_pics[i] = int(ids[1 + i])
+        f.n_pu, f.n_wp, f.n_tu, f.n_coeff, f.n_intra, f.n_ictu, f.n_sub, f.n_levels, f.bs_size = (int(v) for v in cnt)
+
+        def ptr(name, typ):
+            v = self.a[name]
+            return C.cast(v.ctypes.data, C.POINTER(typ)) if v.size else C.cast(None, C.POINTER(typ))
+        for name, _, typ in _FRAME_ARRAYS:
+            setattr(f, name, ptr(name, typ))
+        f.coeffs = ptr("coeffs", C.c_int16)
+        f.sub_start, f.level_start = ptr("sub_start", C.c_uint32), ptr("level_start", C.c_uint32)
+        f.vertical_bs, f.horizontal_bs = ptr("vertical_bs", C.c_uint8), ptr("horizontal_bs", C.c_uint8)
+        f.qp_y_tab, f.is_pcm, f.is_intra = ptr("qp_y_tab", C.c_int8), ptr("is_pcm", C.c_uint8), ptr("is_intra", C.c_uint8)
+        f.deblock, f.sao = ptr("deblock", OhDeblockCtb), ptr("sao", OhSaoCtb)
+        self.frame = f

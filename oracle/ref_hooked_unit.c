@@ -1,0 +1,162 @@
+/*
+ * ref_hooked_unit.c — TEST INFRASTRUCTURE ONLY: the first real run of INTEGRATION.md.
+ *
+ * The reference's hevc.c compiled as it lies in /root/reference (the #include at the bottom; nothing copied) with the three edits
+ * INTEGRATION.md asks a maintainer for, made with the preprocessor instead of an editor:
+ *   1. the arch-hook calls: ff_hevc_dsp_init / ff_hevc_pred_init / ff_videodsp_init are followed by this repository's
+ *      ff_hevcdsp_init_hip / ff_hevcpred_init_hip / ff_videodsp_init_hip (openhevc_amd/csrc/tables.c) — the RECORDING slots;
+ *   2. per picture: after ff_hevc_frame_rps() the recorder is bound to the picture and to its reference pictures (picture id =
+ *      index of the HEVCFrame in s->DPB);
+ *   3. the reference's in-loop filter driver calls (ff_hevc_hls_filters / ff_hevc_hls_filter) are dropped: passes 4-5 run from
+ *      the arrays the CTU loop leaves behind, which ref_hooked_finish() copies into the recorder at the end of the access unit.
+ * Everything else — NAL parsing, parameter sets, CABAC, MV derivation, de-quantisation, the CTU loop with its per-block slot
+ * calls — is the reference's own code running as it always does.  The library (oracle/_ref/libopenhevc_hooked.so) decodes a
+ * stream into WORK LISTS; tests/test_streams.py runs them through the checker (and -m gpu tests through the engine) and compares
+ * the pictures with what the unmodified reference decoder (libopenhevc_ref.so) outputs for the same stream.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "libavcodec/hevc.h"
+#include "../include/ohevc_recorder.h"
+
+/* the hooks and the binding API of openhevc_amd/csrc/tables.c (include/ohevc_tables.h re-declares the table types, which would
+ * clash with the reference's own headers here: the three hooks are declared with untyped table pointers) */
+void ff_hevcdsp_init_hip(void *c, const int bit_depth);
+void ff_hevcpred_init_hip(void *c, const int bit_depth);
+void ff_videodsp_init_hip(void *c, int bit_depth);
+typedef void (*oh_intra_accessor)(struct HEVCContext *s, int x0, int y0, int c_idx, int log2_size, int *mode, int *avail);
+void oh_tables_bind(OhRecorder *rec, uint8_t *const cur_data[3], const int cur_linesize[3]);
+void oh_tables_bind_ref(int slot, uint8_t *const data[3], const int linesize[3]);
+void oh_tables_set_intra_accessor(oh_intra_accessor fn);
+int  oh_tables_finish(void);
+void oh_tables_untranslated_by_family(int out[8]);
+
+static struct {
+    HEVCContext *s;                   /* the context whose picture is being recorded (single-threaded decode) */
+    OhRecorder *rec;
+    OhPicParams p;
+    int open;                         /* a picture was started and not finished yet */
+    int cur_id, n_refs, ref_ids[OH_MAX_REFS];
+    int untranslated;
+} H;
+
+/* INTEGRATION.md §3 */
+static void intra_from_hevc(struct HEVCContext *s, int x0, int y0, int c_idx, int log2_size, int *mode, int *avail)
+{
+    HEVCLocalContext *lc = s->HEVClc;
+    int hshift = s->sps->hshift[c_idx], vshift = s->sps->vshift[c_idx];
+    int size_in_tbs_h = ((1 << log2_size) << hshift) >> s->sps->log2_min_tb_size;
+    int size_in_tbs_v = ((1 << log2_size) << vshift) >> s->sps->log2_min_tb_size;
+    int x_tb = (x0 >> s->sps->log2_min_tb_size) & s->sps->tb_mask, y_tb = (y0 >> s->sps->log2_min_tb_size) & s->sps->tb_mask;
+#define ZS(x, y) s->pps->min_tb_addr_zs[(y) * (s->sps->tb_mask + 2) + (x)]
+    int cur = ZS(x_tb, y_tb);
+    *mode  = c_idx ? lc->tu.intra_pred_mode_c : lc->tu.intra_pred_mode;
+    *avail = (lc->na.cand_bottom_left && cur > ZS(x_tb - 1, (y_tb + size_in_tbs_v) & s->sps->tb_mask) ? OH_AV_BOTTOM_LEFT : 0)
+           | (lc->na.cand_left ? OH_AV_LEFT : 0) | (lc->na.cand_up_left ? OH_AV_UP_LEFT : 0) | (lc->na.cand_up ? OH_AV_UP : 0)
+           | (lc->na.cand_up_right && cur > ZS((x_tb + size_in_tbs_h) & s->sps->tb_mask, y_tb - 1) ? OH_AV_UP_RIGHT : 0);
+#undef ZS
+    /* picture borders truncate the candidates (hevcpred_template.c:111-114 works with sizes; a candidate wholly outside is none) */
+    {
+        const int n = 1 << log2_size, x = x0 >> hshift, y = y0 >> vshift, pw = s->sps->width >> hshift, ph = s->sps->height >> vshift;
+        if (x + n >= pw) *avail &= ~OH_AV_UP_RIGHT;
+        if (y + n >= ph) *avail &= ~OH_AV_BOTTOM_LEFT;
+    }
+}
+
+static int frame_rps_and_bind(HEVCContext *s)
+{
+    int ret = ff_hevc_frame_rps(s);
+    if (ret < 0)
+        return ret;
+    const HEVCSPS *sps = s->sps;
+    OhPicParams p;
+    memset(&p, 0, sizeof(p));
+    p.width = sps->width; p.height = sps->height; p.bit_depth = sps->bit_depth; p.chroma_format_idc = sps->chroma_format_idc;
+    p.log2_ctb_size = sps->log2_ctb_size; p.log2_min_cb_size = sps->log2_min_cb_size; p.log2_min_tb_size = sps->log2_min_tb_size;
+    p.log2_min_pu_size = sps->log2_min_pu_size;
+    p.pcm_loop_filter_disable = sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag;
+    p.transquant_bypass_enable = s->pps->transquant_bypass_enable_flag;
+    p.strong_intra_smoothing = sps->sps_strong_intra_smoothing_enable_flag;
+    p.intra_smoothing_disabled = sps->spsRext.intra_smoothing_disabled_flag;
+    p.cb_qp_offset = s->pps->cb_qp_offset; p.cr_qp_offset = s->pps->cr_qp_offset;
+    p.sao_enabled = sps->sao_enabled; p.deblock_enabled = 1;
+    p.constrained_intra_pred = s->pps->constrained_intra_pred_flag;
+    if (!H.rec || memcmp(&p, &H.p, sizeof(p))) {
+        if (H.rec) oh_rec_destroy(H.rec);
+        H.rec = oh_rec_create(&p);
+        H.p = p;
+    }
+    H.s = s;
+    H.cur_id = (int)(s->ref - s->DPB);
+    /* the pictures this one may reference: its reference picture set (hevc_refs.c:391-470), slot = position in this list */
+    H.n_refs = 0;
+    static const int lists[3] = { ST_CURR_BEF, ST_CURR_AFT, LT_CURR };
+    for (int l = 0; l < 3; l++)
+        for (int i = 0; i < s->rps[lists[l]].nb_refs && H.n_refs < OH_MAX_REFS; i++)
+            H.ref_ids[H.n_refs++] = (int)(s->rps[lists[l]].ref[i] - s->DPB);
+    int32_t ids[OH_MAX_REFS];
+    for (int i = 0; i < H.n_refs; i++) ids[i] = H.ref_ids[i];
+    oh_rec_begin(H.rec, H.cur_id, ids, H.n_refs);
+    oh_tables_set_intra_accessor(intra_from_hevc);
+    oh_tables_bind(H.rec, s->frame->data, s->frame->linesize);
+    for (int i = 0; i < H.n_refs; i++)
+        oh_tables_bind_ref(i, s->DPB[H.ref_ids[i]].frame->data, s->DPB[H.ref_ids[i]].frame->linesize);
+    H.open = 1;
+    return ret;
+}
+
+/* end of the access unit: what passes 4-5 read goes from the context into the recorder; returns the work
+ * list of the picture, or NULL when the access unit held no picture.  *untranslated: slot calls the hooks could not translate. */
+__attribute__((visibility("default"))) const OhFrame *ref_hooked_finish(int *cur_id, int *poc, int *untranslated)
+{
+    if (!H.open)
+        return NULL;
+    HEVCContext *s = H.s;
+    const HEVCSPS *sps = s->sps;
+    H.open = 0;
+    *untranslated = oh_tables_finish();
+    if (*untranslated && getenv("OHEVC_HOOK_DEBUG")) {
+        int why[8];
+        oh_tables_untranslated_by_family(why);
+        fprintf(stderr, "untranslated: transform_add %d, put_pcm %d, intra(no accessor) %d, intra(recorder) %d, emu %d, luma MC %d, l0 half %d, PU %d\n",
+                why[0], why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
+    }
+    *cur_id = H.cur_id; *poc = s->poc;
+    const int n_ctb = sps->ctb_width * sps->ctb_height, n_pu = sps->min_pu_width * sps->min_pu_height;
+    memcpy(oh_rec_vertical_bs(H.rec), s->vertical_bs, (size_t)s->bs_width * s->bs_height);
+    memcpy(oh_rec_horizontal_bs(H.rec), s->horizontal_bs, (size_t)s->bs_width * s->bs_height);
+    memcpy(oh_rec_qp_y_tab(H.rec), s->qp_y_tab, (size_t)(sps->min_cb_width * sps->min_cb_height));
+    memcpy(oh_rec_is_pcm(H.rec), s->is_pcm, (size_t)n_pu);
+    if (s->pps->constrained_intra_pred_flag)
+        for (int i = 0; i < n_pu; i++) oh_rec_is_intra(H.rec)[i] = s->ref->tab_mvf[i].pred_flag == PF_INTRA;
+    OhCtbMaps *m = oh_rec_ctb_maps(H.rec);
+    m->tiles_enabled = s->pps->tiles_enabled_flag;
+    m->loop_filter_across_tiles = s->pps->loop_filter_across_tiles_enabled_flag;
+    for (int ctb = 0; ctb < n_ctb; ctb++) {
+        OhDeblockCtb *d = &oh_rec_deblock(H.rec)[ctb];
+        d->beta_offset = (int8_t)s->deblock[ctb].beta_offset; d->tc_offset = (int8_t)s->deblock[ctb].tc_offset;
+        OhSaoCtb *o = &oh_rec_sao(H.rec)[ctb];
+        const SAOParams *a = &s->sao[ctb];
+        memset(o, 0, sizeof(*o));
+        for (int c = 0; c < 3; c++) {
+            for (int k = 0; k < 5; k++) o->offset_val[c][k] = a->offset_val[c][k];
+            o->band_position[c] = a->band_position[c]; o->eo_class[c] = (uint8_t)a->eo_class[c]; o->type_idx[c] = a->type_idx[c];
+        }
+        m->slice_addr[ctb] = s->tab_slice_address[ctb];
+        m->filter_slice_edges[ctb] = s->filter_slice_edges[ctb];
+        m->tile_id[ctb] = s->pps->tile_id[s->pps->ctb_addr_rs_to_ts[ctb]];
+        m->deblock_disabled[ctb] = 0;                      /* such slices simply derive no boundary strengths (hevc.c:1577) */
+    }
+    return oh_rec_finish(H.rec);
+}
+
+#define ff_hevc_dsp_init(c, bd)   do { ff_hevc_dsp_init(c, bd);  ff_hevcdsp_init_hip((void *)(c), bd); } while (0)
+#define ff_hevc_pred_init(c, bd)  do { ff_hevc_pred_init(c, bd); ff_hevcpred_init_hip((void *)(c), bd); } while (0)
+#define ff_videodsp_init(c, bd)   do { ff_videodsp_init(c, bd);  ff_videodsp_init_hip((void *)(c), bd); } while (0)
+#define ff_hevc_frame_rps(s)      frame_rps_and_bind(s)
+#define ff_hevc_hls_filters(s, x, y, c) ((void)0)
+#define ff_hevc_hls_filter(s, x, y, c)  ((void)0)
+
+#include "libavcodec/hevc.c"

@@ -30,6 +30,11 @@
 #undef  HAVE_ARMV6T2_INLINE
 #define HAVE_ARMV6T2_INLINE 0
 
+/* platform/arm/config.h:174 still carries the placeholder of the template it was generated from (`#define HAVE_GMTIME_R
+ * @GMTIME_R_FOUND@`); libavutil/parseutils.c tests the macro in an #if.  glibc has gmtime_r: say so. */
+#undef  HAVE_GMTIME_R
+#define HAVE_GMTIME_R 1
+
 /* hevc_filter.c reports row progress to frame threads (hevc_filter.c:1040-1050); the harness
  * runs with threads_type == 0, so these are never called.  Declaring the references weak lets
  * the shared object load without pthread_frame.c — no replacement definition is provided. */

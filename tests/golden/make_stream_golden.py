@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/streams/*.npz.  Needs /root/reference (oracle/_ref is built from it): runs only in the build container.
+
+Per case: a synthetic stream from the writer (openhevc_amd/synth/stream.c) is decoded TWICE by the reference's own decoder —
+  * unmodified (oracle/_ref/libopenhevc_ref.so): the MD5 of every plane of every output picture is the expected result;
+  * with this repository's recording hooks linked into its CTU loop (libopenhevc_hooked.so, oracle/ref_hooked_unit.c): the work
+    list of every picture, exactly as the hooks recorded it inside the reference, is stored.
+The fixtures let the CPU checker and the HIP engine be tested against REFERENCE OUTPUT of real bitstream decoding on machines where
+the reference does not exist (the GPU box).  The streams themselves are regenerated on the fly (the writer is deterministic)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import refdec        # noqa: E402
+import streamgen     # noqa: E402
+from openhevc_amd import frame as F    # noqa: E402
+
+STREAM_CASES = [
+    # name, width, height, seed, writer parameters
+    ("ipb_8b", 416, 240, 7, dict(n_pictures=4, gop=2)),
+    ("lowdelay_p_10b_ctb32_tools", 264, 200, 9, dict(n_pictures=3, gop=1, bit_depth=10, log2_ctb_size=5, pcm=1, transquant_bypass=1, transform_skip=1, cu_qp_delta=1)),
+    ("b_ctb16_slices_wpp", 264, 200, 11, dict(n_pictures=3, gop=2, wpp=1, n_slices=3, log2_ctb_size=4, log2_max_tb_size=4)),
+    ("b_tiles_slices_no_lf_across", 416, 240, 12, dict(n_pictures=3, gop=2, tile_cols=2, tile_rows=2, n_slices=3, log2_ctb_size=4, log2_max_tb_size=4,
+                                                    lf_across_tiles=0, lf_across_slices=0)),
+    ("p_weighted_cip_lists", 264, 200, 13, dict(n_pictures=3, gop=1, weighted_pred=1, scaling_list=1, constrained_intra_pred=1)),
+    ("b_tmvp_3refs", 416, 240, 14, dict(n_pictures=4, gop=2, tmvp=1, cabac_init_present=1, deblocking_override=1, n_refs=3)),
+]
+
+
+def build(name, w, h, seed, kw):
+    data, _ = streamgen.write_stream(w, h, seed, **kw)
+    want = refdec.decode(data)
+    out = {"stream_md5": np.frombuffer(hashlib.md5(data).digest(), dtype=np.uint8)}
+    k = [0]
+
+    def on_picture(f, cur, poc):
+        for key, v in F.frame_to_arrays(f).items():
+            out[f"pic{k[0]}_{key}"] = v
+        k[0] += 1
+    n = refdec.record_work_lists(data, on_picture)
+    assert n == len(want), (n, len(want))
+    out["n_pictures"] = np.array([n])
+    out["md5"] = np.frombuffer(b"".join(b"".join(refdec.md5_of(p)) for p in want), dtype=np.uint8).copy()
+    return out
+
+
+def main():
+    for name, w, h, seed, kw in STREAM_CASES:
+        path = os.path.join(HERE, "streams", name + ".npz")
+        np.savez_compressed(path, **build(name, w, h, seed, kw))
+        print(name, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

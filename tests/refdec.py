@@ -1,0 +1,226 @@
+"""ctypes view of the reference's whole decoder (oracle/_ref/libopenhevc_ref.so: its libavutil / libavcodec / libOpenHevc* wrapper
+compiled from /root/reference by oracle/Makefile `refdec`).  TEST INFRASTRUCTURE — the checker for whole streams."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_ref.so")
+REF_TREE = "/root/reference"
+
+
+class Rational(C.Structure):
+    _fields_ = [("num", C.c_int), ("den", C.c_int)]
+
+
+class FrameInfo(C.Structure):                                  # OpenHevc_FrameInfo, openHevcWrapper.h:47-62
+    _fields_ = [("nYPitch", C.c_int), ("nUPitch", C.c_int), ("nVPitch", C.c_int), ("nBitDepth", C.c_int), ("nWidth", C.c_int),
+                ("nHeight", C.c_int), ("chromat_format", C.c_int), ("sample_aspect_ratio", Rational), ("frameRate", Rational),
+                ("display_picture_number", C.c_int), ("flag", C.c_int), ("nTimeStamp", C.c_int64)]
+
+
+class FrameCpy(C.Structure):                                   # OpenHevc_Frame_cpy
+    _fields_ = [("pvY", C.c_void_p), ("pvU", C.c_void_p), ("pvV", C.c_void_p), ("frameInfo", FrameInfo)]
+
+
+def have_refdec():
+    return os.path.exists(LIB) or os.path.isdir(REF_TREE)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if os.path.isdir(REF_TREE):
+            subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "refdec"])
+        L = C.CDLL(LIB)
+        V = C.c_void_p
+        L.libOpenHevcInit.restype = V
+        L.libOpenHevcInit.argtypes = [C.c_int, C.c_int]
+        L.libOpenHevcStartDecoder.argtypes = [V]
+        L.libOpenHevcDecode.argtypes = [V, C.c_char_p, C.c_int, C.c_int64]
+        L.libOpenHevcGetPictureInfoCpy.argtypes = [V, C.POINTER(FrameInfo)]
+        L.libOpenHevcGetPictureInfoCpy.restype = None
+        L.libOpenHevcGetOutputCpy.argtypes = [V, C.c_int, C.POINTER(FrameCpy)]
+        L.libOpenHevcSetCheckMD5.argtypes = [V, C.c_int]
+        L.libOpenHevcSetCheckMD5.restype = None
+        L.libOpenHevcSetDebugMode.argtypes = [V, C.c_int]
+        L.libOpenHevcSetDebugMode.restype = None
+        L.libOpenHevcClose.argtypes = [V]
+        L.libOpenHevcClose.restype = None
+        _lib = L
+    return _lib
+
+
+TRACE_LIB = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_trace.so")
+_tlib = None
+
+
+def parsed_trace(data):
+    """[(id, value)] of the syntax elements the reference decoder parsed from the stream (the decoder built through
+    oracle/ref_trace_unit.c)"""
+    global _tlib, _lib
+    if _tlib is None:
+        if os.path.isdir(REF_TREE):
+            subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "reftrace"])
+        _tlib = C.CDLL(TRACE_LIB)
+    keep, _lib = _lib, None
+    try:
+        lib()                                                  # declare the API on the plain library first (argtypes are per CDLL)
+        L = _tlib
+        for name in ("libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDecode", "libOpenHevcGetPictureInfoCpy", "libOpenHevcGetOutputCpy",
+                     "libOpenHevcSetCheckMD5", "libOpenHevcClose"):
+            getattr(L, name).argtypes = getattr(_lib, name).argtypes
+            getattr(L, name).restype = getattr(_lib, name).restype
+        plain, _lib = _lib, L
+        L.ref_trace_start()
+        decode(data)
+        p = C.c_void_p()
+        L.ref_trace_get.restype = C.c_size_t
+        L.ref_trace_get.argtypes = [C.POINTER(C.c_void_p)]
+        n = L.ref_trace_get(C.byref(p))
+        a = np.frombuffer(C.string_at(p, n * 8), dtype=np.int32).reshape(n, 2).copy() if n else np.zeros((0, 2), np.int32)
+    finally:
+        _lib = keep
+    return a
+
+
+def split_access_units(data):
+    """the byte ranges of the access units of an Annex-B stream in the sense of hevc_parser.c:40-87: a new access unit starts at
+    the first VPS / SPS / PPS / AUD / prefix SEI NAL unit that follows a VCL NAL unit, or at a VCL NAL unit whose
+    first_slice_segment_in_pic_flag is set"""
+    starts = []
+    i, n = 0, len(data)
+    while i + 3 < n:
+        if data[i] == 0 and data[i + 1] == 0 and data[i + 2] == 1:
+            starts.append(i + 3)
+            i += 3
+        else:
+            i += 1
+    aus, cur, seen_vcl = [], 0, False
+    for k, s in enumerate(starts):
+        t = (data[s] >> 1) & 63
+        sc = s - 3 - (1 if s >= 4 and data[s - 4] == 0 else 0)     # include the leading zero of a 4-byte start code
+        new_au = False
+        if t in (32, 33, 34, 35, 39) or 41 <= t <= 44 or 48 <= t <= 55:
+            new_au = seen_vcl
+        elif t <= 9 or 16 <= t <= 21:
+            new_au = seen_vcl and bool(data[s + 2] & 0x80)
+        if new_au:
+            aus.append((cur, sc))
+            cur, seen_vcl = sc, False
+        if t <= 9 or 16 <= t <= 21:
+            seen_vcl = True
+    aus.append((cur, n))
+    return aus
+
+
+def decode(data, threads=1, thread_type=1, check_md5=False):
+    """decodes an Annex-B stream access unit by access unit through the libOpenHevc* API; returns the output pictures as lists of
+    numpy planes (cropped, packed) in output order"""
+    L = lib()
+    h = C.c_void_p(L.libOpenHevcInit(threads, thread_type))
+    assert L.libOpenHevcStartDecoder(h) == 1
+    L.libOpenHevcSetCheckMD5(h, int(check_md5))
+    pics = []
+
+    def grab():
+        info = FrameInfo()
+        L.libOpenHevcGetPictureInfoCpy(h, C.byref(info))
+        dt = np.uint8 if info.nBitDepth == 8 else np.uint16
+        bpp = 1 if info.nBitDepth == 8 else 2
+        w, hh = info.nWidth, info.nHeight
+        planes = [np.zeros((hh, w), dt), np.zeros((hh // 2, w // 2), dt), np.zeros((hh // 2, w // 2), dt)]
+        fc = FrameCpy()
+        fc.pvY, fc.pvU, fc.pvV = (pl.ctypes.data for pl in planes)
+        fc.frameInfo = info
+        assert info.nYPitch == w * bpp, (info.nYPitch, w, bpp)
+        L.libOpenHevcGetOutputCpy(h, 1, C.byref(fc))
+        pics.append(planes)
+
+    aus = split_access_units(data)
+    for k, (a, b) in enumerate(aus):
+        got = L.libOpenHevcDecode(h, bytes(data[a:b]), b - a, k)
+        if got < 0:
+            L.libOpenHevcClose(h)
+            raise RuntimeError(f"reference decoder failed on access unit {k}")
+        if got:
+            grab()
+    while True:                                                # flush
+        got = L.libOpenHevcDecode(h, None, 0, 0)
+        if got <= 0:
+            break
+        grab()
+    L.libOpenHevcClose(h)
+    return pics
+
+
+class captured_stderr:
+    """what the C side (av_log) writes to file descriptor 2 inside the block; `.text` afterwards"""
+
+    def __enter__(self):
+        import tempfile
+        self.tmp = tempfile.TemporaryFile()
+        self.saved = os.dup(2)
+        os.dup2(self.tmp.fileno(), 2)
+        return self
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 2)
+        os.close(self.saved)
+        self.tmp.seek(0)
+        self.text = self.tmp.read().decode(errors="replace")
+        self.tmp.close()
+
+
+def md5_of(planes):
+    return [hashlib.md5(np.ascontiguousarray(pl).tobytes()).digest() for pl in planes]
+
+
+# ---- the reference decoder with this repository's recording hooks linked into its CTU loop (oracle/ref_hooked_unit.c) ----
+HOOKED_LIB = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hooked.so")
+_hlib = None
+
+
+def hooked_lib():
+    global _hlib
+    if _hlib is None:
+        if os.path.isdir(REF_TREE):
+            subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "refhooked"])
+        from openhevc_amd import frame as F
+        L = C.CDLL(HOOKED_LIB)
+        plain = lib()
+        for name in ("libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDecode", "libOpenHevcClose"):
+            getattr(L, name).argtypes = getattr(plain, name).argtypes
+            getattr(L, name).restype = getattr(plain, name).restype
+        L.ref_hooked_finish.restype = C.POINTER(F.OhFrame)
+        L.ref_hooked_finish.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _hlib = L
+    return _hlib
+
+
+def record_work_lists(data, on_picture):
+    """Decodes the stream with the reference's own decoder whose DSP tables hold this repository's RECORDING slots: every access
+    unit yields the work list of its picture.  on_picture(frame, cur_id, poc) is called while the recorder's arrays are valid
+    (until the next access unit); cur_id / frame.ref_pics are indices into the reference's DPB."""
+    L = hooked_lib()
+    h = C.c_void_p(L.libOpenHevcInit(1, 1))
+    assert L.libOpenHevcStartDecoder(h) == 1
+    n = 0
+    for k, (a, b) in enumerate(split_access_units(data)):
+        if L.libOpenHevcDecode(h, bytes(data[a:b]), b - a, k) < 0:
+            L.libOpenHevcClose(h)
+            raise RuntimeError(f"hooked reference decoder failed on access unit {k}")
+        cur, poc, bad = C.c_int(), C.c_int(), C.c_int()
+        f = L.ref_hooked_finish(C.byref(cur), C.byref(poc), C.byref(bad))
+        if f:
+            assert bad.value == 0, f"{bad.value} slot calls of picture {n} could not be translated into work-list items"
+            on_picture(f.contents, cur.value, poc.value)
+            n += 1
+    L.libOpenHevcClose(h)
+    return n

@@ -1,0 +1,80 @@
+"""ctypes view of the synthetic stream writer (include/ohevc_stream.h, openhevc_amd/synth/stream.c in libohevc_host.so)"""
+import ctypes as C
+
+from openhevc_amd import frame as F
+
+_FIELDS = ("width", "height", "bit_depth", "log2_ctb_size", "log2_min_tb_size", "log2_max_tb_size", "max_th_depth_intra", "max_th_depth_inter",
+           "n_pictures", "gop", "n_refs", "idr_period", "qp", "amp", "sao", "pcm", "transquant_bypass", "transform_skip", "cu_qp_delta", "tmvp",
+           "strong_intra_smoothing", "constrained_intra_pred", "scaling_list", "weighted_pred", "sign_data_hiding", "cabac_init_present",
+           "deblocking_override", "n_slices", "tile_cols", "tile_rows", "wpp", "dependent_slices", "lf_across_slices", "lf_across_tiles",
+           "split_pct", "intra_pct", "skip_pct", "merge_pct", "bi_pct", "cbf_pct", "pcm_pct", "bypass_pct", "tskip_pct", "sao_pct", "mvd_range",
+           "coeff_density")
+
+
+class OhStreamParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in _FIELDS] + [("trace", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+SE_NAMES = ("", "sao_merge", "sao_type", "sao_offset_abs", "sao_offset_sign", "sao_band_pos", "sao_eo_class", "end_of_slice", "split_cu", "bypass_flag",
+            "skip", "pred_mode", "part_mode", "pcm_flag", "prev_intra", "mpm_idx", "rem_intra", "chroma_mode", "merge_flag", "merge_idx", "inter_dir",
+            "ref_idx", "mvd_x", "mvd_y", "mvp", "root_cbf", "split_tu", "cbf_luma", "cbf_chroma", "qp_delta_abs", "qp_delta_sign", "residual")
+
+
+class OhStream(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_size_t), ("n_pictures", C.c_int32), ("au_offset", C.POINTER(C.c_size_t))]
+
+
+def _lib():
+    H = F.host()
+    H.oh_stream_defaults.argtypes = [C.POINTER(OhStreamParams), C.c_int, C.c_int, C.c_uint64]
+    H.oh_stream_write.argtypes = [C.POINTER(OhStreamParams), C.POINTER(OhStream)]
+    H.oh_stream_add_md5.argtypes = [C.POINTER(OhStream), C.c_char_p, C.POINTER(OhStream)]
+    H.oh_stream_free.argtypes = [C.POINTER(OhStream)]
+    H.oh_stream_trace.argtypes = [C.POINTER(C.POINTER(C.c_int32))]
+    H.oh_stream_trace.restype = C.c_size_t
+    return H
+
+
+def written_trace():
+    """[(id, value)] of the last write_stream(..., trace=1)"""
+    import numpy as np
+    H = _lib()
+    p = C.POINTER(C.c_int32)()
+    n = H.oh_stream_trace(C.byref(p))
+    a = np.ctypeslib.as_array(p, shape=(2 * n,)).reshape(n, 2).copy() if n else np.zeros((0, 2), np.int32)
+    return a
+
+
+def write_stream(width, height, seed, **kw):
+    """(bytes of the Annex-B stream, [access-unit byte ranges])"""
+    H = _lib()
+    sp = OhStreamParams()
+    H.oh_stream_defaults(C.byref(sp), width, height, seed)
+    for k, v in kw.items():
+        if not hasattr(sp, k):
+            raise AttributeError(k)
+        setattr(sp, k, v)
+    st = OhStream()
+    rc = H.oh_stream_write(C.byref(sp), C.byref(st))
+    if rc:
+        raise ValueError(f"oh_stream_write refused the parameters ({rc})")
+    data = bytes(C.string_at(st.data, st.size))
+    aus = [(st.au_offset[i], st.au_offset[i + 1]) for i in range(st.n_pictures)]
+    H.oh_stream_free(C.byref(st))
+    return data, aus
+
+
+def add_md5(data, aus, digests):
+    """the stream with a picture-hash SEI behind every picture; digests: per picture three 16-byte MD5s"""
+    H = _lib()
+    st = OhStream()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    off = (C.c_size_t * (len(aus) + 1))(*([a for a, _ in aus] + [aus[-1][1]]))
+    st.data, st.size, st.n_pictures, st.au_offset = C.cast(buf, C.POINTER(C.c_uint8)), len(data), len(aus), C.cast(off, C.POINTER(C.c_size_t))
+    out = OhStream()
+    blob = b"".join(b"".join(d) for d in digests)
+    assert H.oh_stream_add_md5(C.byref(st), blob, C.byref(out)) == 0
+    res = bytes(C.string_at(out.data, out.size))
+    res_aus = [(out.au_offset[i], out.au_offset[i + 1]) for i in range(out.n_pictures)]
+    H.oh_stream_free(C.byref(out))
+    return res, res_aus

@@ -1,0 +1,129 @@
+"""Whole streams through the reference's own decoder (container only: oracle/_ref is built from /root/reference).
+
+1. What the stream writer (openhevc_amd/synth/stream.c) wrote is what the reference PARSES, syntax element by syntax element
+   (oracle/ref_trace_unit.c logs the reference's CABAC calls).
+2. INTEGRATION.md for real: the reference's CTU loop with this repository's recording hooks in its DSP tables
+   (oracle/ref_hooked_unit.c) yields work lists; the checker's pictures from those lists equal the pictures the UNMODIFIED
+   reference decoder outputs — bit for bit, for every tool the writer covers.  This pins what earlier rounds could only restate:
+   the MC drivers (hevc.c:1641-1949), de-quantisation (hevc_cabac.c:1478-1494, 1818-1841), neighbour availability
+   (hevc.c:2592-2642), boundary strengths, SAO parsing, PCM / bypass, slices, tiles, wavefronts.
+3. The picture-hash SEI the writer appends is accepted by the reference's decode-checksum option."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import refdec
+import streamgen
+from openhevc_amd import frame as F
+from oracle_lib import host_pic_array, oracle
+
+pytestmark = pytest.mark.skipif(not refdec.have_refdec(), reason="reference tree / oracle/_ref not present")
+
+CASES = [
+    # name, w, h, seed, writer parameters
+    ("i_64", 64, 64, 1, dict(n_pictures=1, gop=0, sao=0, amp=0)),
+    ("intra", 416, 240, 7, dict(n_pictures=2, gop=0)),
+    ("low_delay_p", 416, 240, 7, dict(n_pictures=3, gop=1)),
+    ("low_delay_b", 416, 240, 7, dict(n_pictures=4, gop=2)),
+    ("pcm_bypass_tskip_qpdelta", 416, 240, 9, dict(n_pictures=3, gop=2, pcm=1, transquant_bypass=1, transform_skip=1, cu_qp_delta=1)),
+    ("main10_ctb32", 416, 240, 9, dict(n_pictures=3, gop=2, bit_depth=10, log2_ctb_size=5, pcm=1, transform_skip=1)),
+    ("ctb16", 416, 240, 9, dict(n_pictures=3, gop=2, log2_ctb_size=4, log2_max_tb_size=4, cu_qp_delta=1)),
+    ("slices", 416, 240, 9, dict(n_pictures=3, gop=2, n_slices=4)),
+    ("tiles", 416, 240, 9, dict(n_pictures=3, gop=2, tile_cols=3, tile_rows=2, log2_ctb_size=5)),
+    ("wpp", 416, 240, 9, dict(n_pictures=3, gop=2, wpp=1, log2_ctb_size=5)),
+    ("wpp_slices_ctb16", 416, 240, 9, dict(n_pictures=3, gop=2, wpp=1, n_slices=3, log2_ctb_size=4, log2_max_tb_size=4)),
+    ("tiles_slices_no_lf_across", 416, 240, 9, dict(n_pictures=3, gop=2, tile_cols=2, tile_rows=2, n_slices=3, log2_ctb_size=4, log2_max_tb_size=4,
+                                                  lf_across_tiles=0, lf_across_slices=0)),
+    ("weighted_cip_lists", 416, 240, 9, dict(n_pictures=3, gop=1, weighted_pred=1, scaling_list=1, constrained_intra_pred=1)),
+    ("tmvp_3refs", 416, 240, 9, dict(n_pictures=4, gop=2, tmvp=1, cabac_init_present=1, deblocking_override=1, n_refs=3)),
+    ("partial_ctbs", 200, 136, 5, dict(n_pictures=3, gop=2, n_slices=2, pcm=1)),
+    ("far_mvd", 264, 200, 6, dict(n_pictures=3, gop=2, mvd_range=4000, skip_pct=10, merge_pct=10)),
+]
+IDS = [c[0] for c in CASES]
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_writer_syntax_is_what_the_reference_parses(case):
+    _, w, h, seed, kw = case
+    data, aus = streamgen.write_stream(w, h, seed, trace=1, **kw)
+    wrote = streamgen.written_trace()
+    assert [tuple(a) for a in refdec.split_access_units(data)] == [tuple(a) for a in aus]
+    parsed = refdec.parsed_trace(data)
+    for flag in (7, 13):                                      # end_of_slice / pcm_flag: the reference returns a non-zero position for "1"
+        parsed[parsed[:, 0] == flag, 1] = parsed[parsed[:, 0] == flag, 1] != 0
+    assert len(wrote) == len(parsed), (len(wrote), len(parsed))
+    bad = np.nonzero((wrote != parsed).any(axis=1))[0]
+    assert len(bad) == 0, f"element {bad[0]}: wrote {streamgen.SE_NAMES[wrote[bad[0], 0]]}={wrote[bad[0], 1]}, parsed {streamgen.SE_NAMES[parsed[bad[0], 0]]}={parsed[bad[0], 1]}"
+    assert len(wrote) > 20
+
+
+def decode_through_hooks(data):
+    """pictures (decode order) reconstructed by the CHECKER from the work lists the hooked reference decoder records"""
+    pics, got = {}, []
+
+    def on_picture(f, cur, poc):
+        for i in [cur] + [f.ref_pics[k] for k in range(F.OH_MAX_REFS) if f.ref_pics[k] >= 0]:
+            if i not in pics:
+                pics[i] = F.HostPic(f.p)
+        assert oracle().oh_or_frame(C.byref(f), host_pic_array(pics)) == 0
+        got.append([pics[cur].visible(c).copy() for c in range(3)])
+    refdec.record_work_lists(data, on_picture)
+    return got
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_hooked_ctu_loop_reproduces_the_reference_decoder(case):
+    _, w, h, seed, kw = case
+    data, _ = streamgen.write_stream(w, h, seed, **kw)
+    want = refdec.decode(data)
+    got = decode_through_hooks(data)
+    assert len(got) == len(want) == kw["n_pictures"]
+    for k in range(len(want)):
+        for c in range(3):
+            assert np.array_equal(want[k][c], got[k][c]), (case[0], "picture", k, "plane", c)
+
+
+def test_picture_hash_sei_is_accepted_by_the_reference():
+    data, aus = streamgen.write_stream(264, 200, 21, n_pictures=3, gop=2, bit_depth=10)
+    pics = refdec.decode(data)
+    with_sei, aus2 = streamgen.add_md5(data, aus, [refdec.md5_of(p) for p in pics])
+    assert len(with_sei) == len(data) + 3 * (4 + 2 + 51 + 1)                      # start code, NAL header, payload, trailing byte
+    assert [tuple(a) for a in refdec.split_access_units(with_sei)] == [tuple(a) for a in aus2]      # a suffix SEI stays in its picture's AU
+    with refdec.captured_stderr() as log:                                           # hevc.c:4144-4162: the verdict is logged per plane
+        again = refdec.decode(with_sei, check_md5=True)
+    assert all(np.array_equal(a[c], b[c]) for a, b in zip(pics, again) for c in range(3))
+    assert log.text.count("Correct MD5") == 9 and "Incorrect MD5" not in log.text
+    wrong = [refdec.md5_of(p) for p in pics]
+    wrong[1] = [bytes(16)] * 3
+    bad, _ = streamgen.add_md5(data, aus, wrong)
+    with refdec.captured_stderr() as log:
+        refdec.decode(bad, check_md5=True)
+    assert log.text.count("Incorrect MD5") == 3 and log.text.count("Correct MD5") == 6
+
+
+def test_reference_threading_modes_agree():
+    """the reference's frame / slice threads (pthread_frame.c, pthread_slice.c incl. its wavefront entry points) output what
+    its single-threaded decode outputs: the streams exercise them too"""
+    data, _ = streamgen.write_stream(416, 240, 31, n_pictures=4, gop=2, wpp=1, log2_ctb_size=4, log2_max_tb_size=4)
+    one = refdec.decode(data)
+    for threads, kind in ((4, 1), (4, 2)):
+        other = refdec.decode(data, threads=threads, thread_type=kind)
+        assert len(other) == len(one)
+        assert all(np.array_equal(a[c], b[c]) for a, b in zip(one, other) for c in range(3)), (threads, kind)
+
+
+def test_committed_fixtures_are_current():
+    """tests/golden/streams/*.npz = what make_stream_golden.py produces today (writer, hooks and reference unchanged)"""
+    import hashlib
+    import os
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import make_stream_golden as M
+    for name, w, h, seed, kw in M.STREAM_CASES:
+        have = np.load(os.path.join(gold, "streams", name + ".npz"))
+        data, _ = streamgen.write_stream(w, h, seed, **kw)
+        assert hashlib.md5(data).digest() == have["stream_md5"].tobytes(), name
+        want = refdec.decode(data)
+        assert b"".join(b"".join(refdec.md5_of(p)) for p in want) == have["md5"].tobytes(), name

@@ -66,6 +66,65 @@ def cpu_baseline(params, plan_kwargs, budget_s=12.0):
                 sample=f"{steps} GOP(s) = {pics} pictures of the same synthetic stream in {dt:.1f} s, single thread, {what}")
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def decoder_baseline(params, n_pictures=16):
+    """The reference's WHOLE decoder (oracle/_ref/libopenhevc_ref.so = its libavutil + libavcodec HEVC files + libOpenHevc* wrapper, built in
+    the container from the sources where they lie; _sse: the same with the tree's SSE4 intrinsics in the tables, deblocking in C) on a
+    synthetic stream of the workload's geometry written by openhevc_amd/synth/stream.c: 1 thread and all host threads
+    (slice threads over the stream's wavefront entry points, pthread_slice.c).  BASELINE.json north_star: "openHEVC's own CPU path (C and SSE4)
+    on synthetic streams".  Returns None when the libraries did not travel."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refdec
+    import streamgen
+    if not (os.path.exists(refdec.LIB) or os.path.isdir(refdec.REF_TREE)):
+        return None
+    if params.chroma_format_idc != 1:
+        return None
+    cores = len(os.sched_getaffinity(0))
+    t0 = time.perf_counter()
+    data, aus = streamgen.write_stream(params.width, params.height, 5, n_pictures=n_pictures, gop=2, bit_depth=params.bit_depth, wpp=1)
+    t_write = time.perf_counter() - t0
+    mpix = n_pictures * params.width * params.height / 1e6
+    out = dict(cpu_model=cpu_model(), host_threads=cores,
+               stream=f"{n_pictures} pictures {params.width}x{params.height} {params.bit_depth} bit, IDR + low-delay B (2 references), 64x64 CTBs, wavefront entry points, "
+                      f"SAO + deblocking on, {len(data) / 1e6:.1f} MB (written in {t_write:.1f} s)")
+
+    def run(L, threads, kind, reps):
+        best = None
+        for _ in range(reps):
+            t = time.perf_counter()
+            pics = refdec.decode(data, threads=threads, thread_type=kind, L=L, keep=False)
+            dt = time.perf_counter() - t
+            assert len(pics) == n_pictures, (len(pics), n_pictures)
+            best = dt if best is None else min(best, dt)
+        return dict(Mpixels_per_s=round(mpix / best, 1), fps=round(n_pictures / best, 2), threads=threads)
+
+    devnull = os.open(os.devnull, os.O_WRONLY)               # the wrapper prints its thread count on every open
+    saved = os.dup(2)
+    os.dup2(devnull, 2)
+    try:
+        out["c_1t"] = run(refdec.lib(), 1, 1, 1)
+        out["c_Nt"] = run(refdec.lib(), cores, 2, 2)
+        if os.path.exists(refdec.SSE_LIB) or os.path.isdir(refdec.REF_TREE):
+            out["sse_1t"] = run(refdec.sse_lib(), 1, 1, 1)
+            out["sse_Nt"] = run(refdec.sse_lib(), cores, 2, 2)
+    finally:
+        os.dup2(saved, 2)
+        os.close(saved)
+        os.close(devnull)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,6 +425,13 @@ def main():
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, plan_kwargs)
+            dec = decoder_baseline(params)
+            if dec is not None:
+                out["cpu_baseline"]["whole_decoder"] = dec
+                for k in ("c_1t", "c_Nt", "sse_1t", "sse_Nt"):
+                    if k in dec:
+                        out["cpu_baseline"][k] = dec[k]["Mpixels_per_s"]
+                out["cpu_baseline"]["cpu_model"] = dec["cpu_model"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -35,6 +35,47 @@
 #undef  HAVE_GMTIME_R
 #define HAVE_GMTIME_R 1
 
+/* the SSE4 variant (oracle/Makefile `refdec_sse`): only hevcdsp.c, hevcpred.c, hevc_filter.c and the x86/ intrinsics files are
+ * compiled with -DOH_REF_X86, which turns on the `if (ARCH_X86) ff_hevcdsp_init_x86(...)` hooks (hevcdsp.c:1326, hevcpred.c:84)
+ * and the HAVE_SSE* blocks; every other file keeps the portable configuration above.  No assembler: *_EXTERNAL only gates the
+ * EXTERNAL_SSE2(flags)-style tests of x86/hevcdsp_init.c (libavutil/x86/cpu.h), see ref_x86dsp_unit.c for the yasm symbols. */
+#ifdef OH_REF_X86
+#undef  ARCH_X86
+#define ARCH_X86 1
+#undef  ARCH_X86_64
+#define ARCH_X86_64 1
+#undef  ARCH_X86_32
+#define ARCH_X86_32 0
+#undef  HAVE_MMX
+#define HAVE_MMX 1
+#undef  HAVE_MMX_EXTERNAL
+#define HAVE_MMX_EXTERNAL 1
+#undef  HAVE_MMXEXT
+#define HAVE_MMXEXT 1
+#undef  HAVE_MMXEXT_EXTERNAL
+#define HAVE_MMXEXT_EXTERNAL 1
+#undef  HAVE_SSE
+#define HAVE_SSE 1
+#undef  HAVE_SSE2
+#define HAVE_SSE2 1
+#undef  HAVE_SSE2_EXTERNAL
+#define HAVE_SSE2_EXTERNAL 1
+#undef  HAVE_SSE3
+#define HAVE_SSE3 1
+#undef  HAVE_SSSE3
+#define HAVE_SSSE3 1
+#undef  HAVE_SSSE3_EXTERNAL
+#define HAVE_SSSE3_EXTERNAL 1
+#undef  HAVE_SSE4
+#define HAVE_SSE4 1
+#undef  HAVE_SSE4_EXTERNAL
+#define HAVE_SSE4_EXTERNAL 1
+#undef  HAVE_SSE42
+#define HAVE_SSE42 1
+#undef  HAVE_SSE42_EXTERNAL
+#define HAVE_SSE42_EXTERNAL 1
+#endif
+
 /* hevc_filter.c reports row progress to frame threads (hevc_filter.c:1040-1050); the harness
  * runs with threads_type == 0, so these are never called.  Declaring the references weak lets
  * the shared object load without pthread_frame.c — no replacement definition is provided. */

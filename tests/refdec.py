@@ -120,16 +120,39 @@ def split_access_units(data):
     return aus
 
 
-def decode(data, threads=1, thread_type=1, check_md5=False):
+SSE_LIB = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_ref_sse.so")
+_slib = None
+
+
+def sse_lib():
+    """the same decoder with the reference's SSE4 intrinsics in its tables (oracle/Makefile `refdec_sse`, oracle/ref_x86dsp_unit.c)"""
+    global _slib
+    if _slib is None:
+        if os.path.isdir(REF_TREE):
+            subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "refdec_sse"])
+        plain = lib()
+        L = C.CDLL(SSE_LIB)
+        for name in ("libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDecode", "libOpenHevcGetPictureInfoCpy", "libOpenHevcGetOutputCpy",
+                     "libOpenHevcSetCheckMD5", "libOpenHevcSetDebugMode", "libOpenHevcClose"):
+            getattr(L, name).argtypes = getattr(plain, name).argtypes
+            getattr(L, name).restype = getattr(plain, name).restype
+        _slib = L
+    return _slib
+
+
+def decode(data, threads=1, thread_type=1, check_md5=False, L=None, keep=True):
     """decodes an Annex-B stream access unit by access unit through the libOpenHevc* API; returns the output pictures as lists of
-    numpy planes (cropped, packed) in output order"""
-    L = lib()
+    numpy planes (cropped, packed) in output order (keep=False: only None per output picture — timing runs)"""
+    L = L or lib()
     h = C.c_void_p(L.libOpenHevcInit(threads, thread_type))
     assert L.libOpenHevcStartDecoder(h) == 1
     L.libOpenHevcSetCheckMD5(h, int(check_md5))
     pics = []
 
     def grab():
+        if not keep:
+            pics.append(None)
+            return
         info = FrameInfo()
         L.libOpenHevcGetPictureInfoCpy(h, C.byref(info))
         dt = np.uint8 if info.nBitDepth == 8 else np.uint16

@@ -113,6 +113,19 @@ def test_reference_threading_modes_agree():
         assert all(np.array_equal(a[c], b[c]) for a, b in zip(one, other) for c in range(3)), (threads, kind)
 
 
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_reference_sse_build_agrees_with_its_c_build(bit_depth):
+    """oracle/_ref/libopenhevc_ref_sse.so (the tree's SSE4 intrinsics in the tables, bench.py's cpu_baseline.sse_*) decodes what the C
+    build decodes, bit for bit: the baseline timed is a correct decoder"""
+    for seed in (41, 42):
+        data, _ = streamgen.write_stream(416, 240, seed, n_pictures=5, gop=2, bit_depth=bit_depth, amp=1, pcm=1, transform_skip=1,
+                                         weighted_pred=int(seed == 42), wpp=1)
+        want = refdec.decode(data)
+        got = refdec.decode(data, L=refdec.sse_lib(), threads=3, thread_type=2)
+        assert len(got) == len(want) == 5
+        assert all(np.array_equal(a[c], b[c]) for a, b in zip(want, got) for c in range(3))
+
+
 def test_committed_fixtures_are_current():
     """tests/golden/streams/*.npz = what make_stream_golden.py produces today (writer, hooks and reference unchanged)"""
     import hashlib

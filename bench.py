@@ -90,7 +90,7 @@ def decoder_baseline(params, n_pictures=16):
         return None
     if params.chroma_format_idc != 1:
         return None
-    cores = len(os.sched_getaffinity(0))
+    cores = min(len(os.sched_getaffinity(0)), 16)            # pthread_internal.h:26 MAX_AUTO_THREADS 16: the reference's slice-thread tables end there
     t0 = time.perf_counter()
     data, aus = streamgen.write_stream(params.width, params.height, 5, n_pictures=n_pictures, gop=2, bit_depth=params.bit_depth, wpp=1)
     t_write = time.perf_counter() - t0

@@ -86,6 +86,10 @@ int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3], const ptr
 typedef struct OhWindow { int32_t left, right, top, bottom; } OhWindow;     /* luma samples, as HEVCWindow after hevc_ps.c scaled it */
 int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *win, uint8_t *const planes[3], const ptrdiff_t strides[3]);
 
+/* MD5 of the three planes of n finished pictures computed on the GPU — the digests of the decoded-picture-hash SEI (hevc.c:4146-4162,
+ * calc_md5 hevc.c:4623-4638: whole coded planes, rows packed, little-endian samples).  digests: n x 3 x 16 bytes.  Waits for the engine. */
+int oh_pics_md5(OhEngine *e, const int *pic_ids, int n, uint8_t *digests);
+
 /* SHVC inter-layer reference picture: resample the finished base-layer picture src_pic into
  * the enhancement-layer picture dst_pic, bit-exact with the reference's whole-picture slot
  * HEVCDSPContext.upsample_base_layer_frame (hevcdsp_template.c:2164-2438, call site hevc.c:3241).

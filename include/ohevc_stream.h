@@ -36,7 +36,7 @@ typedef struct OhStreamParams {
     int32_t qp;                         /* slice QP */
     /* tools (0 / 1) */
     int32_t amp, sao, pcm, transquant_bypass, transform_skip, cu_qp_delta, tmvp, strong_intra_smoothing, constrained_intra_pred,
-            scaling_list, weighted_pred, sign_data_hiding, cabac_init_present, deblocking_override;
+            scaling_list /* 1 default lists, 2 random lists in the SPS */, weighted_pred, sign_data_hiding, cabac_init_present, deblocking_override;
     /* picture structure */
     int32_t n_slices;                   /* slices per picture (>= 1), at random CTB addresses (whole tiles when tiles are on) */
     int32_t tile_cols, tile_rows;       /* > 1: uniformly spaced tiles */
@@ -48,7 +48,8 @@ typedef struct OhStreamParams {
     int32_t mvd_range;                  /* |mvd| bound in quarter samples; occasionally far larger */
     int32_t coeff_density;              /* 1..100: how many coefficients a coded block gets */
     int32_t trace;                      /* 1: keep the list of syntax elements written (oh_stream_trace) */
-    int32_t reserved[7];
+    int32_t levels;                     /* 1: keep the quantised levels of every residual block written (oh_stream_levels); needs cu_qp_delta = 0 */
+    int32_t reserved[6];
 } OhStreamParams;
 
 /* syntax elements of the slice data as (id, value) pairs in coding order — the writer's side of tests/test_streams.py; the ids are
@@ -58,6 +59,14 @@ enum { OH_SE_SAO_MERGE = 1, OH_SE_SAO_TYPE, OH_SE_SAO_OFFSET_ABS, OH_SE_SAO_OFFS
        OH_SE_REM_INTRA, OH_SE_CHROMA_MODE, OH_SE_MERGE_FLAG, OH_SE_MERGE_IDX, OH_SE_INTER_DIR, OH_SE_REF_IDX, OH_SE_MVD_X, OH_SE_MVD_Y, OH_SE_MVP,
        OH_SE_ROOT_CBF, OH_SE_SPLIT_TU, OH_SE_CBF_LUMA, OH_SE_CBF_CHROMA, OH_SE_QP_DELTA_ABS, OH_SE_QP_DELTA_SIGN, OH_SE_RESIDUAL };
 size_t oh_stream_trace(const int32_t **recs);            /* of the last oh_stream_write with trace = 1; pairs (id, value) */
+
+/* the residual blocks of the last oh_stream_write with levels = 1, in coding order, pictures one after the other, as uint32 words:
+ *   log2_size | c_idx << 4 | transform_skip << 8 | cu_transquant_bypass << 9 | intra CU << 10 | qp << 16     qp: the block's QP with QpBdOffset
+ *   n                                                                                                       number of non-zero levels
+ *   n x (pos | (uint16_t)level << 16)                                                                       pos = y * N + x
+ * — what residual_coding hands to de-quantisation (hevc_cabac.c:1478-1494, 1818-1841): the sparse hand-over of include/ohevc_frame.h is
+ * built from this in tests/test_sparse_pin.py and must reproduce the reference decoder's pictures. */
+size_t oh_stream_levels(const uint32_t **words);
 
 typedef struct OhStream {
     uint8_t *data;                      /* Annex-B byte stream (start codes included) */

@@ -590,6 +590,48 @@ extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *w
     return OH_OK;
 }
 
+/* Picture hash on the GPU: the three plane digests of the reference's SEI check (hevc.c:4146-4162 over calc_md5,
+ * hevc.c:4623-4638: the whole coded planes, sps->width x sps->height and the chroma sizes, packed rows) for n finished pictures in one
+ * launch of one chain per (picture, plane) — md5.hip.  48 bytes per picture come back instead of the picture.  Waits for the engine
+ * stream.  digests: n x 3 x 16 bytes (monochrome: planes 1, 2 zero). */
+extern "C" int oh_pics_md5(OhEngine *e, const int *pic_ids, int n, uint8_t *digests)
+{
+    if (!e || n < 0 || (n && (!pic_ids || !digests)))
+        return OH_E_ARG;
+    if (!n)
+        return OH_OK;
+    for (int i = 0; i < n; i++)
+        if (!get_pic(e, pic_ids[i]))
+            FAIL(e, OH_E_ARG, "oh_pics_md5: unknown picture %d", pic_ids[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t jobs_bytes = align_up((size_t)n * 3 * sizeof(OhMd5Job), 256);
+    OhEngine::Stage *sg = stage_acquire(e, jobs_bytes + (size_t)n * 48);
+    if (!sg)
+        FAIL(e, OH_E_NOMEM, "hipHostMalloc for %d picture hashes failed", n);
+    OhMd5Job *jobs = (OhMd5Job *)sg->p;
+    uint8_t *out = (uint8_t *)sg->p + jobs_bytes;
+    int nj = 0;
+    std::vector<int> slot((size_t)n * 3, -1);
+    for (int i = 0; i < n; i++) {
+        const Pic *p = get_pic(e, pic_ids[i]);
+        const uint32_t bpp = p->p.bit_depth > 8 ? 2 : 1;
+        for (int c = 0; c < (p->p.chroma_format_idc ? 3 : 1); c++) {
+            OhMd5Job &j = jobs[nj];
+            j.base = p->final_b ? p->b[c] : p->a[c];
+            j.pitch = (uint32_t)p->stride[c] * bpp; j.row_bytes = (uint32_t)p->w[c] * bpp; j.rows = (uint32_t)p->h[c]; j.pad = 0;
+            slot[(size_t)i * 3 + c] = nj++;
+        }
+    }
+    ohk_md5(jobs, nj, out, e->stream);                        /* pinned host memory is mapped: the kernel reads the jobs and writes the digests there */
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (size_t k = 0; k < slot.size(); k++) {
+        if (slot[k] >= 0) memcpy(digests + k * 16, out + (size_t)slot[k] * 16, 16);
+        else memset(digests + k * 16, 0, 16);
+    }
+    return OH_OK;
+}
+
 extern "C" int oh_pic_device_planes(OhEngine *e, int pic_id, void *planes[3], int32_t stride[3], int32_t width[3], int32_t height[3])
 {
     if (!e)

@@ -5,8 +5,18 @@
 #include <hip/hip_runtime.h>
 #include "dev_frame.h"
 
+/* one MD5 chain: a plane's packed rows (md5.hip) */
+struct OhMd5Job {
+    const void *base;            /* first sample of the plane */
+    uint32_t    pitch;           /* bytes between rows */
+    uint32_t    row_bytes;       /* bytes hashed per row */
+    uint32_t    rows;
+    uint32_t    pad;
+};
+
 extern "C" {
 int  ohk_init(void);
+void ohk_md5(const OhMd5Job *jobs, int n, void *digests, hipStream_t st);
 void ohk_inter(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_luma, uint32_t max_chroma, hipStream_t st);
 void ohk_residual(const OhBatch *B, int n, const OhPicParams *p, const uint32_t max_cnt[4], hipStream_t st);
 void ohk_cross(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_cross, hipStream_t st);

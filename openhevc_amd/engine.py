@@ -57,6 +57,7 @@ def lib():
         L.oh_pic_upload.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download_window.argtypes = [V, I, C.POINTER(OhWindow), C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
+        L.oh_pics_md5.argtypes = [V, C.POINTER(C.c_int), I, C.POINTER(C.c_uint8)]
         L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
         L.oh_frames_upload.argtypes = [V, C.POINTER(C.POINTER(F.OhFrame)), I, PP]
         L.oh_frame_execute.argtypes = [V, V]
@@ -167,6 +168,15 @@ class Engine:
         win = OhWindow(left, right, top, bottom)
         self._chk(self.L.oh_pic_download_window(self.h, pid, C.byref(win), d, s), "oh_pic_download_window")
         return [pl[:, :pl.shape[1] - pad // dt().itemsize] if pad else pl for pl in planes]
+
+    def pics_md5(self, pids):
+        """[[16-byte MD5 of plane 0, 1, 2]] of finished pictures, computed on the GPU (oh_pics_md5)"""
+        n = len(pids)
+        ids = (C.c_int * max(n, 1))(*pids)
+        out = (C.c_uint8 * (48 * max(n, 1)))()
+        self._chk(self.L.oh_pics_md5(self.h, ids, n, out), "oh_pics_md5")
+        raw = bytes(out)
+        return [[raw[48 * i + 16 * c:48 * i + 16 * c + 16] for c in range(3)] for i in range(n)]
 
     def pic_device_planes(self, pid):
         p = (C.c_void_p * 3)()

@@ -198,6 +198,28 @@ static void tr(int id, int v)
 }
 size_t oh_stream_trace(const int32_t **recs) { *recs = g_trace; return g_trace_n / 2; }
 
+/* the quantised levels of every residual block written, for the sparse hand-over (OhStreamParams.levels, include/ohevc_stream.h) */
+static uint32_t *g_lev;
+static size_t g_lev_n, g_lev_cap;
+static int g_lev_on;
+static void lev_put(uint32_t v)
+{
+    if (g_lev_n + 1 > g_lev_cap) { g_lev_cap = g_lev_cap ? 2 * g_lev_cap : 1 << 16; g_lev = (uint32_t *)realloc(g_lev, g_lev_cap * sizeof(uint32_t)); }
+    g_lev[g_lev_n++] = v;
+}
+size_t oh_stream_levels(const uint32_t **words) { *words = g_lev; return g_lev_n; }
+
+/* chroma QP of a block (8.6.1: qPi -> QpC for ChromaArrayType 1); the writer's PPS carries cb / cr offsets +1 / -2, no slice offsets */
+static int chroma_qp(int qp_y, int c_idx, int bit_depth)
+{
+    static const uint8_t tab[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };     /* qPi 30..43 */
+    const int bd_off = 6 * (bit_depth - 8);
+    int qpi = qp_y + (c_idx == 1 ? 1 : -2);
+    qpi = qpi < -bd_off ? -bd_off : qpi > 57 ? 57 : qpi;
+    const int qpc = qpi < 30 ? qpi : qpi >= 43 ? qpi - 6 : tab[qpi - 30];
+    return qpc + bd_off;
+}
+
 /* ================================================================================================= generator state */
 typedef struct Rng { uint64_t s; } Rng;
 static uint64_t rnd64(Rng *g)
@@ -303,7 +325,35 @@ static void write_sps(W *w)
     put_ue(&b, (uint32_t)(p->log2_max_tb_size - p->log2_min_tb_size));
     put_ue(&b, (uint32_t)p->max_th_depth_inter); put_ue(&b, (uint32_t)p->max_th_depth_intra);
     put_bit(&b, p->scaling_list != 0);
-    if (p->scaling_list) put_bit(&b, 0);                   /* default lists */
+    if (p->scaling_list) {
+        put_bit(&b, p->scaling_list > 1);                  /* sps_scaling_list_data_present_flag: 0 = the default lists */
+        if (p->scaling_list > 1) {                         /* scaling_list_data() 7.3.4 with random lists */
+            Rng sg = { p->seed * 0x9E3779B97F4A7C15ull + 4242 };
+            for (int size_id = 0; size_id < 4; size_id++)
+                for (int matrix_id = 0; matrix_id < 6; matrix_id += size_id == 3 ? 3 : 1) {
+                    const int kind = rnd(&sg, 4);          /* 0: the default list, 1: copy of the previous matrix, else explicit */
+                    if (kind < 2) {
+                        put_bit(&b, 0);
+                        put_ue(&b, kind == 1 && matrix_id && size_id != 3 ? 1 : 0);   /* scaling_list_pred_matrix_id_delta; 0 = the default list */
+                        continue;
+                    }
+                    put_bit(&b, 1);
+                    int next = 8;
+                    if (size_id > 1) { const int dc = 1 + rnd(&sg, 64); put_se(&b, dc - 8); next = dc; }
+                    const int coef_num = size_id == 0 ? 16 : 64;
+                    for (int i = 0; i < coef_num; i++) {
+                        int v = next + rnd(&sg, 33) - 16;
+                        if (rnd(&sg, 16) == 0) v = 1 + rnd(&sg, 255);
+                        v = v < 1 ? 1 : v > 255 ? 255 : v;
+                        int d = v - next;
+                        if (d > 127) d -= 256;
+                        if (d < -128) d += 256;
+                        put_se(&b, d);
+                        next = v;
+                    }
+                }
+        }
+    }
     put_bit(&b, p->amp != 0);
     put_bit(&b, p->sao != 0);
     put_bit(&b, p->pcm != 0);
@@ -481,8 +531,11 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
         }
     }
     tr(OH_SE_RESIDUAL, log2 | (c_idx << 4) | (scan << 8));
-    if (w->p->transform_skip && !w->cu_bypass && log2 == 2)
-        enc_bin(c, C_TSKIP + (c_idx ? 1 : 0), pct(g, w->p->tskip_pct));
+    int tskip = 0;
+    if (w->p->transform_skip && !w->cu_bypass && log2 == 2) {
+        tskip = pct(g, w->p->tskip_pct);
+        enc_bin(c, C_TSKIP + (c_idx ? 1 : 0), tskip);
+    }
     /* last significant coefficient in scan order */
     int last_sb = -1, last_pos = -1, lx = 0, ly = 0;
     const int n_sb = 1 << (2 * n_sb_log2);
@@ -496,6 +549,18 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
         }
     }
     if (last_sb < 0) { lev[0] = 1; last_sb = 0; last_pos = 0; lx = ly = 0; }
+    if (g_lev_on) {
+        /* header: log2 | c_idx << 4 | transform_skip << 8 | cu_transquant_bypass << 9 | intra CU << 10 | QP (with QpBdOffset; valid while
+         * cu_qp_delta is off: the slice QP) << 16; then the number of levels; then pos | level << 16 in raster order */
+        const int bd_off = 6 * (w->p->bit_depth - 8);
+        const int qp = c_idx ? chroma_qp(w->sl.qp, c_idx, w->p->bit_depth) : w->sl.qp + bd_off;
+        lev_put((uint32_t)log2 | (uint32_t)c_idx << 4 | (uint32_t)tskip << 8 | (uint32_t)(w->cu_bypass != 0) << 9 | (uint32_t)(cu_intra != 0) << 10 | (uint32_t)qp << 16);
+        uint32_t cnt = 0;
+        for (int i = 0; i < n * n; i++) cnt += lev[i] != 0;
+        lev_put(cnt);
+        for (int i = 0; i < n * n; i++)
+            if (lev[i]) lev_put((uint32_t)i | (uint32_t)(uint16_t)lev[i] << 16);
+    }
     {
         int cx = lx, cy = ly;
         if (scan == 2) { cx = ly; cy = lx; }               /* coded swapped for the vertical scan */
@@ -597,7 +662,6 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
             }
         }
     }
-    (void)cu_intra;
 }
 
 /* ---- transform tree ---- */
@@ -1139,6 +1203,7 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     memset(&w, 0, sizeof(w));
     w.p = p;
     g_trace_on = p->trace != 0; g_trace_n = 0;
+    g_lev_on = p->levels != 0 && !p->cu_qp_delta; g_lev_n = 0;
     w.g.s = p->seed * 0x2545F4914F6CDD1Dull + 77;
     w.lc = p->log2_ctb_size; w.ctb = 1 << w.lc;
     w.ctbw = (p->width + w.ctb - 1) >> w.lc; w.ctbh = (p->height + w.ctb - 1) >> w.lc; w.n_ctb = w.ctbw * w.ctbh;

@@ -40,6 +40,8 @@ static struct {
     int open;                         /* a picture was started and not finished yet */
     int cur_id, n_refs, ref_ids[OH_MAX_REFS];
     int untranslated;
+    int scaling_on;
+    OhScalingList scaling;
 } H;
 
 /* INTEGRATION.md §3 */
@@ -149,7 +151,23 @@ __attribute__((visibility("default"))) const OhFrame *ref_hooked_finish(int *cur
         m->tile_id[ctb] = s->pps->tile_id[s->pps->ctb_addr_rs_to_ts[ctb]];
         m->deblock_disabled[ctb] = 0;                      /* such slices simply derive no boundary strengths (hevc.c:1577) */
     }
+    /* the scaling lists in force (hevc_cabac.c:1480-1483 picks the PPS's when it carries its own): kept for ref_hooked_scaling_list */
+    H.scaling_on = sps->scaling_list_enable_flag;
+    if (H.scaling_on) {
+        const ScalingList *sl = s->pps->scaling_list_data_present_flag ? &s->pps->scaling_list : &sps->scaling_list;
+        memcpy(H.scaling.sl, sl->sl, sizeof(H.scaling.sl));
+        memcpy(H.scaling.sl_dc, sl->sl_dc, sizeof(H.scaling.sl_dc));
+    }
     return oh_rec_finish(H.rec);
+}
+
+/* the scaling lists of the picture ref_hooked_finish just returned (as the decoder holds them after hevc_ps.c parsed or defaulted
+ * them); returns 0 when the SPS has them off (flat 16).  tests/test_sparse_pin.py hands them over with the sparse levels. */
+__attribute__((visibility("default"))) int ref_hooked_scaling_list(OhScalingList *out)
+{
+    if (H.scaling_on)
+        *out = H.scaling;
+    return H.scaling_on;
 }
 
 #define ff_hevc_dsp_init(c, bd)   do { ff_hevc_dsp_init(c, bd);  ff_hevcdsp_init_hip((void *)(c), bd); } while (0)

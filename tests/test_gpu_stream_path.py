@@ -1,0 +1,111 @@
+"""-m gpu: the byte-stream side on the MI355X — picture MD5s computed on the GPU against hashlib, and the command-line harness
+(openhevc_amd/ohevc_dec) decoding written streams end to end: Annex-B file -> access units -> front end (the reference's host
+decoder with this repository's recording table slots linked in: oracle/_ref/libopenhevc_hooked.so, built in the container)
+-> work lists -> GPU passes -> GPU MD5 against the stream's picture-hash SEI, whose digests come from the reference decoder."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+from openhevc_amd import frame as F
+
+pytestmark = pytest.mark.gpu
+
+
+def params(w, h, bd, cf):
+    return F.pic_params(w, h, bit_depth=bd, chroma_format_idc=cf)
+
+
+@pytest.mark.parametrize("w,h,bd,cf", [(64, 64, 8, 1), (416, 240, 8, 1), (416, 240, 10, 1), (200, 136, 10, 3), (264, 200, 8, 2), (72, 40, 8, 0),
+                                        (1920, 1080, 10, 1), (8, 8, 8, 1), (24, 8, 8, 1)])
+def test_picture_md5_on_the_gpu_is_hashlib_md5(w, h, bd, cf):
+    """oh_pics_md5 == MD5 of the packed rows of each plane (calc_md5, hevc.c:4623-4638), several pictures per launch; the sizes cover
+    messages that end exactly on a block boundary, one-block messages (8x8 chroma = 16 bytes) and rows that are not a multiple of 64 bytes"""
+    from openhevc_amd.engine import Engine
+    rng = np.random.default_rng(w * 131 + h * 7 + bd + cf)
+    eng = Engine(0)
+    p = params(w, h, bd, cf)
+    pids, want = [], []
+    for k in range(3):
+        hp = F.HostPic(p)
+        for c in range(F.n_planes(p)):
+            v = hp.visible(c)
+            v[...] = rng.integers(0, 1 << bd, v.shape, dtype=v.dtype)
+        pid = eng.pic_alloc(p)
+        eng.pic_upload(pid, hp)
+        pids.append(pid)
+        want.append([hashlib.md5(np.ascontiguousarray(hp.visible(c)).tobytes()).digest() if c < F.n_planes(p) else bytes(16) for c in range(3)])
+    got = eng.pics_md5(pids)
+    eng.close()
+    assert got == want
+
+
+def test_picture_md5_follows_the_finished_half():
+    """after a work list with SAO the finished picture lives in the other half of the allocation: the hash is of what oh_pic_download returns"""
+    from openhevc_amd.engine import Engine, remap_frame
+    eng = Engine(0)
+    rec = F.Recorder(params(416, 240, 8, 1))
+    f = rec.synth(F.synth_params(0, 3, sao_pct=90), 0)
+    pid = eng.pic_alloc(f.p)
+    eng.frame_submit(remap_frame(f, {0: pid}))
+    assert eng.pic_final_half(pid) == 1
+    hp = eng.pic_download(pid, f.p)
+    want = [hashlib.md5(np.ascontiguousarray(hp.visible(c)).tobytes()).digest() for c in range(3)]
+    assert eng.pics_md5([pid]) == [want]
+    eng.close()
+    rec.close()
+
+
+HOOKED = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hooked.so")
+REFDEC = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_ref.so")
+HARNESS = os.path.join(ROOT, "openhevc_amd", "ohevc_dec")
+need_front_end = pytest.mark.skipif(not (os.path.exists(HOOKED) and os.path.exists(REFDEC) and os.path.exists(HARNESS)),
+                                    reason="oracle/_ref front end / harness binary did not travel")
+
+STREAMS = [
+    ("main8_lowdelay", 416, 240, 11, dict(n_pictures=8, gop=2)),
+    ("main10_tools", 416, 240, 12, dict(n_pictures=6, gop=2, bit_depth=10, amp=1, pcm=1, transform_skip=1, transquant_bypass=1, weighted_pred=1, scaling_list=1)),
+    ("slices_tiles", 416, 240, 13, dict(n_pictures=5, gop=1, n_slices=3, tile_cols=2, tile_rows=2, lf_across_tiles=0)),
+    ("intra_ctb16", 264, 200, 14, dict(n_pictures=3, gop=0, log2_ctb_size=4, log2_max_tb_size=4)),
+    ("hd_main10", 1920, 1080, 15, dict(n_pictures=4, gop=2, bit_depth=10, wpp=1)),
+]
+
+
+@need_front_end
+@pytest.mark.parametrize("case", STREAMS, ids=[c[0] for c in STREAMS])
+def test_harness_decodes_streams_and_the_gpu_md5_matches_the_sei(case, tmp_path):
+    import refdec
+    import streamgen
+    name, w, h, seed, kw = case
+    data, aus = streamgen.write_stream(w, h, seed, **kw)
+    pics = refdec.decode(data)
+    digests = [refdec.md5_of(p) for p in pics]
+    with_sei, _ = streamgen.add_md5(data, aus, digests)
+    path = tmp_path / (name + ".bin")
+    path.write_bytes(with_sei)
+    out = tmp_path / "out.yuv"
+    r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-n", "-o", str(out)], capture_output=True, text=True, timeout=600)
+    n = kw["n_pictures"]
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("Correct MD5") == 3 * n and "Incorrect MD5" not in r.stdout
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith(f"frame= {n} fps= ") and last.endswith(f"video_size= {w}x{h}"), last
+    # -o: the pictures themselves (decode order = output order for these low-delay structures)
+    raw = (tmp_path / f"out_{w}x{h}.yuv").read_bytes()
+    assert raw == b"".join(np.ascontiguousarray(pl).tobytes() for p in pics for pl in p)
+    # a wrong digest in the stream is reported per plane and fails the run (exit code 3)
+    wrong = [list(d) for d in digests]
+    wrong[1][2] = bytes(16)
+    bad, _ = streamgen.add_md5(data, aus, wrong)
+    path.write_bytes(bad)
+    r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1
+    # -c: no check, -s: stop early
+    r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-c", "-s", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MD5" not in r.stdout and r.stdout.strip().splitlines()[-1].startswith("frame= 2 ")

@@ -436,4 +436,11 @@ class FrameFromArrays:
         f.vertical_bs, f.horizontal_bs = ptr("vertical_bs", C.c_uint8), ptr("horizontal_bs", C.c_uint8)
         f.qp_y_tab, f.is_pcm, f.is_intra = ptr("qp_y_tab", C.c_int8), ptr("is_pcm", C.c_uint8), ptr("is_intra", C.c_uint8)
         f.deblock, f.sao = ptr("deblock", OhDeblockCtb), ptr("sao", OhSaoCtb)
+        if "sparse" in self.a:                             # optional: the sparse hand-over (uint32 records, per-TU offsets, scaling lists)
+            f.n_sparse = int(self.a["sparse"].size)
+            f.sparse, f.tu_sparse = ptr("sparse", C.c_uint32), ptr("tu_sparse", C.c_uint32)
+            assert self.a["tu_sparse"].size == f.n_tu
+        if "scaling" in self.a:
+            assert self.a["scaling"].nbytes == 4 * 6 * 64 + 2 * 6
+            f.scaling = self.a["scaling"].ctypes.data
         self.frame = f

@@ -223,6 +223,7 @@ def hooked_lib():
             getattr(L, name).restype = getattr(plain, name).restype
         L.ref_hooked_finish.restype = C.POINTER(F.OhFrame)
         L.ref_hooked_finish.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ref_hooked_scaling_list.argtypes = [C.c_void_p]
         _hlib = L
     return _hlib
 

@@ -32,7 +32,18 @@ def _lib():
     H.oh_stream_free.argtypes = [C.POINTER(OhStream)]
     H.oh_stream_trace.argtypes = [C.POINTER(C.POINTER(C.c_int32))]
     H.oh_stream_trace.restype = C.c_size_t
+    H.oh_stream_levels.argtypes = [C.POINTER(C.POINTER(C.c_uint32))]
+    H.oh_stream_levels.restype = C.c_size_t
     return H
+
+
+def written_levels():
+    """uint32 words of the last write_stream(..., levels=1): the residual blocks in coding order (include/ohevc_stream.h)"""
+    import numpy as np
+    H = _lib()
+    p = C.POINTER(C.c_uint32)()
+    n = H.oh_stream_levels(C.byref(p))
+    return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
 
 
 def written_trace():

@@ -104,11 +104,13 @@ __global__ __launch_bounds__(256) void bs_kernel(const BsArgs a)
             }
         }
     }
-    G_MUT(uint8_t, a.hbs)[(x + y * bsw) >> 2] = (uint8_t)h;
-    G_MUT(uint8_t, a.vbs)[(x + y * bsw) >> 2] = (uint8_t)v;
+    /* four strengths to the byte (dev_frame.h: vbs / hbs), the grids were cleared before the launch: only non-zero ones are written */
+    const uint32_t i = (uint32_t)(x + y * bsw) >> 2;
+    if (h) atomicOr((uint32_t *)a.hbs + (i >> 4), (uint32_t)h << ((i & 15) * 2));
+    if (v) atomicOr((uint32_t *)a.vbs + (i >> 4), (uint32_t)v << ((i & 15) * 2));
 }
 
-/* both grids of one picture; vbs / hbs: oh_bs_size() bytes each, the tail behind the last row is cleared by the caller */
+/* both grids of one picture; vbs / hbs: oh_bs_size() strengths each, four to the byte, cleared by the caller (word-aligned size) */
 extern "C" void ohk_bs_derive(const OhPicParams *p, const void *mvf, const void *cbf, const void *call_log2, const void *ctb_flags,
                               int across_tiles, void *vbs, void *hbs, hipStream_t st)
 {

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void deblock_luma_kernel(const OhBatch B)
     if (x >= W || y >= H)
         return;
     const int bsw = W >> 2;
-    const int bs = (HORIZ ? f->hbs : f->vbs)[(x + y * bsw) >> 2];
+    const int bsi = (x + y * bsw) >> 2, bs = ((HORIZ ? f->hbs : f->vbs)[bsi >> 2] >> ((bsi & 3) * 2)) & 3;      /* four strengths to the byte */
     if (!bs)
         return;
     const int lc = pp.log2_ctb_size, ctbw = (W + (1 << lc) - 1) >> lc;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void deblock_chroma_kernel(const OhBatch B)
     if (x >= W || y >= H)
         return;
     const int bsw = W >> 2;
-    const int bs = (HORIZ ? f->hbs : f->vbs)[(x + y * bsw) >> 2];
+    const int bsi = (x + y * bsw) >> 2, bs = ((HORIZ ? f->hbs : f->vbs)[bsi >> 2] >> ((bsi & 3) * 2)) & 3;      /* four strengths to the byte */
     const int lc = pp.log2_ctb_size, ctbw = (W + (1 << lc) - 1) >> lc;
     if (HORIZ && f->sao_stale && !(gx & 1)) {
         /* 16x16 CTBs, subsampled chroma: deblocking_filter_CTB handles the horizontal chroma edges of a CTB's columns in the call

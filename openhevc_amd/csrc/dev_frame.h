@@ -138,7 +138,7 @@ struct DevFrame {
     const uint32_t  *sub_start;       /* sub-level ranges into intra[]                         */
     const uint32_t  *sub_small;       /* per sub-level: its first sub_small[] blocks are <= 8x8 (slot path)      */
     const uint32_t  *lvl_start;       /* wavefront level ranges into ictu[]                    */
-    const uint8_t   *vbs, *hbs;
+    const uint8_t   *vbs, *hbs;       /* boundary strengths of the 4-sample edge segments, FOUR to the byte: entry i in bits 2 (i & 3) of byte i >> 2 */
     const int8_t    *qp;
     const uint8_t   *is_pcm;          /* may be null                                          */
     const OhDeblockCtb *db;

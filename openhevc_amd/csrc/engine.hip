@@ -512,6 +512,23 @@ extern "C" int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3]
     return OH_OK;
 }
 
+/* n boundary strengths (0..2, one per byte: hevc_filter.c's vertical_bs / horizontal_bs) -> (n + 3) / 4 bytes, entry i in bits
+ * 2 (i & 3) of byte i >> 2 — the form the deblock pass reads.  Four bytes per multiply: the 2-bit fields land in the top byte. */
+static void pack_bs(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        uint32_t x;
+        memcpy(&x, src + i, 4);
+        dst[i >> 2] = (uint8_t)(((x & 0x03030303u) * 0x01041040u) >> 24);
+    }
+    if (i < n) {
+        uint32_t v = 0;
+        for (size_t k = i; k < n; k++) v |= (uint32_t)(src[k] & 3) << ((k & 3) * 2);
+        dst[i >> 2] = (uint8_t)v;
+    }
+}
+
 /* a pinned buffer of at least `bytes` whose previous copy has completed (uploads and downloads share the pool) */
 static OhEngine::Stage *stage_acquire(OhEngine *e, size_t bytes)
 {
@@ -790,12 +807,13 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     const bool has_db = p.deblock_enabled != 0;
 
     /* arena: [copied: header, raw lists, side arrays, coefficient pool] [device only: prepared lists, scratch, residual pool] */
-    struct Seg { const void *src; size_t bytes, off; };
-    Seg seg[40];
+    struct Seg { const void *src; size_t bytes, off; size_t pack_n; };     /* pack_n != 0: src holds pack_n boundary strengths, one per byte */
+    Seg seg[48];
     int ns = 0;
     size_t total = 0;
     auto add = [&](const void *src, size_t bytes) {
-        seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].off = total;
+        if (ns >= 48) abort();                                  /* a segment was added without growing seg[] */
+        seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].off = total; seg[ns].pack_n = 0;
         total += align_up(bytes ? bytes : 1, 256);
         return ns++;
     };
@@ -818,15 +836,21 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_isin = add(cip ? f->is_intra : nullptr, cip ? n_pcm : 0);
     const OhBsInputs *bsi = has_db ? f->bs_in : nullptr;
     const size_t bs_bytes = bsi ? oh_bs_size(&p) : f->bs_size;
-    int s_vbs = add(has_db && !bsi ? f->vertical_bs : nullptr, has_db ? bs_bytes : 0);     /* with bs_in: written by bs_kernel after the copy */
-    int s_hbs = add(has_db && !bsi ? f->horizontal_bs : nullptr, has_db ? bs_bytes : 0);
+    /* the grids cross PCIe and live in HBM four strengths to the byte (0..2 each: 2 bits) — a megabyte less per 4K picture */
+    const size_t bs_packed = (bs_bytes + 3) / 4;
+    int s_vbs = add(has_db && !bsi ? f->vertical_bs : nullptr, has_db ? bs_packed : 0);    /* with bs_in: written by bs_kernel after the copy */
+    int s_hbs = add(has_db && !bsi ? f->horizontal_bs : nullptr, has_db ? bs_packed : 0);
+    if (has_db && !bsi) seg[s_vbs].pack_n = seg[s_hbs].pack_n = bs_bytes;
     const size_t n_mtb = (size_t)(p.width >> p.log2_min_tb_size) * (p.height >> p.log2_min_tb_size);
     int s_mvf = add(bsi ? bsi->mvf : nullptr, bsi ? n_pcm * sizeof(OhMvField) : 0);
     int s_cbf = add(bsi ? bsi->cbf_luma : nullptr, bsi ? n_mtb : 0);
     int s_call = add(bsi ? bsi->call_log2 : nullptr, bsi ? n_mtb : 0);
     int s_bsf = add(bsi ? bsi->ctb_flags : nullptr, bsi ? n_ctb : 0);
     int s_qp = add(has_db ? f->qp_y_tab : nullptr, has_db ? oh_qp_tab_size(&p) : 0);
-    int s_pcm = add(f->is_pcm, f->is_pcm ? n_pcm : 0);
+    /* the PCM / bypass map is read by the deblock and SAO passes only under these two flags (hevc_filter.c:180, 337; deblock.hip, sao.hip):
+     * without them its half megabyte per 4K picture stays on the host */
+    const bool need_pcm = f->is_pcm && (p.pcm_loop_filter_disable || p.transquant_bypass_enable);
+    int s_pcm = add(need_pcm ? f->is_pcm : nullptr, need_pcm ? n_pcm : 0);
     int s_db = add(has_db ? f->deblock : nullptr, has_db ? n_ctb * sizeof(OhDeblockCtb) : 0);
     int s_sao = add(has_sao ? f->sao : nullptr, has_sao ? n_ctb * sizeof(OhSaoCtb) : 0);
     int s_coef = add(f->coeffs, (size_t)f->n_coeff * sizeof(int16_t));
@@ -926,7 +950,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.is_intra = cip ? AT(const uint8_t *, s_isin) : nullptr;
     hd.vbs = AT(const uint8_t *, s_vbs); hd.hbs = AT(const uint8_t *, s_hbs);
     hd.qp = AT(const int8_t *, s_qp);
-    hd.is_pcm = f->is_pcm ? AT(const uint8_t *, s_pcm) : nullptr;
+    hd.is_pcm = need_pcm ? AT(const uint8_t *, s_pcm) : nullptr;
     hd.db = AT(const OhDeblockCtb *, s_db);
     hd.sao = has_sao ? AT(const OhSaoCtb *, s_sao) : nullptr;
     hd.pu_off = AT(const uint32_t *, s_puoff); hd.ctu_aux = AT(uint32_t *, s_aux); hd.tu_keep = AT(uint8_t *, s_keep); hd.tu_cursor = AT(uint32_t *, s_cursor);
@@ -957,8 +981,10 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     void *stage = sg->p;
     { HostTimer t(e, OH_HT_UPLOAD_MEMCPY);
     for (int i = 0; i < ns; i++)
-        if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
-            memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
+        if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes) {
+            if (seg[i].pack_n) pack_bs((uint8_t *)stage + seg[i].off, (const uint8_t *)seg[i].src, seg[i].pack_n);
+            else memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
+        }
     }
     /* asynchronous: the caller's arrays are already copied out; the pinned buffer stays busy until `done` */
     HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
@@ -969,8 +995,8 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     sg->busy = hrc == hipSuccess;
     e->up_bytes += copy_bytes;
     if (hrc == hipSuccess && bsi) {                        /* both grids from the maps: once per work list, the maps never change */
-        hrc = hipMemsetAsync(base + seg[s_vbs].off, 0, bs_bytes, cs);                        /* the padded tail is read by the deblock pass */
-        if (hrc == hipSuccess) hrc = hipMemsetAsync(base + seg[s_hbs].off, 0, bs_bytes, cs);
+        hrc = hipMemsetAsync(base + seg[s_vbs].off, 0, align_up(bs_packed, 4), cs);          /* bs_kernel ORs the non-zero strengths in; the padded tail is read by the deblock pass */
+        if (hrc == hipSuccess) hrc = hipMemsetAsync(base + seg[s_hbs].off, 0, align_up(bs_packed, 4), cs);
         if (hrc == hipSuccess)
             ohk_bs_derive(&p, base + seg[s_mvf].off, base + seg[s_cbf].off, base + seg[s_call].off, base + seg[s_bsf].off, bsi->loop_filter_across_tiles,
                           base + seg[s_vbs].off, base + seg[s_hbs].off, cs);
@@ -1348,10 +1374,15 @@ extern "C" int oh_frame_download_bs(OhEngine *e, OhDevFrame *df, uint8_t *vbs, u
     DevFrame hd;
     HIPCHK(e, hipMemcpyAsync(&hd, df->d, sizeof(hd), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    const size_t n = bytes < oh_bs_size(&df->p) ? bytes : oh_bs_size(&df->p);
-    HIPCHK(e, hipMemcpyAsync(vbs, hd.vbs, n, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(hbs, hd.hbs, n, hipMemcpyDeviceToHost, e->stream));
+    const size_t n = bytes < oh_bs_size(&df->p) ? bytes : oh_bs_size(&df->p), np = (n + 3) / 4;
+    std::vector<uint8_t> pk(2 * np);
+    HIPCHK(e, hipMemcpyAsync(pk.data(), hd.vbs, np, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(pk.data() + np, hd.hbs, np, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < n; i++) {                          /* back to one strength per byte, the reference's layout */
+        vbs[i] = (pk[i >> 2] >> ((i & 3) * 2)) & 3;
+        hbs[i] = (pk[np + (i >> 2)] >> ((i & 3) * 2)) & 3;
+    }
     return OH_OK;
 }
 

@@ -132,8 +132,17 @@ def run_steps_batched(chains, dist=None, exchange=None):
     so is the union of their tails.  The exchange after a wave is one all-gather per chain, or — with exchange =
     exchange_map(...) — one batch of point-to-point transfers to the ranks that reference the pictures."""
     plan0, be0 = chains[0][0], chains[0][1]
+    batches = [[(be, pl.waves[w].name) for pl, be, _ in chains] for w in range(len(plan0.waves))]
+    tail = [(be, pic.name) for pl, be, _ in chains for pic in pl.tail]
+    # a backend that hands work lists over per picture takes the NEXT batch's lists while the GPU still prepares / runs this one's
+    # (what a decoder's host thread does: it is already parsing picture n + 1); the step after this one starts with wave 0 again
+    ahead = getattr(be0, "hand_over_ahead", None)
+    following = batches[1:] + ([tail] if tail else []) + [batches[0]]
     for w in range(len(plan0.waves)):
-        be0.execute_batch([(be, pl.waves[w].name) for pl, be, _ in chains])
+        if ahead is not None:
+            be0.execute_batch(batches[w], then=following[w])
+        else:
+            be0.execute_batch(batches[w])
         if plan0.world > 1 and exchange is None:          # everybody gets everything: one all-gather per chain
             for pl, be, group in chains:
                 half = be.final_half(pl.waves[w].name)
@@ -173,9 +182,11 @@ def run_steps_batched(chains, dist=None, exchange=None):
                 dev.copy_(host)
             for be, name, half in done:
                 be.set_final_half(name, half)
-    tail = [(be, pic.name) for pl, be, _ in chains for pic in pl.tail]
     if tail:
-        be0.execute_batch(tail)
+        if ahead is not None:
+            be0.execute_batch(tail, then=batches[0])
+        else:
+            be0.execute_batch(tail)
 
 
 def pictures_per_step(plan: StepPlan):
@@ -257,15 +268,18 @@ class EngineBackend(Backend):
         self.frames: Dict[Tuple, object] = {}
         self.resident = False
         self.upload_s, self.uploads = 0.0, 0                      # host time spent inside oh_frame_upload
+        self._ahead = {}                                          # chunk key -> work lists handed over ahead of their execute
         if resident:
             self.make_resident()
 
     def make_resident(self):
+        self.drop_ahead()
         for name, hdr in self.headers.items():
             self.frames[name] = self.engine.frame_upload(hdr)
         self.resident = True
 
     def drop_resident(self):
+        self.drop_ahead()
         self.engine.sync()
         for df in self.frames.values():
             self.engine.frame_free(df)
@@ -278,24 +292,49 @@ class EngineBackend(Backend):
     def execute(self, name):
         self.execute_batch([(self, name)])
 
-    def execute_batch(self, items):
+    hand_over_ahead = True                                    # run_steps_batched: execute_batch(items, then=next batch)
+
+    def _hand_over(self, chunk):
+        """oh_frames_upload of up to 32 work lists (validation, H2D on the copy stream, list preparation kernels behind it)"""
+        import time
+        key = tuple((id(be), name) for be, name in chunk)
+        if key in self._ahead:
+            return
+        t0 = time.perf_counter()
+        self._ahead[key] = self.engine.frames_upload([be.headers[name] for be, name in chunk])
+        self.upload_s += time.perf_counter() - t0
+        self.uploads += len(chunk)
+
+    def execute_batch(self, items, then=None):
         assert all(be.engine is self.engine for be, _ in items), "a batch runs on one engine"
         if all(be.resident for be, _ in items):
             self.engine.frames_execute([be.frames[name] for be, name in items])
             return
         import time
-        for c0 in range(0, len(items), 32):                   # one launch per pass covers at most 32 pictures: hand over that many, run them, let go
-            t0 = time.perf_counter()
-            dfs = self.engine.frames_upload([be.headers[name] for be, name in items[c0:c0 + 32]])
+        # one launch per pass covers at most 32 pictures: hand over that many, run them, let go.  The lists of the chunk that
+        # comes NEXT (of this batch, else the first of `then`) are handed over before this chunk's passes are enqueued, so their
+        # copy and preparation run while this chunk executes and the host never waits for a preparation it has just started.
+        chunks = [items[c0:c0 + 32] for c0 in range(0, len(items), 32)]
+        for i, chunk in enumerate(chunks):
+            self._hand_over(chunk)
+            dfs = self._ahead.pop(tuple((id(be), name) for be, name in chunk))
+            nxt = chunks[i + 1] if i + 1 < len(chunks) else (then[:32] if then else None)
+            if nxt:
+                self._hand_over(nxt)
             t1 = time.perf_counter()
-            self.upload_s += t1 - t0
-            self.uploads += len(dfs)
             self.engine.frames_execute(dfs)
             t2 = time.perf_counter()
             for df in dfs:
                 self.engine.frame_release(df)
             self.execute_s = getattr(self, "execute_s", 0.0) + (t2 - t1)
             self.release_s = getattr(self, "release_s", 0.0) + (time.perf_counter() - t2)
+
+    def drop_ahead(self):
+        """work lists handed over ahead of a batch that never ran (end of a run)"""
+        for dfs in self._ahead.values():
+            for df in dfs:
+                self.engine.frame_release(df)
+        self._ahead = {}
 
     def final_half(self, name):
         return self.engine.pic_final_half(self.ids[name])
@@ -304,6 +343,7 @@ class EngineBackend(Backend):
         self.engine.pic_set_final_half(self.ids[name], half)
 
     def close(self):
+        self.drop_ahead()
         self.drop_resident()
         if self.own_engine:
             self.engine.close()

@@ -144,6 +144,12 @@ def main():
                     "each into its own pictures): bounds host memory, every hand-over still copies its own bytes")
     ap.add_argument("--sparse-pct", type=int, default=100, help="%% of transform blocks handed over as quantised levels and de-quantised on the GPU "
                     "(SURVEY 8f rank 1: what residual_coding parses) instead of dense de-quantised coefficients (2 B per coded sample over PCIe)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --chains GOP chains per GPU (work grows with N); strong: --chains chains over ALL GPUs — a wave of a chain is N "
+                         "pictures, picture p decoded on GPU p mod N, so the pictures of the step are fixed and split N ways")
+    ap.add_argument("--gop", default="ra", choices=["ra", "ldp", "intra"],
+                    help="GOP shape of the chains (openhevc_amd/parallel.py make_step_plan): random access (I + reference B + non-reference B), "
+                         "low delay P (every picture on the neighbour GPU's previous picture), all intra")
     ap.add_argument("--exchange", default="readers", choices=["readers", "allgather"],
                     help="N>1: send finished reference pictures to the ranks that reference them (point-to-point batches), or replicate them everywhere (one all-gather per chain and wave)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -192,13 +198,15 @@ def main():
     if args.chains is None:
         args.chains = 96 if params.width * params.height <= 3840 * 2160 else 24
     n_chains = max(1, args.chains)
+    if args.scaling == "strong" and world > 1:
+        n_chains = max(1, n_chains // world)               # the same pictures per step as one GPU decodes alone, split over the ranks
     n_streams = max(1, min(args.streams, n_chains))
     knobs = dict(sparse_pct=args.sparse_pct, bs_from_motion=int(args.bs_from_motion))
     # host work lists: --host-gops distinct GOPs (seeds), generated once — the stand-in for what the reference's CTU loop records
     n_host = max(1, min(args.host_gops, n_chains))
     host = []
     for m in range(n_host):
-        plan_m = P.make_step_plan(world, rank, n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + m)
+        plan_m = P.make_step_plan(world, rank, n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + m, gop=args.gop)
         host.append((plan_m, P.host_work_lists(params, plan_m, knobs)))
     host_bytes = sum(fc.bytes for _, (lists, _) in host for fc in lists.values())
     groups = [[] for _ in range(n_streams)]                # per stream: [(stream, engine, process group), (plan, backend, group)...]
@@ -209,16 +217,22 @@ def main():
         if not g:
             stream = torch.cuda.Stream()
             # the collectives of one stream are issued in the same order on every rank, so its chains share a
-            # communicator; different streams must not (their collectives interleave differently per rank)
-            g.append((stream, Engine(local_rank, stream=stream.cuda_stream), dist.new_group() if world > 1 else None))
-        stream, engine, group = g[0]
+            # communicator; different streams must not (their collectives interleave differently per rank).
+            # The chains of the stream advance in lockstep: their pictures live in ONE GroupStore, laid out so that a wave is one
+            # message per peer (or one all-gather), and the exchange runs on the group's own stream (P.Comm).
+            n_here = len(range(k, n_chains, n_streams))
+            gstore = P.GroupStore(torch, torch.device("cuda", local_rank), params, world, n_here, args.waves, args.tail)
+            g.append((stream, Engine(local_rank, stream=stream.cuda_stream), dist.new_group() if world > 1 else None, gstore,
+                      P.Comm(torch, torch.device("cuda", local_rank)) if world > 1 else None))
+        stream, engine, group, gstore, comm = g[0]
         with torch.cuda.stream(stream):
-            be_k = P.EngineBackend(torch, local_rank, params, plan_k, engine=engine, host_lists=lists_k, resident=False)
+            be_k = P.EngineBackend(torch, local_rank, params, plan_k, engine=engine, host_lists=lists_k, resident=False,
+                                   group=(gstore, len(g) - 1))
         g.append((plan_k, be_k, group))
         chains.append((plan_k, be_k, stream, group))
     engines = [g[0][1] for g in groups]
     plan = chains[0][0]
-    plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643)
+    plan_kwargs = dict(n_waves=args.waves, n_tail=args.tail, seed=0x48455643, gop=args.gop)
     pics_per_step = P.pictures_per_step(plan) * n_chains      # a step advances every chain in flight by one GOP
 
     def barrier():
@@ -226,7 +240,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    exchange = P.exchange_map(world, rank, args.waves, args.tail) if world > 1 and args.exchange == "readers" else None
+    exchange = P.exchange_map(world, rank, args.waves, args.tail, gop=args.gop) if world > 1 and args.exchange == "readers" else None
+    comms = [g[0][4] for g in groups if g and g[0][4] is not None]
     # one host thread per engine / stream (an engine is a single-submitter object).  With N > 1 the streams' collectives must be
     # issued in the same relative order on every rank, so one thread enqueues all streams.
     host_threads = n_streams if world == 1 else 1
@@ -234,7 +249,7 @@ def main():
     def run_group(g, n_steps):
         with torch.cuda.stream(g[0][0]):
             for _ in range(n_steps):
-                P.run_steps_batched(g[1:], dist if world > 1 else None, exchange)
+                P.run_steps_batched(g[1:], dist if world > 1 else None, exchange, g[0][4])
 
     def run(n_steps):
         """one step = every chain in flight advances by one GOP: each stream runs its chains as lockstep batches"""
@@ -272,6 +287,8 @@ def main():
             eng.profile(0 if args.no_profile else 2)      # events between passes and around every intra launch
         for _, be_k, _, _ in chains:
             be_k.upload_s, be_k.uploads, be_k.execute_s, be_k.release_s = 0.0, 0, 0.0, 0.0
+        for cm in comms:
+            cm.reset()
         barrier()
         t0 = time.perf_counter()
         run(n_steps)
@@ -284,7 +301,18 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            # the exchange of the region, per rank: time on the exchange streams (events), bytes, messages
+            mine = dict(ms_per_step=round(sum(cm.ms() for cm in comms) / n_steps, 3),
+                        MB_sent_per_step=round(sum(cm.bytes_sent for cm in comms) / n_steps / 1e6, 2),
+                        MB_received_per_step=round(sum(cm.bytes_recv for cm in comms) / n_steps / 1e6, 2),
+                        messages_per_step=sum(cm.messages for cm in comms) / n_steps, collectives_per_step=sum(cm.collectives for cm in comms) / n_steps)
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            exchange_stats.clear()
+            exchange_stats.extend(every)
         return dt, dt_enqueue
+
+    exchange_stats = []
 
     luma_px = params.width * params.height
     b = 2 if params.bit_depth > 8 else 1
@@ -341,8 +369,10 @@ def main():
 
     total_pics = world * pics_per_step * args.steps
     decode = None
+    decode_exchange = None
     if args.mode == "decode":
         dt, dt_enq = timed(args.warmup, args.steps)
+        decode_exchange = list(exchange_stats)
         up_s = sum(be_k.upload_s for _, be_k, _, _ in chains)
         n_up = sum(be_k.uploads for _, be_k, _, _ in chains)
         ex_s = sum(getattr(be_k, "execute_s", 0.0) for _, be_k, _, _ in chains)
@@ -367,6 +397,8 @@ def main():
             for _, be_k, _ in g[1:]:
                 be_k.make_resident()
     kdt, kdt_enq = timed(k_warm, k_steps)
+    if args.mode == "kernel_only":
+        decode_exchange = list(exchange_stats)
     kernel_only = dict(dt=kdt, dt_enqueue=kdt_enq, roofline=collect(kdt, k_steps) if rank == 0 else None)
 
     # the pictures of the timed regions are real pictures: one chain's GOP against the checker (bit-exact) before anything is printed
@@ -390,7 +422,7 @@ def main():
             "value": round(n_pics_h * luma_px / dt_h / 1e6, 2), "unit": "Mpixels/s", "fps": round(n_pics_h / dt_h, 2),
             "n_gpus": world, "steps": steps_h, "warmup": args.warmup if decode is not None else k_warm, "ms_per_step": round(dt_h / steps_h * 1e3, 4),
             "host_enqueue_ms_per_step": round(head["dt_enqueue"] / steps_h * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "u8" if params.bit_depth == 8 else "u16", "data": "synthetic",
             "mode": ("decode: every picture's work list handed over inside the timed region (oh_frame_upload = validation + list preparation + H2D, "
                      "passes, stream-ordered release)" if decode is not None else "kernel_only: resident work lists replayed"),
@@ -410,9 +442,12 @@ def main():
                        "chains_in_flight_per_gpu": n_chains, "streams_per_gpu": n_streams,
                        "host_work_lists": f"{n_host} distinct GOPs, {round(host_bytes / n_host / P.pictures_per_step(plan) / 1e6, 2)} MB per picture on average",
                        "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
+                       "gop": args.gop,
                        "exchange": ("none (1 GPU)" if world == 1 else
-                                    "finished reference pictures sent point-to-point (RCCL) to the ranks that reference them, one batch per wave and stream"
-                                    if exchange is not None else "one RCCL all-gather of the finished reference pictures per chain and wave"),
+                                    "finished reference pictures sent point-to-point (RCCL) to the ranks that reference them: ONE message per peer, wave and "
+                                    "stream (the pictures of all chains of the stream are contiguous per rank), on the stream's own exchange stream between HIP events"
+                                    if exchange is not None else "one RCCL all-gather of the finished reference pictures per wave and stream, on the stream's own exchange stream"),
+                       "exchange_per_rank": decode_exchange if world > 1 else None,
                        "generator": dict(gen, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
             "roofline": head["roofline"],
             "check": check,

@@ -43,19 +43,37 @@ class StepPlan:
         return self.waves + self.tail
 
 
-def make_step_plan(world, rank, n_waves=4, n_tail=12, seed=1):
-    """Deterministic plan; every rank can compute every rank's plan (used for validation)."""
+GOPS = ("ra", "ldp", "intra")
+
+
+def make_step_plan(world, rank, n_waves=4, n_tail=12, seed=1, gop="ra"):
+    """Deterministic plan; every rank can compute every rank's plan (used for validation).  gop:
+      "ra"     the random-access shape above: I, reference B pictures on two pictures of the wave before (one of them another
+               rank's), non-reference B pictures on the last two waves
+      "ldp"    low delay P: every picture after the I picture is a P picture on ONE picture of the wave before — the NEIGHBOUR
+               rank's, i.e. picture n of the chain is decoded on GPU n mod G from what GPU (n - 1) mod G produced; the tail's
+               P pictures read the last wave
+      "intra"  all intra: nothing references anything, nothing is exchanged"""
+    assert gop in GOPS, gop
     plan = StepPlan(world, rank)
     for w in range(n_waves):
         s = seed * 1000003 + w * 1009 + rank * 7919
-        if w == 0:
-            plan.waves.append(PicturePlan(("ref", 0, rank), 0, [], s))
+        if w == 0 or gop == "intra":
+            plan.waves.append(PicturePlan(("ref", w, rank), 0, [], s))
+        elif gop == "ldp":
+            plan.waves.append(PicturePlan(("ref", w, rank), 1, [("ref", w - 1, (rank + 1) % world)], s))
         else:
             refs = [("ref", w - 1, rank), ("ref", w - 1, (rank + 1) % world)]
             plan.waves.append(PicturePlan(("ref", w, rank), 2, refs, s))
     last = n_waves - 1
     for k in range(n_tail):
         s = seed * 1000003 + 500 * 1009 + k * 104729 + rank * 7919
+        if gop == "intra":
+            plan.tail.append(PicturePlan(("tail", k), 0, [], s))
+            continue
+        if gop == "ldp":
+            plan.tail.append(PicturePlan(("tail", k), 1, [("ref", last, (rank + k) % world)], s))
+            continue
         a = ("ref", last, rank)
         b = ("ref", last - (k % 2) if last else 0, (rank + 1 + k) % world)
         plan.tail.append(PicturePlan(("tail", k), 2, [a, b] if a != b else [a, ("ref", last, (rank + 1) % world)], s))
@@ -98,13 +116,13 @@ def run_step(plan: StepPlan, backend: Backend, dist=None, group=None):
         backend.execute(pic.name)
 
 
-def exchange_map(world, rank, n_waves, n_tail):
+def exchange_map(world, rank, n_waves, n_tail, gop="ra"):
     """Who references whose reference pictures: per wave (send_to, recv_from) of this rank.  A decoder knows its reference
     picture sets ahead of time, so a finished picture only has to reach the GPUs that will read it — the general case is the
     all-gather (everybody), this is the same exchange restricted to the readers."""
     need = {}
     for r in range(world):
-        for pic in make_step_plan(world, r, n_waves=n_waves, n_tail=n_tail).pictures():
+        for pic in make_step_plan(world, r, n_waves=n_waves, n_tail=n_tail, gop=gop).pictures():
             for ref in pic.refs:
                 if ref[2] != r:
                     need.setdefault((ref[1], ref[2]), set()).add(r)
@@ -125,7 +143,108 @@ def _staged(dist, group, tensor):
 P2P_CHAINS = 8          # chains per batch_isend_irecv call (bounds the operations inside one RCCL group call)
 
 
-def run_steps_batched(chains, dist=None, exchange=None):
+class Comm:
+    """The exchange's own stream and its account.  The transfers of a wave are enqueued on `stream` behind an event recorded on the
+    engine's stream after the wave's passes, and the engine's stream waits for the event that ends them — hipStreamWaitEvent both
+    ways, no host wait — so the copy engines / xGMI links work while the other streams' passes (and this stream's hand-over of the
+    next batch) go on.  bytes / messages / time are per rank (bench.py prints them)."""
+
+    def __init__(self, torch, device=None):
+        self.torch = torch
+        self.stream = torch.cuda.Stream(device) if device is not None and torch.cuda.is_available() else None
+        self.bytes_sent = self.bytes_recv = self.messages = self.collectives = 0
+        self.host_s = 0.0                                  # time of exchanges that ran on the host (CPU tensors / staged rehearsal)
+        self._events = []
+
+    def reset(self):
+        self.bytes_sent = self.bytes_recv = self.messages = self.collectives = 0
+        self.host_s = 0.0
+        self._events = []
+
+    def ms(self):
+        """device time between the first and last operation of every exchange (call after a synchronize) + host-side exchanges"""
+        return sum(a.elapsed_time(b) for a, b in self._events) + self.host_s * 1e3
+
+
+def _exchange_grouped(chains, w, dist, exchange, comm):
+    """One wave's reference pictures of ALL chains of a lockstep group: the group's buffers (GroupStore) keep what a rank
+    contributes — its picture of every chain — contiguous, so the wave costs ONE all-gather, or with exchange_map ONE message per
+    peer that references this rank's pictures, however many chains are in flight."""
+    import time
+    pl0, be0, group = chains[0]
+    gs = be0.store.group
+    torch = gs.torch
+    half = be0.final_half(pl0.waves[w].name)
+    assert all(be.final_half(pl.waves[w].name) == half for pl, be, _ in chains), "the chains of a group finish a wave in the same half"
+    buf = gs.waves[w][half]                                # [world][n_chains][half_bytes], contiguous
+    rank, world = pl0.rank, pl0.world
+    send_to, recv_from = (list(r for r in range(world) if r != rank),) * 2 if exchange is None else exchange[w]
+    on_dev = buf.is_cuda
+    stage = _staged(dist, group, buf)
+    cur = torch.cuda.current_stream() if on_dev else None
+    use_stream = on_dev and comm is not None and comm.stream is not None
+    t0 = t1 = None
+    t_host = time.perf_counter()
+    if use_stream:
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        comm.stream.wait_event(ready)                      # the wave's passes first
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx = torch.cuda.stream(comm.stream) if use_stream else _null_context()
+    with ctx:
+        if t0 is not None:
+            t0.record()
+        if exchange is None:
+            if send_to:
+                if stage:
+                    host = buf.cpu()
+                    dist.all_gather_into_tensor(host.view(-1), host[rank].clone().view(-1), group=group)
+                    buf.copy_(host)
+                else:
+                    dist.all_gather_into_tensor(buf.view(-1), buf[rank].view(-1), group=group)
+                if comm is not None:
+                    comm.collectives += 1
+        else:
+            ops, landed = [], []
+            mine = buf[rank].cpu() if stage and send_to else buf[rank]
+            ops += [dist.P2POp(dist.isend, mine, dst, group) for dst in send_to]
+            for src in recv_from:
+                into = buf[src].cpu() if stage else buf[src]
+                ops.append(dist.P2POp(dist.irecv, into, src, group))
+                if stage:
+                    landed.append((buf[src], into))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for dev, host in landed:
+                dev.copy_(host)
+            if comm is not None:
+                comm.messages += len(ops)
+        if t1 is not None:
+            t1.record()
+    if use_stream:
+        cur.wait_event(t1)                                 # the next batch reads what arrived
+        comm._events.append((t0, t1))
+    elif comm is not None:
+        comm.host_s += time.perf_counter() - t_host
+    if comm is not None:
+        per_rank = buf[rank].numel()
+        comm.bytes_sent += per_rank * len(send_to)
+        comm.bytes_recv += per_rank * len(recv_from)
+    for pl, be, _ in chains:
+        for src in recv_from:
+            be.set_final_half(("ref", w, src), half)
+
+
+class _null_context:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def run_steps_batched(chains, dist=None, exchange=None, comm=None):
     """Enqueue one step of EVERY chain in lockstep.  chains: list of (plan, backend, process group); the
     chains are independent GOPs with the same schedule, so wave w of all of them is one batch of
     mutually independent pictures (Backend.execute_batch: one launch per pass over the whole batch), and
@@ -143,7 +262,9 @@ def run_steps_batched(chains, dist=None, exchange=None):
             be0.execute_batch(batches[w], then=following[w])
         else:
             be0.execute_batch(batches[w])
-        if plan0.world > 1 and exchange is None:          # everybody gets everything: one all-gather per chain
+        if plan0.world > 1 and getattr(be0.store, "group", None) is not None:
+            _exchange_grouped(chains, w, dist, exchange, comm)
+        elif plan0.world > 1 and exchange is None:        # everybody gets everything: one all-gather per chain
             for pl, be, group in chains:
                 half = be.final_half(pl.waves[w].name)
                 buf = be.wave_tensor(w)[half]
@@ -202,15 +323,38 @@ def default_synth_knobs():
                 qp_base=30, qp_var=5, sao_pct=50)
 
 
+class GroupStore:
+    """The picture buffers of the chains that advance in LOCKSTEP on one stream, laid out for the exchange:
+         wave w : uint8 tensor [2 halves][world][n_chains][half_bytes]
+    so everything one rank contributes to a wave — its reference picture of EVERY chain — is one contiguous block per half: one
+    message per peer and wave (or one all-gather per wave) whatever the number of chains in flight (_exchange_grouped).
+         tail   : uint8 tensor [n_chains][n_tail][2][half_bytes]   (non-reference pictures, never exchanged)"""
+
+    def __init__(self, torch, device, params, world, n_chains, n_waves, n_tail):
+        from . import frame as F
+        self.torch = torch
+        self.half_bytes = F.half_layout(params)[0]
+        self.n_chains = n_chains
+        self.waves = [torch.zeros((2, world, n_chains, self.half_bytes), dtype=torch.uint8, device=device) for _ in range(n_waves)]
+        self.tail = torch.zeros((n_chains, max(n_tail, 1), 2, self.half_bytes), dtype=torch.uint8, device=device)
+
+
 class PictureStore:
     """Names -> picture buffers laid out for the wave all-gather:
          wave w : uint8 tensor [2 halves][world][half_bytes]   (reference pictures of every rank)
-         tail   : uint8 tensor [n_tail][2][half_bytes]         (this rank's non-reference pictures)"""
+         tail   : uint8 tensor [n_tail][2][half_bytes]         (this rank's non-reference pictures)
+    group = (GroupStore, k): chain k's views into a lockstep group's buffers instead of buffers of its own."""
 
-    def __init__(self, torch, device, params, plan, n_waves, n_tail):
+    def __init__(self, torch, device, params, plan, n_waves, n_tail, group=None):
         from . import frame as F
         self.half_bytes, self.strides, self.offsets = F.half_layout(params)
         self.params, self.plan = params, plan
+        self.group = None
+        if group is not None:
+            self.group, k = group
+            self.waves = [t[:, :, k] for t in self.group.waves]
+            self.tail = self.group.tail[k]
+            return
         self.waves = [torch.zeros((2, plan.world, self.half_bytes), dtype=torch.uint8, device=device) for _ in range(n_waves)]
         self.tail = torch.zeros((max(n_tail, 1), 2, self.half_bytes), dtype=torch.uint8, device=device)
 
@@ -243,7 +387,7 @@ def host_work_lists(params, plan, knobs=None):
 
 
 class EngineBackend(Backend):
-    def __init__(self, torch, device_index, params, plan, knobs=None, engine=None, host_lists=None, resident=True):
+    def __init__(self, torch, device_index, params, plan, knobs=None, engine=None, host_lists=None, resident=True, group=None):
         """engine: share another backend's engine (its stream, picture ids and batches); None = own engine
         on the current torch stream.
         host_lists: (lists, stats) of host_work_lists() to decode (several chains may share one host copy: every chain binds
@@ -257,7 +401,7 @@ class EngineBackend(Backend):
         torch.cuda.set_device(dev)
         self.own_engine = engine is None
         self.engine = engine if engine is not None else Engine(device_index, stream=torch.cuda.current_stream().cuda_stream)
-        self.store = PictureStore(torch, dev, params, plan, len(plan.waves), len(plan.tail))
+        self.store = PictureStore(torch, dev, params, plan, len(plan.waves), len(plan.tail), group=group)   # group: (GroupStore, chain index)
         self.ids: Dict[Tuple, int] = {}
         for name in self.store.names():
             h0, h1 = self.store.halves(name)

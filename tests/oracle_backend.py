@@ -11,9 +11,9 @@ from oracle_lib import OhHostPicC, oracle, ref
 
 
 class OracleBackend(P.Backend):
-    def __init__(self, params, plan, knobs=None):
+    def __init__(self, params, plan, knobs=None, group=None):
         self.params, self.plan = params, plan
-        self.store = P.PictureStore(torch, torch.device("cpu"), params, plan, len(plan.waves), len(plan.tail))
+        self.store = P.PictureStore(torch, torch.device("cpu"), params, plan, len(plan.waves), len(plan.tail), group=group)
         names = self.store.names()
         self.ids = {n: i for i, n in enumerate(names)}
         self.final = {n: 0 for n in names}

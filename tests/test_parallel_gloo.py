@@ -61,14 +61,43 @@ def _worker(rank, world, port, w, h, out_path, batched=False, p2p=False):
     dist.destroy_process_group()
 
 
-def _single_process_expectation(world, w, h):
+def _grouped_worker(rank, world, port, w, h, out_path, gop, p2p, n_chains):
+    """the production layout: the chains of a lockstep group share a GroupStore, a wave is exchanged as ONE all-gather or ONE
+    message per peer (openhevc_amd/parallel.py _exchange_grouped), accounted in a Comm"""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from openhevc_amd import frame as F
+    from openhevc_amd import parallel as P
+    from oracle_backend import OracleBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = F.pic_params(w, h)
+    gs = P.GroupStore(torch, torch.device("cpu"), p, world, n_chains, 3, 2)
+    chains = []
+    for k in range(n_chains):
+        plan = P.make_step_plan(world, rank, n_waves=3, n_tail=2, seed=5 + k, gop=gop)
+        chains.append((plan, OracleBackend(p, plan, group=(gs, k)), None))
+    comm = P.Comm(torch)
+    ex = P.exchange_map(world, rank, 3, 2, gop=gop) if p2p else None
+    for _ in range(2):
+        P.run_steps_batched(chains, dist, ex, comm)
+    be = chains[0][1]
+    res = {str(n): _digest(be.picture(n)) for n in be.store.names()}
+    res["comm"] = dict(sent=comm.bytes_sent, recv=comm.bytes_recv, messages=comm.messages, collectives=comm.collectives, half_bytes=gs.half_bytes)
+    torch.save(res, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process_expectation(world, w, h, gop="ra"):
     """one process plays every rank in turn (wave by wave), no collectives"""
     sys.path.insert(0, HERE)
     from openhevc_amd import frame as F
     from openhevc_amd import parallel as P
     from oracle_backend import OracleBackend
     p = F.pic_params(w, h)
-    plans = [P.make_step_plan(world, r, n_waves=3, n_tail=2, seed=5) for r in range(world)]
+    plans = [P.make_step_plan(world, r, n_waves=3, n_tail=2, seed=5, gop=gop) for r in range(world)]
     backs = [OracleBackend(p, pl) for pl in plans]
     for _ in range(2):
         for wv in range(3):
@@ -121,6 +150,51 @@ def test_four_ranks_point_to_point_exchange(tmp_path):
         ex = P.exchange_map(world, r, 3, 2)
         assert all(r not in s and r not in t for s, t in ex)
         assert sum(len(s) for s, _ in ex) < 3 * (world - 1)        # fewer transfers than replicating everything
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("gop,p2p", [("ra", False), ("ra", True), ("ldp", True), ("ldp", False), ("intra", True)])
+def test_grouped_exchange_one_message_per_peer_and_wave(tmp_path, gop, p2p):
+    """three chains in one lockstep group over two ranks: pictures equal the single-process decode for every GOP shape, and the
+    exchange is counted: per wave ONE all-gather, or one send + one receive per peer that references the pictures — independent of
+    the number of chains — carrying n_chains pictures each"""
+    world, w, h, n_chains = 2, 128, 72, 3
+    out = str(tmp_path / "res")
+    mp.spawn(_grouped_worker, args=(world, _free_port(), w, h, out, gop, p2p, n_chains), nprocs=world, join=True)
+    want = _single_process_expectation(world, w, h, gop)
+    from openhevc_amd import parallel as P
+    for r in range(world):
+        got = torch.load(f"{out}.{r}")
+        comm = got.pop("comm")
+        plan = P.make_step_plan(world, r, n_waves=3, n_tail=2, seed=5, gop=gop)
+        mine = {str(pic.name) for pic in plan.pictures()} | {str(ref) for pic in plan.pictures() for ref in pic.refs}
+        for k in mine:
+            assert got[k] == want[r][k], f"{gop}: rank {r}: picture {k} differs from the single-process decode"
+        steps, waves = 2, 3
+        if not p2p:
+            assert comm["collectives"] == steps * waves and comm["messages"] == 0
+            assert comm["sent"] == comm["recv"] == steps * waves * n_chains * comm["half_bytes"] * (world - 1)
+        else:
+            ex = P.exchange_map(world, r, 3, 2, gop=gop)
+            n_msg = sum(len(a) + len(b) for a, b in ex)
+            assert comm["messages"] == steps * n_msg and comm["collectives"] == 0
+            assert comm["sent"] == steps * sum(len(a) for a, _ in ex) * n_chains * comm["half_bytes"]
+            if gop == "intra":
+                assert n_msg == 0                            # nothing references anything: nothing moves
+            else:
+                assert 0 < n_msg <= 2 * waves * (world - 1)
+
+
+def test_gop_shapes():
+    from openhevc_amd import parallel as P
+    for world in (1, 2, 4):
+        for r in range(world):
+            ldp = P.make_step_plan(world, r, gop="ldp")
+            assert [p.slice_type for p in ldp.waves] == [0, 1, 1, 1] and all(len(p.refs) == 1 for p in ldp.waves[1:] + ldp.tail)
+            assert all(p.refs[0] == ("ref", p.name[1] - 1, (r + 1) % world) for p in ldp.waves[1:])     # picture n on GPU n mod G reads GPU n-1's
+            intra = P.make_step_plan(world, r, gop="intra")
+            assert all(p.slice_type == 0 and not p.refs for p in intra.pictures())
+            assert P.pictures_per_step(ldp) == P.pictures_per_step(intra) == P.pictures_per_step(P.make_step_plan(world, r))
 
 
 def test_plan_is_balanced_and_cross_rank():

@@ -95,6 +95,15 @@ int oh_pics_md5(OhEngine *e, const int *pic_ids, int n, uint8_t *digests);
  * HEVCDSPContext.upsample_base_layer_frame (hevcdsp_template.c:2164-2438, call site hevc.c:3241).
  * 8-bit 4:2:0 only, like that routine (OH_E_UNSUPPORTED otherwise).  u: oh_upsample_setup(). */
 int oh_pic_upsample(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u);
+/* The same resampling for a LIST of CTBs of the enhancement-layer picture (raster addresses for CTBs of 1 << log2_ctb_size luma
+ * samples; the rest of dst_pic is left as it is): the granularity of the reference's default build, which up-samples a CTB when
+ * a prediction unit first reads the inter-layer reference there (ACTIVE_PU_UPSAMPLING hevc.h:117, ff_upsample_block
+ * hevc_filter.c:1370-1426, is_upsampled[]).  A decoder collects the CTBs its picture's inter-layer PUs touch and issues one call
+ * before the picture's work list.  Same samples as the reference's CTB path wherever that path and its whole-picture slot agree:
+ * no scaled reference layer offsets and no phase alignment (tests/test_upsample_vs_ref.py); offsets are refused
+ * (OH_E_UNSUPPORTED — use oh_pic_upsample).  The motion-field half of that path (ff_upscale_mv_block, hevc_filter.c:1311-1368)
+ * feeds merge / AMVP derivation (hevc_mvs.c), host work by SURVEY §8, and stays with the host decoder. */
+int oh_pic_upsample_ctbs(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u, int log2_ctb_size, const uint32_t *ctb_addrs, int n);
 
 /* work lists.  OhFrame.cur_pic / ref_pics[] hold engine picture ids.
  * upload copies every array to HBM (after it returns the host arrays may be reused);

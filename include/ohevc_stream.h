@@ -49,7 +49,8 @@ typedef struct OhStreamParams {
     int32_t coeff_density;              /* 1..100: how many coefficients a coded block gets */
     int32_t trace;                      /* 1: keep the list of syntax elements written (oh_stream_trace) */
     int32_t levels;                     /* 1: keep the quantised levels of every residual block written (oh_stream_levels); needs cu_qp_delta = 0 */
-    int32_t reserved[6];
+    int32_t conf_win_left, conf_win_right, conf_win_top, conf_win_bottom;   /* conformance window in luma samples (even), 0 = none */
+    int32_t reserved[2];
 } OhStreamParams;
 
 /* syntax elements of the slice data as (id, value) pairs in coding order — the writer's side of tests/test_streams.py; the ids are

@@ -181,7 +181,6 @@ static __host__ __device__ inline size_t oh_sao_stale_index(const OhPicParams *p
 struct OhUpPlane {
     const void *src; int32_t sstride, w_bl, h_bl;
     void *dst;       int32_t dstride, w_el, h_el;
-    int16_t *tmp;                                  /* [h_bl][w_el] */
     int32_t left, right_end_h, right_end_v, top, bottom_end;
     int32_t scale_x, add_x, scale_y, add_y, y_bias;
 };

@@ -98,8 +98,6 @@ struct OhEngine {
     double      host_ms[OH_N_HOST_TIMES] = {};   /* where the host time of the hand-over path goes (oh_engine_host_times) */
     uint64_t    host_calls[OH_N_HOST_TIMES] = {};
     uint64_t    up_bytes = 0;                    /* bytes of work lists sent over PCIe since the last reset */
-    int16_t    *up_tmp = nullptr;        /* intermediate rows of oh_pic_upsample */
-    size_t      up_tmp_elems = 0;
     uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
 };
 
@@ -293,8 +291,6 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &ev : e->sync_events) (void)hipEventDestroy(ev);
     for (void *b : e->sum_pool) (void)hipHostFree(b);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-    if (e->up_tmp)
-        (void)hipFree(e->up_tmp);
     if (e->own_stream)
         (void)hipStreamDestroy(e->stream);
     delete e;
@@ -430,40 +426,56 @@ extern "C" int oh_pic_set_final_half(OhEngine *e, int pic_id, int half)
 }
 
 /* SHVC inter-layer reference: upsample_base_layer_frame (hevcdsp_template.c:2164-2438, called at hevc.c:3241) */
-extern "C" int oh_pic_upsample(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u)
+static OhEngine::Stage *stage_acquire(OhEngine *e, size_t bytes);
+
+/* SHVC up-sampling of tiles of the enhancement-layer picture: ctbs == nullptr: the whole picture (the reference's whole-picture
+ * slot, hevc.c:3241); else the listed CTBs (raster addresses, CTB size 1 << log2_ctb) — the on-demand granularity of the
+ * reference's default build (ff_upsample_block, hevc_filter.c:1370-1426: a CTB is up-sampled when a PU first predicts from it) */
+static int upsample_tiles(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u, int log2_ctb, const uint32_t *ctbs, int n_ctbs, const char *who)
 {
     if (!e || !u)
         return OH_E_ARG;
     Pic *el = get_pic(e, dst_pic), *bl = get_pic(e, src_pic);
     if (!el || !bl || el == bl)
-        FAIL(e, OH_E_ARG, "oh_pic_upsample: bad picture ids");
+        FAIL(e, OH_E_ARG, "%s: bad picture ids", who);
     if (el->p.bit_depth != 8 || bl->p.bit_depth != 8 || el->p.chroma_format_idc != 1 || bl->p.chroma_format_idc != 1)
-        FAIL(e, OH_E_UNSUPPORTED, "oh_pic_upsample: the reference's frame up-sampler is written for 8-bit 4:2:0 (byte edge buffers, shift 12)");
+        FAIL(e, OH_E_UNSUPPORTED, "%s: the reference's up-sampler is written for 8-bit 4:2:0 (byte edge buffers, shift 12)", who);
     const int w_el = el->p.width, h_el = el->p.height, w_bl = bl->p.width, h_bl = bl->p.height;
     if (u->win_left < 0 || u->win_right < 0 || u->win_top < 0 || u->win_bottom < 0 || u->win_left + u->win_right >= w_el ||
         u->win_top + u->win_bottom >= h_el || u->scale_x_lum <= 0 || u->scale_y_lum <= 0 || u->scale_x_cr <= 0 || u->scale_y_cr <= 0)
-        FAIL(e, OH_E_ARG, "oh_pic_upsample: bad window / scale");
+        FAIL(e, OH_E_ARG, "%s: bad window / scale", who);
+    if (u->scale_x_lum > 65536 || u->scale_y_lum > 65536 || u->scale_x_cr > 65536 || u->scale_y_cr > 65536)
+        FAIL(e, OH_E_UNSUPPORTED, "%s: the enhancement layer is smaller than the base layer (scale > 1): not a spatial-scalability configuration", who);
     HIPCHK(e, hipSetDevice(e->device));
-    const size_t need = (size_t)w_el * (size_t)(h_bl > h_el ? h_bl : h_el);
-    if (need > e->up_tmp_elems) {
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (e->up_tmp) (void)hipFree(e->up_tmp);
-        e->up_tmp = nullptr; e->up_tmp_elems = 0;
-        if (hipMalloc((void **)&e->up_tmp, need * sizeof(int16_t)) != hipSuccess)
-            FAIL(e, OH_E_NOMEM, "oh_pic_upsample: hipMalloc(%zu) failed", need * sizeof(int16_t));
-        e->up_tmp_elems = need;
+    const int tile = ctbs ? 1 << log2_ctb : 64;
+    const uint32_t *dlist = nullptr;
+    OhEngine::Stage *sg = nullptr;
+    if (ctbs) {
+        if (log2_ctb < 4 || log2_ctb > 6 || n_ctbs < 0)
+            FAIL(e, OH_E_ARG, "%s: CTB size / count", who);
+        if (!n_ctbs)
+            return OH_OK;
+        const uint32_t n_ctb = (uint32_t)(((w_el + tile - 1) / tile) * ((h_el + tile - 1) / tile));
+        for (int i = 0; i < n_ctbs; i++)
+            if (ctbs[i] >= n_ctb)
+                FAIL(e, OH_E_ARG, "%s: CTB address %u of %u", who, ctbs[i], n_ctb);
+        sg = stage_acquire(e, (size_t)n_ctbs * sizeof(uint32_t));       /* pinned and mapped: the kernels read the list there */
+        if (!sg)
+            FAIL(e, OH_E_NOMEM, "%s: no staging buffer", who);
+        memcpy(sg->p, ctbs, (size_t)n_ctbs * sizeof(uint32_t));
+        dlist = (const uint32_t *)sg->p;
     }
     void *const *src = bl->final_b ? bl->b : bl->a;
     OhUpPlane a;
     /* luma: BL rows = min(BL height, EL height) (:2220); x clipped to [left, right_end] inclusive (:2223) */
     a.src = src[0]; a.sstride = bl->stride[0]; a.w_bl = w_bl; a.h_bl = h_bl <= h_el ? h_bl : h_el;
-    a.dst = el->a[0]; a.dstride = el->stride[0]; a.w_el = w_el; a.h_el = h_el; a.tmp = e->up_tmp;
+    a.dst = el->a[0]; a.dstride = el->stride[0]; a.w_el = w_el; a.h_el = h_el;
     a.left = u->win_left; a.right_end_h = w_el - u->win_right; a.right_end_v = w_el - u->win_right;
     a.top = u->win_top; a.bottom_end = h_el - u->win_bottom;
     a.scale_x = u->scale_x_lum; a.add_x = u->add_x_lum; a.scale_y = u->scale_y_lum; a.add_y = u->add_y_lum; a.y_bias = 0;
-    ohk_upsample_plane(&a, 8, e->stream);
+    ohk_upsample_plane(&a, 8, tile, tile, dlist, n_ctbs, e->stream);
     /* chroma: BL rows = max(BL height, EL chroma height) >> 1 (:2317-2320); x clipped to [left, right_end - 1] (:2324);
-     * the vertical position carries the -4 of :2384 */
+     * the vertical position carries the -4 of :2384.  A CTB's chroma tile has the same index in a grid of half-size tiles. */
     const int wc_el = w_el >> 1, hc_el = h_el >> 1;
     for (int c = 1; c <= 2; c++) {
         a.src = src[c]; a.sstride = bl->stride[c]; a.w_bl = w_bl >> 1; a.h_bl = (h_bl > hc_el ? h_bl : hc_el) >> 1;
@@ -472,11 +484,34 @@ extern "C" int oh_pic_upsample(OhEngine *e, int dst_pic, int src_pic, const OhUp
         a.left = u->win_left >> 1; a.right_end_v = wc_el - (u->win_right >> 1); a.right_end_h = a.right_end_v - 1;
         a.top = u->win_top >> 1; a.bottom_end = hc_el - (u->win_bottom >> 1);
         a.scale_x = u->scale_x_cr; a.add_x = u->add_x_cr; a.scale_y = u->scale_y_cr; a.add_y = u->add_y_cr; a.y_bias = 4;
-        ohk_upsample_plane(&a, 4, e->stream);
+        ohk_upsample_plane(&a, 4, tile >> 1, tile >> 1, dlist, n_ctbs, e->stream);
     }
     HIPCHK(e, hipGetLastError());
+    if (sg) {
+        HIPCHK(e, hipEventRecord(sg->done, e->stream));
+        sg->busy = true;
+    }
     el->final_b = false;                                   /* the resampled picture is a finished picture in half 0 */
     return OH_OK;
+}
+
+extern "C" int oh_pic_upsample(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u)
+{
+    return upsample_tiles(e, dst_pic, src_pic, u, 6, nullptr, 0, "oh_pic_upsample");
+}
+
+extern "C" int oh_pic_upsample_ctbs(OhEngine *e, int dst_pic, int src_pic, const OhUpsample *u, int log2_ctb_size, const uint32_t *ctb_addrs, int n)
+{
+    if (!ctb_addrs && n)
+        return OH_E_ARG;
+    /* the reference's block path positions by its block driver and its x2 / x1.5 slots ignore the phase: with scaled reference
+     * layer offsets or phase alignment it produces OTHER samples than the whole-picture slot (tests/test_upsample_vs_ref.py
+     * records both).  This entry point is the whole-picture arithmetic per CTB, so it stands for the block path only where the
+     * reference's two paths agree. */
+    if (u && (u->win_left || u->win_right || u->win_top || u->win_bottom))
+        FAIL(e, OH_E_UNSUPPORTED, "oh_pic_upsample_ctbs: scaled reference layer offsets — the reference's CTB path and its whole-picture slot differ there; use oh_pic_upsample");
+    static const uint32_t none = 0;
+    return upsample_tiles(e, dst_pic, src_pic, u, log2_ctb_size, n ? ctb_addrs : &none, n, "oh_pic_upsample_ctbs");
 }
 
 extern "C" int oh_pic_upload(OhEngine *e, int pic_id, const uint8_t *const planes[3], const ptrdiff_t strides[3])

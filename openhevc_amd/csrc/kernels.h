@@ -22,7 +22,7 @@ void ohk_residual(const OhBatch *B, int n, const OhPicParams *p, const uint32_t 
 void ohk_cross(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_cross, hipStream_t st);
 void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st);
 void ohk_deblock(const OhBatch *B, int n, const OhPicParams *p, int horiz, hipStream_t st);
-void ohk_upsample_plane(const OhUpPlane *a, int taps, hipStream_t st);
+void ohk_upsample_plane(const OhUpPlane *a, int taps, int tw, int th, const uint32_t *list, int n_list, hipStream_t st);
 void ohk_sao(const OhBatch *B, int n, const OhPicParams *p, hipStream_t st);
 void ohk_prepare(const OhBatch *B, int nb, const OhPrepCounts *max_counts, uint32_t max_mc_runs, uint32_t max_cross, hipStream_t st);
 void ohk_bs_derive(const OhPicParams *p, const void *mvf, const void *cbf, const void *call_log2, const void *ctb_flags,

@@ -57,6 +57,7 @@ def lib():
         L.oh_pic_upload.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download_window.argtypes = [V, I, C.POINTER(OhWindow), C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
+        L.oh_pic_upsample_ctbs.argtypes = [V, I, I, C.c_void_p, I, C.POINTER(C.c_uint32), I]
         L.oh_pics_md5.argtypes = [V, C.POINTER(C.c_int), I, C.POINTER(C.c_uint8)]
         L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
         L.oh_frames_upload.argtypes = [V, C.POINTER(C.POINTER(F.OhFrame)), I, PP]
@@ -189,6 +190,10 @@ class Engine:
         self._chk(self.L.oh_pic_upsample(self.h, dst_pid, src_pid, C.byref(u)), "oh_pic_upsample")
 
     # ---- work lists ----
+    def pic_upsample_ctbs(self, dst_pid, src_pid, u, log2_ctb_size, ctb_addrs):
+        a = (C.c_uint32 * max(len(ctb_addrs), 1))(*ctb_addrs)
+        self._chk(self.L.oh_pic_upsample_ctbs(self.h, dst_pid, src_pid, C.byref(u), log2_ctb_size, a, len(ctb_addrs)), "oh_pic_upsample_ctbs")
+
     def frame_upload(self, frame):
         df = C.c_void_p()
         self._chk(self.L.oh_frame_upload(self.h, C.byref(frame), C.byref(df)), "oh_frame_upload")

@@ -314,7 +314,14 @@ static void write_sps(W *w)
     put_ue(&b, 0);                                         /* sps id */
     put_ue(&b, 1);                                         /* chroma_format_idc 4:2:0 */
     put_ue(&b, (uint32_t)p->width); put_ue(&b, (uint32_t)p->height);
-    put_bit(&b, 0);                                        /* conformance window */
+    {   /* conformance window, offsets in chroma sample units (4:2:0: two luma samples) */
+        const int any = p->conf_win_left | p->conf_win_right | p->conf_win_top | p->conf_win_bottom;
+        put_bit(&b, any != 0);
+        if (any) {
+            put_ue(&b, (uint32_t)p->conf_win_left / 2); put_ue(&b, (uint32_t)p->conf_win_right / 2);
+            put_ue(&b, (uint32_t)p->conf_win_top / 2); put_ue(&b, (uint32_t)p->conf_win_bottom / 2);
+        }
+    }
     put_ue(&b, (uint32_t)p->bit_depth - 8); put_ue(&b, (uint32_t)p->bit_depth - 8);
     put_ue(&b, 4);                                         /* log2_max_poc_lsb = 8 */
     put_bit(&b, 1);

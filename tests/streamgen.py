@@ -12,7 +12,7 @@ _FIELDS = ("width", "height", "bit_depth", "log2_ctb_size", "log2_min_tb_size", 
 
 
 class OhStreamParams(C.Structure):
-    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in _FIELDS] + [("trace", C.c_int32), ("levels", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in _FIELDS] + [("trace", C.c_int32), ("levels", C.c_int32)] + [(n, C.c_int32) for n in ("conf_win_left", "conf_win_right", "conf_win_top", "conf_win_bottom")] + [("reserved", C.c_int32 * 2)]
 
 
 SE_NAMES = ("", "sao_merge", "sao_type", "sao_offset_abs", "sao_offset_sign", "sao_band_pos", "sao_eo_class", "end_of_slice", "split_cu", "bypass_flag",

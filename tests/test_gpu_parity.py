@@ -383,6 +383,42 @@ def test_shvc_upsample_pictures(eng):
             rec.close()
         eng.pic_free(b_id)
         eng.pic_free(e_id)
+    # on-demand granularity: a list of CTBs (what ff_upsample_block marks in is_upsampled[]) gives the whole-picture samples inside
+    # those CTBs and leaves every other sample alone; all CTBs = the whole picture — for 64, 32 and 16 sample CTBs
+    for case in gold["cases"]:
+        u, bl, pe = upsample_inputs(case)
+        if u.win_left or u.win_right or u.win_top or u.win_bottom:
+            b_id, e_id = eng.pic_alloc(bl.params), eng.pic_alloc(pe)
+            with pytest.raises(EngineError):                # the reference's own CTB path differs from its whole-picture slot there
+                eng.pic_upsample_ctbs(e_id, b_id, u, 6, [0])
+            eng.pic_free(b_id)
+            eng.pic_free(e_id)
+            continue
+        b_id, whole, part = eng.pic_alloc(bl.params), eng.pic_alloc(pe), eng.pic_alloc(pe)
+        eng.pic_upload(b_id, bl)
+        eng.pic_upsample(whole, b_id, u)
+        want = eng.pic_download(whole, pe)
+        for lc in (6, 5, 4):
+            ctb = 1 << lc
+            cw, ch = (pe.width + ctb - 1) >> lc, (pe.height + ctb - 1) >> lc
+            rng = np.random.default_rng(lc)
+            some = sorted(rng.choice(cw * ch, size=max(1, cw * ch // 3), replace=False).tolist())
+            blank = F.HostPic(pe, fill=7)
+            eng.pic_upload(part, blank)
+            eng.pic_upsample_ctbs(part, b_id, u, lc, some)
+            got = eng.pic_download(part, pe)
+            for c in range(3):
+                s = 1 if c else 0
+                g, w_, mask = got.visible(c), want.visible(c), np.zeros(got.visible(c).shape, bool)
+                for a in some:
+                    x0, y0 = (a % cw) * (ctb >> s), (a // cw) * (ctb >> s)
+                    mask[y0:y0 + (ctb >> s), x0:x0 + (ctb >> s)] = True
+                assert np.array_equal(g[mask], w_[mask]) and (g[~mask] == 7).all(), (case[0], lc, c)
+            eng.pic_upsample_ctbs(part, b_id, u, lc, [a for a in range(cw * ch) if a not in some])
+            assert md5_planes(eng.pic_download(part, pe)) == gold["expected"][case[0]], (case[0], lc)
+            eng.pic_upsample_ctbs(part, b_id, u, lc, [])                     # an empty list is nothing to do
+        for i in (b_id, whole, part):
+            eng.pic_free(i)
     # the reference's routine is 8-bit only: a 10-bit request is refused, not approximated
     p10 = F.pic_params(416, 240, bit_depth=10)
     a, b = eng.pic_alloc(p10), eng.pic_alloc(p10)

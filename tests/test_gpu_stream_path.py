@@ -109,3 +109,33 @@ def test_harness_decodes_streams_and_the_gpu_md5_matches_the_sei(case, tmp_path)
     # -c: no check, -s: stop early
     r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-c", "-s", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MD5" not in r.stdout and r.stdout.strip().splitlines()[-1].startswith("frame= 2 ")
+
+
+@need_front_end
+@pytest.mark.parametrize("bit_depth,win", [(8, (6, 10, 4, 12)), (10, (0, 2, 8, 0)), (8, (14, 0, 0, 2))], ids=["8bit", "10bit", "8bit_left_bottom"])
+def test_output_window_equals_the_reference_decoder_output(bit_depth, win):
+    """SURVEY §8 f4 pinned against the reference: a stream whose SPS carries a conformance window — the reference decoder outputs
+    the cropped pictures (ff_hevc_output_frame hevc_refs.c:248-254 + libOpenHevcGetOutputCpy); the engine reconstructs the coded
+    pictures from the recorded work lists and oh_pic_download_window must hand back exactly those planes"""
+    import refdec
+    import streamgen
+    from openhevc_amd.engine import Engine, remap_frame
+    left, right, top, bottom = win
+    data, _ = streamgen.write_stream(416, 240, 90 + bit_depth, n_pictures=3, gop=2, bit_depth=bit_depth, conf_win_left=left, conf_win_right=right,
+                                     conf_win_top=top, conf_win_bottom=bottom)
+    want = refdec.decode(data)
+    assert want[0][0].shape == (240 - top - bottom, 416 - left - right)
+    eng = Engine(0)
+    ids, got = {}, []
+
+    def on_picture(f, cur, poc):
+        for i in [cur] + [f.ref_pics[k] for k in range(F.OH_MAX_REFS) if f.ref_pics[k] >= 0]:
+            if i not in ids:
+                ids[i] = eng.pic_alloc(f.p)
+        eng.frame_submit(remap_frame(f, ids))
+        got.append(eng.pic_download_window(ids[cur], f.p, left=left, right=right, top=top, bottom=bottom, pad=64 if bit_depth == 8 else 0))
+    assert refdec.record_work_lists(data, on_picture) == 3
+    eng.close()
+    for k in range(3):
+        for c in range(3):
+            assert np.array_equal(got[k][c], want[k][c]), (k, c)

@@ -117,5 +117,6 @@ def test_engine_dequantisation_reproduces_the_reference_decoder(case):
         eng.frame_submit(remap_frame(f, ids))
         got = eng.pic_download(ids[cur], f.p)
         for c in range(3):
-            assert np.array_equal(got.visible(c), want[k][c]), (case[0], "picture", k, "plane", c)
+            d = np.argwhere(got.visible(c) != want[k][c])
+            assert len(d) == 0, (case[0], "picture", k, "plane", c, "samples", len(d), "first", d[:4].tolist(), "box", d.min(0).tolist(), d.max(0).tolist())
     eng.close()

@@ -140,3 +140,17 @@ def test_committed_fixtures_are_current():
         assert hashlib.md5(data).digest() == have["stream_md5"].tobytes(), name
         want = refdec.decode(data)
         assert b"".join(b"".join(refdec.md5_of(p)) for p in want) == have["md5"].tobytes(), name
+
+
+def test_conformance_window_is_cropped_by_the_reference_output():
+    """the writer's conformance window reaches the reference's output path: its pictures are the coded pictures (here: reconstructed by
+    the checker from the recorded work lists) cropped by the window — the data the engine's oh_pic_download_window is pinned on (-m gpu)"""
+    left, right, top, bottom = 6, 10, 4, 12
+    data, _ = streamgen.write_stream(416, 240, 97, n_pictures=3, gop=2, conf_win_left=left, conf_win_right=right, conf_win_top=top, conf_win_bottom=bottom)
+    want = refdec.decode(data)
+    full = decode_through_hooks(data)
+    for k in range(3):
+        for c in range(3):
+            s = 1 if c else 0
+            crop = full[k][c][top >> s:(240 >> s) - (bottom >> s), left >> s:(416 >> s) - (right >> s)]
+            assert np.array_equal(crop, want[k][c]), (k, c)

@@ -15,5 +15,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch --
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --steps 1 --no-cpu-baseline --no-profile > $O/bench_under_pmc_write.json 2> $O/rocprof_write.log
 echo "write done"
-python3 $R/tools/profile_round.py /tmp/p_stats /tmp/p_fetch /tmp/p_write $O r01
+python3 $R/tools/profile_round.py /tmp/p_stats /tmp/p_fetch /tmp/p_write $O r02
 ls -la $O

@@ -8,12 +8,15 @@
  * Arithmetic follows the reference exactly (file:line cited per kernel, paths relative to
  * /root/reference/libavcodec/); tests/ check every kernel bit-for-bit against the CPU checker.
  *
- *   pass 1  mc.hip        mc_kernel         one wave per <=16x16 luma tile (+ its chroma), LDS window + 2-stage filter
- *   pass 2  residual.hip  residual_kernel   one wave per transform block, two LDS matrix passes
- *   pass 3  intra.hip     intra_ctu_kernel  one workgroup per CTU of one wavefront level, waves take the blocks of a sub-level
+ *   hand-over prep.hip   prep_*           raw lists -> MC jobs, TU size buckets, intra descriptors, level statistics (one launch set per 32 lists)
+ *   pass 1  mc.hip        mc_kernel         a wave runs four <=8x8 blocks of one plane (16 lanes each): windows in LDS, v_dot2 h- and v-pass
+ *   pass 2  residual.hip  residual_kernel   one launch per size; sixteen 4x4 / four 8x8 / one 16x16 / one 32x32 block per wave, two LDS matrix passes
+ *   pass 3  intra.hip     intra_ctu_kernel  one workgroup per CTU of one wavefront level; <=8x8 blocks four per wave, prepared one sub-level ahead
  *   pass 4  deblock.hip   deblock_*_kernel  one lane per 4-line edge segment, V pass then H pass, in place
- *   pass 5  sao.hip       sao_kernel        one lane per sample, cur -> out
- *   SHVC    upsample.hip  upsample_*_kernel one lane per output sample, two launches per plane
+ *   pass 5  sao.hip       sao_kernel        eight samples per lane, CTB-uniform waves, half 0 -> half 1
+ *   BS      bs.hip        bs_kernel         optional: both boundary-strength grids from the motion field, one lane per 4x4 cell
+ *   SHVC    upsample.hip  upsample_tile_kernel  one workgroup per tile (CTB), window and horizontal rows in LDS
+ *   output  md5.hip       md5_kernel        one wave per (picture, plane) MD5 chain
  */
 #include "kernels_common.h"
 

@@ -50,95 +50,94 @@ static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, int v0, 
     *(uint2v *)lds = uint2v{ (unsigned)(v0 | (v1 << 16)), (unsigned)(v2 | (v3 << 16)) };
 }
 
-/* constrained_intra_pred (hevcpred_template.c:185-286) for one block, run by ONE lane over the wave's edge arrays
- * left[k] = E[1 + k], top[k] = E[67 + k] (k = -1..63) after the gather with the re-derived candidate flags.
- * lm / tm: bit g = the 4-sample group g of the left column / top row lies in an intra CU; corner likewise. */
-typedef __attribute__((address_space(3))) int lds_int;     /* keeps the accesses ds_* (a generic pointer would make them flat_*,
-                                                              which are not ordered against ds_* of the same wave) */
-static __device__ __forceinline__ void cip_patch(lds_int *E, const int n, const int avail, const unsigned lm, const unsigned tm, const bool corner_intra,
-                                              const int size_max_x, const int size_max_y, const int bl_size,
-                                              const bool x_nz, const bool y_nz, const int bd)
+/* constrained_intra_pred (hevcpred_template.c:185-286) for one block, lane-parallel.  Lane i owns left[i] and top[i] (i = 0..63) as
+ * gathered with the re-derived candidate flags (unavailable entries hold the reference's memset value); lm1 / tm1 are left[-1] /
+ * top[-1].  lm / tm: bit g = the 4-sample group g of the left column / top row lies in an intra CU; corner_intra likewise.
+ *
+ * The reference walks the arrays with four kinds of sweeps whose loop-carried value `a` only ever comes from an INTRA group, and
+ * intra groups are never written by the sweep that reads them — so every sweep is a map: a non-intra group takes one element of the
+ * nearest intra group before it (EXTEND_DOWN / RIGHT: its LAST element) or after it (EXTEND_UP: its FIRST element), found with
+ * clz / ctz on the group mask and fetched with one lane permute; EXTEND_LEFT only ever fills the run of non-intra samples in front
+ * of the first intra one.  The sweeps run in the reference's order, each on the arrays the previous one left, followed by its
+ * plain fills for unavailable edges (:251-286).  All conditions are wave-uniform.  tests: every `*_cip*` picture case, golden
+ * `b_10b_cip`, the random sweeps; the map form was checked against the sweep form on 200 k random edge configurations. */
+static __device__ __forceinline__ int cip_fwd(const int v, const unsigned mask, const int limit, const int init, const int lane)
 {
-    lds_int *left = E + 1, *top = E + 67;
+    const int g = lane >> 2;
+    const unsigned below = mask & ((1u << g) - 1u);
+    const int got = __shfl(v, below ? 4 * (31 - __clz((int)below)) + 3 : lane);
+    return (lane < limit && !((mask >> g) & 1u)) ? (below ? got : init) : v;
+}
+static __device__ __forceinline__ int cip_bwd(const int v, const unsigned mask, const int limit, const int lane)
+{
+    const int g = lane >> 2;
+    const unsigned above = ((mask >> (g + 1)) << (g + 1)) & ((1u << (limit >> 2)) - 1u);
+    const int init = __builtin_amdgcn_readlane(v, (limit - 1) & 63);
+    const int got = __shfl(v, above ? 4 * (__ffs((int)above) - 1) : lane);
+    return (lane < limit && !((mask >> g) & 1u)) ? (above ? got : init) : v;
+}
+static __device__ __forceinline__ void cip_lanes(int &Lv, int &Tv, int &corner, const int lane, const int n, const int avail, unsigned lm, unsigned tm,
+                                              const bool corner_intra, const int smx, const int smy, const int bl_size,
+                                              const bool x_nz, const bool y_nz, const int bd, int lm1, int tm1)
+{
     bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT, a_u = avail & OH_AV_UP, a_ur = avail & OH_AV_UP_RIGHT;
-    auto isl = [&](int j) { return j < 0 ? corner_intra : ((lm >> (j >> 2)) & 1) != 0; };
-    auto ist = [&](int j) { return j < 0 ? corner_intra : ((tm >> (j >> 2)) & 1) != 0; };
+    lm &= 0xffffu; tm &= 0xffffu;
     if (a_bl || a_l || a_ul || a_u || a_ur) {
-        int j = n + bl_size - 1;
+        /* first sample of the top row inside an intra CU, or size_max_x (:205-211, :217-219); an available edge always holds one */
+        const unsigned tmx = tm & ((1u << ((smx + 3) >> 2)) - 1u);
+        const int jt = min(tmx ? min(4 * (__ffs((int)tmx) - 1), smx) : smx, 63);
+        const int tj = __builtin_amdgcn_readlane(Tv, jt);
         if (a_bl || a_l || a_ul) {
-            while (j > -1 && !isl(j)) j--;
-            if (!isl(j)) {
-                j = 0;
-                while (j < size_max_x && !ist(j)) j++;
-                for (int i = j; i > -1; i--)
-                    if (!ist(i - 1)) top[i - 1] = top[i];
-                left[-1] = top[-1];
+            const int j0 = n + bl_size - 1;
+            if (!((lm & ((1u << ((j0 >> 2) + 1)) - 1u)) || corner_intra)) {       /* nothing intra in the left column or the corner: start from the top row */
+                if (lane < jt) Tv = tj;
+                tm1 = tj;
             }
-        } else {
-            j = 0;
-            while (j < size_max_x && !ist(j)) j++;
-            if (j > 0) {
-                for (int i = j; i > (x_nz ? -1 : 0); i--)
-                    if (!ist(i - 1)) top[i - 1] = top[i];
-                if (!x_nz) top[-1] = top[0];
-            }
+        } else if (jt > 0) {
+            if (lane < jt) Tv = tj;
+            if (!x_nz || !corner_intra) tm1 = tj;
         }
-        left[-1] = top[-1];
-        if (a_bl || a_l) {
-            int a = left[-1];
-            for (int i = 0; i < size_max_y; i += 4) {
-                if (!isl(i)) { left[i] = a; left[i + 1] = a; left[i + 2] = a; left[i + 3] = a; }
-                else a = left[i + 3];
-            }
-        }
-        if (!a_l)  for (int i = 0; i < n; i++) left[i] = left[-1];
-        if (!a_bl) { const int v = left[n - 1]; for (int i = 0; i < n; i++) left[n + i] = v; }
+        lm1 = tm1;
+        if (a_bl || a_l) Lv = cip_fwd(Lv, lm, smy, lm1, lane);
+        if (!a_l && lane < n) Lv = lm1;
+        if (!a_bl) { const int v = __builtin_amdgcn_readlane(Lv, (n - 1) & 63); if (lane >= n && lane < 2 * n) Lv = v; }
         if (!x_nz) {
-            for (int i = 0; i < size_max_y; i++) left[i] = 0;
+            if (lane < smy) Lv = 0;
         } else {
-            int a = left[size_max_y - 1];
-            for (int i = size_max_y - 1; i > -1; i -= 4) {
-                if (!isl(i - 3)) { left[i - 3] = a; left[i - 2] = a; left[i - 1] = a; left[i] = a; }
-                else a = left[i - 3];
-            }
-            if (y_nz && !corner_intra) left[-1] = left[0];
+            Lv = cip_bwd(Lv, lm, smy, lane);
+            if (y_nz && !corner_intra) lm1 = __builtin_amdgcn_readlane(Lv, 0);
         }
-        top[-1] = left[-1];
-        if (y_nz) {
-            int a = left[-1];
-            for (int i = 0; i < size_max_x; i += 4) {
-                if (!ist(i)) { top[i] = a; top[i + 1] = a; top[i + 2] = a; top[i + 3] = a; }
-                else a = top[i + 3];
-            }
-        }
+        tm1 = lm1;
+        if (y_nz) Tv = cip_fwd(Tv, tm, smx, lm1, lane);
     }
     /* missing samples, :251-286 */
     if (!a_bl) {
         if (a_l) {
-            const int v = left[n - 1];
-            for (int i = 0; i < n; i++) left[n + i] = v;
+            const int v = __builtin_amdgcn_readlane(Lv, (n - 1) & 63);
+            if (lane >= n && lane < 2 * n) Lv = v;
         } else if (a_ul) {
-            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            if (lane < 2 * n) Lv = lm1;
             a_l = true;
         } else if (a_u) {
-            left[-1] = top[0];
-            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            lm1 = __builtin_amdgcn_readlane(Tv, 0);
+            if (lane < 2 * n) Lv = lm1;
             a_ul = a_l = true;
         } else if (a_ur) {
-            for (int i = 0; i < n; i++) top[i] = top[n];
-            left[-1] = top[n];
-            for (int i = 0; i < 2 * n; i++) left[i] = left[-1];
+            const int v = __builtin_amdgcn_readlane(Tv, n & 63);
+            if (lane < n) Tv = v;
+            lm1 = v;
+            if (lane < 2 * n) Lv = lm1;
             a_u = a_ul = a_l = true;
         } else {
-            left[-1] = 1 << (bd - 1);
-            for (int i = 0; i < 2 * n; i++) { top[i] = left[-1]; left[i] = left[-1]; }
+            lm1 = 1 << (bd - 1);
+            if (lane < 2 * n) { Lv = lm1; Tv = lm1; }
         }
     }
-    if (!a_l)  { const int v = left[n]; for (int i = 0; i < n; i++) left[i] = v; }
-    if (!a_ul) left[-1] = left[0];
-    if (!a_u)  for (int i = 0; i < n; i++) top[i] = left[-1];
-    if (!a_ur) { const int v = top[n - 1]; for (int i = 0; i < n; i++) top[n + i] = v; }
-    top[-1] = left[-1];
+    if (!a_l) { const int v = __builtin_amdgcn_readlane(Lv, n & 63); if (lane < n) Lv = v; }
+    if (!a_ul) lm1 = __builtin_amdgcn_readlane(Lv, 0);
+    if (!a_u && lane < n) Tv = lm1;
+    if (!a_ur) { const int v = __builtin_amdgcn_readlane(Tv, (n - 1) & 63); if (lane >= n && lane < 2 * n) Tv = v; }
+    corner = lm1;                                                           /* top[-1] = left[-1] */
 }
 
 template <typename PX, bool CIP, bool STAGED>
@@ -190,19 +189,13 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const int t_0 = __builtin_amdgcn_readlane(tv, 0), t_n1 = __builtin_amdgcn_readlane(tv, n - 1), t_n = __builtin_amdgcn_readlane(tv, n & 63);
     int corner, left_i, top_i;
     if (CIP && (flags & OH_IF_CIP)) {
-        /* constrained intra prediction (own kernel instantiation, so the common one carries none of this): rare, so one lane replays the reference's sweeps over the published edges
-         * (cip_patch) instead of a lane-parallel closed form */
+        /* constrained intra prediction (own kernel instantiation, so the common one carries none of this): the reference's sweeps as
+         * lane-parallel maps over the edge arrays in registers (cip_lanes) */
         const int fill = sizeof(PX) == 1 ? 128 : 0x8080;                   /* memset(.., 128, ..) over 16-bit samples, :158-160 */
-        int *E = s.E;
-        E[1 + i] = l_ok ? lv : fill;
-        E[67 + i] = t_ok ? tv : fill;
-        if (lane == 0) { E[0] = a_ul ? cv : 0; E[66] = a_ul ? cv : 128; }
-        WSYNC();
-        if (lane == 0)
-            cip_patch((lds_int *)E, n, avail, w7 & 0xffff, w7 >> 16, (flags & OH_IF_CIP_CORNER) != 0, a_ur ? n + tr_size : n, a_bl ? n + bl_size : n,
-                      a_bl ? bl_size : 0, bx != 0, by != 0, bd);
-        WSYNC();
-        left_i = E[1 + i]; top_i = E[67 + i]; corner = E[0];
+        left_i = l_ok ? lv : fill;
+        top_i = t_ok ? tv : fill;
+        cip_lanes(left_i, top_i, corner, lane, n, avail, w7 & 0xffff, w7 >> 16, (flags & OH_IF_CIP_CORNER) != 0, a_ur ? n + tr_size : n, a_bl ? n + bl_size : n,
+                  a_bl ? bl_size : 0, bx != 0, by != 0, bd, a_ul ? cv : 0, a_ul ? cv : 128);
     } else if (a_bl || a_l) {
         left_i = i < n ? (a_l ? lv : l_n) : (a_bl ? lv : l_n1);
         corner = a_ul ? cv : (a_l ? l_0 : l_n);

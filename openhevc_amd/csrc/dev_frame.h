@@ -90,7 +90,8 @@ struct DevIntraCtu {
     uint32_t sub_first;
     uint16_t n_sub, ctu;
     uint32_t res_lo, res_cnt;     /* int16 elements; res_cnt == 0: blocks read their residual from HBM */
-    uint32_t item0, n_items;      /* the CTU's blocks: intra[item0 .. item0 + n_items) (= sub_start range, resolved on the host) */
+    uint32_t item0, n_items;      /* the CTU's blocks: intra[item0 .. item0 + (n_items & 0xffff)) (= sub_start range); n_items >> 16: the
+                                     samples they cover / 64 (all planes): a CTU that is mostly inter writes back its blocks, not its rectangle */
     int16_t  bx0, bx1, by0, by1;  /* CTU-local luma rectangle [x0,x1) x [y0,y1) that covers every sample a block of the
                                      CTU reads (its row above and column to the left, up to 2n): what gets staged */
 };

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
     const OhCtuAreas ar = oh_ctu_areas(lc, pp.chroma_format_idc);
 
     /* stage: block descriptors, sub-level table, residual blocks */
-    const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items, (uint32_t)OH_MAX_CTU_BLOCKS);
+    const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items & 0xffffu, (uint32_t)OH_MAX_CTU_BLOCKS), area64 = ctu.n_items >> 16;
     {
         const GLOBAL uint4v *__restrict__ src = (const GLOBAL uint4v *)(f->intra + item0);
         uint4v *dst = (uint4v *)items;
@@ -644,9 +644,35 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
         STAMP(t2);
         ACC(0, t0, t1); ACC(1, t1, t2);
     }
+    /* The last sub-level's barrier has been passed.  A CTU that is mostly INTER (B pictures: a few intra blocks scattered over a
+     * rectangle that spans the CTU) stores its blocks, a quarter wave per block, instead of the rectangle: measured on the
+     * >= 16 k-workgroup launches of B pictures the rectangle's write-back was 19 % of the launch (profiles/r02_intra_staging_experiment.txt) */
+    uint32_t rect = 0;
+    for (int c = 0; c < nplanes; c++) {
+        const int hs = hsh(pp, c), vs = vsh(pp, c);
+        rect += (uint32_t)(max(((ctu.bx1 + (1 << hs) - 1) >> hs) - max(ctu.bx0 >> hs, 0), 0) * max(((ctu.by1 + (1 << vs) - 1) >> vs) - max(ctu.by0 >> vs, 0), 0));
+    }
+    if (area64 * 64u * 2u < rect) {
+        const uint64_t gp0 = (uint64_t)f->cur.p[0], gp1 = (uint64_t)f->cur.p[1], gp2 = (uint64_t)f->cur.p[2];
+        const int st0 = f->cur.stride[0], st1 = f->cur.stride[1];
+        const int quarter = tid >> 4, sl = tid & 15, nq = nthr >> 4;
+        for (uint32_t it = quarter; it < n_items; it += nq) {
+            const uint32_t w0 = ((const uint32_t *)&items[it])[0], w1 = ((const uint32_t *)&items[it])[1];
+            const uint32_t w3 = ((const uint32_t *)&items[it])[3], w4 = ((const uint32_t *)&items[it])[4];
+            const int bx = w0 & 0xffff, by = w0 >> 16, ci = w1 & 0xff, log2 = (w1 >> 8) & 0xff, n = 1 << log2;
+            const int cm_off = w3 & 0xffff, rs = w4 & 0xffff, stride = ci ? st1 : st0;
+            GLOBAL PX *__restrict__ g = G_MUT(PX, ci == 0 ? gp0 : (ci == 1 ? gp1 : gp2)) + (size_t)by * stride + bx;
+            for (int gi = sl; gi < (n * n) >> 2; gi += 16) {
+                const int y = (4 * gi) >> log2, x0 = (4 * gi) & (n - 1);
+                const uint2v pk = *(const uint2v *)&M[cm_off + y * rs + x0];
+                GLOBAL PX *__restrict__ d = g + (size_t)y * stride + x0;
+                if (sizeof(PX) == 1) *(GLOBAL uint32_t *)d = __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200);
+                else                 *(GLOBAL uint2v *)d = pk;
+            }
+        }
+    } else
     /* the reconstructed CTU goes to HBM in one coalesced sweep: the staged rectangle inside the CTU (it covers every
-     * block; samples of inter blocks in it are rewritten with the values they were staged with).  The last sub-level's
-     * barrier has been passed. */
+     * block; samples of inter blocks in it are rewritten with the values they were staged with). */
     for (int c = 0; c < nplanes; c++) {
         const int hs = hsh(pp, c), vs = vsh(pp, c);
         const int wc = (1 << lc) >> hs, hc = (1 << lc) >> vs, rs = wc + 4;

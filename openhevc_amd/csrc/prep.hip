@@ -431,10 +431,12 @@ __global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
     unsigned long long lo = ~0ull, hi = 0;
     int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
     int any_res = 0, bad = 0;
+    uint32_t area = 0;                                        /* samples the CTU's blocks cover, all planes */
     for (uint32_t b = b0 + lane; b < b1; b += 64) {
         const uint4v q0 = *(const GLOBAL uint4v *)(di + b);
         const int x = q0[0] & 0xffff, y = q0[0] >> 16, ci = q0[1] & 0xff, log2 = (q0[1] >> 8) & 0xff, n = 1 << log2;
         const uint32_t res_off = q0[2];
+        area += 1u << (2 * log2);
         const int hs = hsh(p, ci), vs = vsh(p, ci);
         if ((uint32_t)((((y << vs) >> lc) * ctbw) + ((x << hs) >> lc)) != c.ctu) bad = 1;       /* the CTU is written back from c.ctu's origin */
         const int lx = x - ((((x << hs) >> lc) << lc) >> hs), ly = y - ((((y << vs) >> lc) << lc) >> vs);
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
         by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
         any_res |= __shfl_xor(any_res, d); bad |= __shfl_xor(bad, d);
         slot_passes += __shfl_xor((int)slot_passes, d);
+        area += (uint32_t)__shfl_xor((int)area, d);
     }
     if (bad) { if (!lane) fail(f, OH_PE_INTRA_TABLES, k); return; }
     uint32_t res_lo = 0, res_cnt = 0;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
         }
     if (!lane) {
         alignas(16) DevIntraCtu d;
-        d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu; d.item0 = b0; d.n_items = b1 - b0;
+        d.sub_first = c.sub_first; d.n_sub = c.n_sub; d.ctu = c.ctu; d.item0 = b0; d.n_items = (b1 - b0) | min((area + 63) >> 6, 0xffffu) << 16;
         d.res_lo = res_lo; d.res_cnt = res_cnt;
         d.bx0 = (int16_t)bx0; d.bx1 = (int16_t)bx1; d.by0 = (int16_t)by0; d.by1 = (int16_t)by1;
         uint4v q[2];
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(64) void prep_intra_levels(const OhBatch B)
         const DevIntraCtu d = gload(f->ictu + k);
         const uint32_t aux = f->ctu_aux[k];
         if (aux & 0x80000000u) staged = 0;
-        max_items = max(max_items, min(d.n_items, (uint32_t)OH_MAX_CTU_BLOCKS));
+        max_items = max(max_items, min(d.n_items & 0xffffu, (uint32_t)OH_MAX_CTU_BLOCKS));
         max_sub = max(max_sub, min((uint32_t)d.n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
         max_res = max(max_res, d.res_cnt);
         sum_items += aux & 0x7fffffffu;

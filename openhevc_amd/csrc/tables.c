@@ -62,7 +62,7 @@ static int resolve_dst(const uint8_t *dst, ptrdiff_t stride, int *c, int *x, int
     return 0;
 }
 
-/* source pointers lie in a reference picture (possibly in its padding) or in an emulation buffer */
+/* source pointers lie inside a reference plane or in an emulation buffer */
 static int resolve_src(const uint8_t *src, ptrdiff_t stride, int plane, int *slot, int *x, int *y)
 {
     for (int e = 0; e < 2; e++)
@@ -81,7 +81,11 @@ static int resolve_src(const uint8_t *src, ptrdiff_t stride, int plane, int *slo
         if (T.refs[s].linesize[plane] != stride || !resolve(&T.refs[s], plane, src, T.bpp, &xx, &yy))
             continue;
         int pw = T.p.width >> oh_hshift(&T.p, plane), ph = T.p.height >> oh_vshift(&T.p, plane);
-        if (xx >= -128 && yy >= -128 && xx < pw + 128 && yy < ph + 128) { best = s; *x = xx; *y = yy; break; }
+        /* INSIDE the plane, nothing looser: a block whose taps leave the picture goes through emulated_edge_mc first
+         * (hevc.c:1660-1675 and siblings), so a pointer that is not in an emulation buffer is the block's top-left sample inside
+         * its reference plane.  A tolerance around the plane would let the pointer match a NEIGHBOURING allocation — the frames of
+         * the DPB often lie back to back on the heap — and pick the wrong reference depending on where malloc put them. */
+        if (xx >= 0 && yy >= 0 && xx < pw && yy < ph) { best = s; *x = xx; *y = yy; break; }
     }
     if (best < 0)
         return 0;

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""stress: the sparse-pin cases through the engine many times; prints where a picture differs from the reference decoder's"""
+"""stress: the sparse-pin cases through the engine many times, lists prepared afresh every time (as the test does); prints where a
+picture differs from the reference decoder's and whether the prepared lists themselves changed between repetitions"""
+import hashlib
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,10 +11,20 @@ import test_sparse_pin as T
 from openhevc_amd import frame as F
 from openhevc_amd.engine import Engine, remap_frame
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-prep = {c[0]: T.sparse_work_lists(c) for c in T.CASES}
+seen = {}
 bad = 0
 for trial in range(n):
-    for name, (lists, want) in prep.items():
+    for case in T.CASES:
+        name = case[0]
+        lists, want = T.sparse_work_lists(case)
+        h = hashlib.md5()
+        for a, cur, _ in lists:
+            for k in sorted(a):
+                h.update(k.encode()); h.update(np.ascontiguousarray(a[k]).tobytes())
+        for p in want:
+            for pl in p: h.update(np.ascontiguousarray(pl).tobytes())
+        if seen.setdefault(name, h.hexdigest()) != h.hexdigest():
+            print("trial", trial, name, "HOST SIDE CHANGED: lists / reference pictures differ from the first preparation", flush=True)
         eng = Engine(0); ids = {}
         for k, (a, cur, _) in enumerate(lists):
             ff = F.FrameFromArrays(a); f = ff.frame
@@ -24,6 +36,7 @@ for trial in range(n):
                 d = np.argwhere(got.visible(c) != want[k][c])
                 if len(d):
                     bad += 1
-                    print("trial", trial, name, "picture", k, "plane", c, "mismatches", len(d), "first", d[:6].tolist(), "bbox", d.min(0).tolist(), d.max(0).tolist(), flush=True)
+                    print("trial", trial, name, "picture", k, "plane", c, "mismatches", len(d), "first", d[:6].tolist(), "bbox", d.min(0).tolist(), d.max(0).tolist(),
+                          "got", [int(got.visible(c)[tuple(q)]) for q in d[:4]], "want", [int(want[k][c][tuple(q)]) for q in d[:4]], flush=True)
         eng.close()
 print("done", n, "trials,", bad, "bad planes")

@@ -10,7 +10,7 @@
  * from the syntax, which is the point — the reference decoder (oracle/_ref, built from /root/reference) decodes these
  * streams and is the checker for everything downstream of entropy decoding (tests/test_streams.py).
  *
- * Scope: Main / Main 10 (4:2:0, 8 or 10 bit), one layer.  Written from the H.265 syntax (7.3) and CABAC (9.3) clauses.
+ * Scope: Main / Main 10 (4:2:0) and the 4:4:4 range-extension profile incl. cross-component prediction, 8 or 10 bit, one layer.  Written from the H.265 syntax (7.3) and CABAC (9.3) clauses.
  */
 #ifndef OHEVC_STREAM_H
 #define OHEVC_STREAM_H
@@ -50,7 +50,9 @@ typedef struct OhStreamParams {
     int32_t trace;                      /* 1: keep the list of syntax elements written (oh_stream_trace) */
     int32_t levels;                     /* 1: keep the quantised levels of every residual block written (oh_stream_levels); needs cu_qp_delta = 0 */
     int32_t conf_win_left, conf_win_right, conf_win_top, conf_win_bottom;   /* conformance window in luma samples (even), 0 = none */
-    int32_t reserved[2];
+    int32_t chroma_format_idc;          /* 1 (4:2:0, Main / Main 10) or 3 (4:4:4, format range extensions profile: chroma blocks of luma size incl. 4x4,
+                                           one intra_chroma_pred_mode per partition, chroma QP = min(qPi, 51)) */
+    int32_t cross_component_pred;       /* 4:4:4 only: cross_component_prediction_enabled_flag, random log2_res_scale_abs_plus1 / sign per chroma block */
 } OhStreamParams;
 
 /* syntax elements of the slice data as (id, value) pairs in coding order — the writer's side of tests/test_streams.py; the ids are
@@ -58,12 +60,14 @@ typedef struct OhStreamParams {
 enum { OH_SE_SAO_MERGE = 1, OH_SE_SAO_TYPE, OH_SE_SAO_OFFSET_ABS, OH_SE_SAO_OFFSET_SIGN, OH_SE_SAO_BAND_POS, OH_SE_SAO_EO_CLASS, OH_SE_END_OF_SLICE,
        OH_SE_SPLIT_CU, OH_SE_BYPASS_FLAG, OH_SE_SKIP, OH_SE_PRED_MODE, OH_SE_PART_MODE, OH_SE_PCM_FLAG, OH_SE_PREV_INTRA, OH_SE_MPM_IDX,
        OH_SE_REM_INTRA, OH_SE_CHROMA_MODE, OH_SE_MERGE_FLAG, OH_SE_MERGE_IDX, OH_SE_INTER_DIR, OH_SE_REF_IDX, OH_SE_MVD_X, OH_SE_MVD_Y, OH_SE_MVP,
-       OH_SE_ROOT_CBF, OH_SE_SPLIT_TU, OH_SE_CBF_LUMA, OH_SE_CBF_CHROMA, OH_SE_QP_DELTA_ABS, OH_SE_QP_DELTA_SIGN, OH_SE_RESIDUAL };
+       OH_SE_ROOT_CBF, OH_SE_SPLIT_TU, OH_SE_CBF_LUMA, OH_SE_CBF_CHROMA, OH_SE_QP_DELTA_ABS, OH_SE_QP_DELTA_SIGN, OH_SE_RESIDUAL,
+       OH_SE_RES_SCALE_ABS, OH_SE_RES_SCALE_SIGN };
 size_t oh_stream_trace(const int32_t **recs);            /* of the last oh_stream_write with trace = 1; pairs (id, value) */
 
 /* the residual blocks of the last oh_stream_write with levels = 1, in coding order, pictures one after the other, as uint32 words:
- *   log2_size | c_idx << 4 | transform_skip << 8 | cu_transquant_bypass << 9 | intra CU << 10 | qp << 16     qp: the block's QP with QpBdOffset
- *   n                                                                                                       number of non-zero levels
+ *   log2_size | c_idx << 4 | transform_skip << 8 | cu_transquant_bypass << 9 | intra CU << 10 | cross-component prediction << 11 |
+ *   no residual_coding() (a cross-component block with cbf = 0) << 12 | qp << 16                             qp: the block's QP with QpBdOffset
+ *   n | (uint8_t)res_scale_val << 24                                                                        number of non-zero levels
  *   n x (pos | (uint16_t)level << 16)                                                                       pos = y * N + x
  * — what residual_coding hands to de-quantisation (hevc_cabac.c:1478-1494, 1818-1841): the sparse hand-over of include/ohevc_frame.h is
  * built from this in tests/test_sparse_pin.py and must reproduce the reference decoder's pictures. */

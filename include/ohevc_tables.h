@@ -131,6 +131,12 @@ typedef void (*oh_intra_accessor)(struct HEVCContext *s, int x0, int y0, int c_i
 void oh_tables_bind(OhRecorder *rec, uint8_t *const cur_data[3], const int cur_linesize[3]);
 void oh_tables_bind_ref(int slot, uint8_t *const data[3], const int linesize[3]);
 void oh_tables_set_intra_accessor(oh_intra_accessor fn);
+/* Cross-component prediction (4:4:4 range extension, hevc.c:1295-1365, hevc_cabac.c:1942-1947): the reference adds
+ * (res_scale_val * luma residual) >> 3 to a chroma block's residual on the host, between the slot calls — with recording slots the
+ * luma residual does not exist yet.  The host decoder instead skips that addition and calls this right after it parsed the
+ * component's res_scale_val (hls_cross_component_pred): the NEXT chroma block that reaches transform_add is linked to the luma
+ * block of the same transform unit (oh_rec_tu_cross) and the engine does the addition.  INTEGRATION.md §10. */
+void oh_tables_cross(int res_scale_val);
 /* flush the PU being assembled; returns the number of slot calls that could not be translated
  * (unknown pointers, unsupported slots) since oh_tables_bind() */
 int  oh_tables_finish(void);

@@ -28,6 +28,8 @@ typedef struct Tables {
     int emu_next;
     /* list-0 half of a bi-predicted block: put_hevc_{q,e}pel into a stack int16 array */
     struct { const int16_t *tmp; int slot, mvx, mvy, valid; } l0;
+    /* cross-component prediction: the transform unit's luma block, and the scale announced for the next chroma block (oh_tables_cross) */
+    uint32_t last_y_tu; int last_y_valid, cross_pending, cross_scale;
     /* PU being assembled: recorded by the luma call, chroma calls only complete the weights */
     struct { int valid, x, y, w, h, ref[2], mv[2][2], weighted; OhWeights wp; } pu;
 } Tables;
@@ -166,6 +168,20 @@ static void transform_add_n(uint8_t *dst, int16_t *coeffs, ptrdiff_t stride, int
         oh_rec_intra_attach_tu(T.rec, T.li_index, tu);
         T.li_valid = 0;
     }
+    if (c == 0) {
+        T.last_y_tu = tu; T.last_y_valid = tu != OH_NO_COEFF;
+    } else if (T.cross_pending) {
+        /* the host decoder left the chroma block WITHOUT the scaled luma residual: link it, the engine adds
+         * (res_scale_val * luma residual) >> 3 once the luma residual exists */
+        if (!T.last_y_valid || tu == OH_NO_COEFF || oh_rec_tu_cross(T.rec, tu, T.last_y_tu, T.cross_scale) != 0) { T.untranslated++; T.why[0]++; }
+        T.cross_pending = 0;
+    }
+}
+
+void oh_tables_cross(int res_scale_val)
+{
+    T.cross_pending = res_scale_val != 0;                 /* scale 0 adds nothing */
+    T.cross_scale = res_scale_val;
 }
 static void s_transform_add0(uint8_t *d, int16_t *c, ptrdiff_t s) { transform_add_n(d, c, s, 2); }
 static void s_transform_add1(uint8_t *d, int16_t *c, ptrdiff_t s) { transform_add_n(d, c, s, 3); }

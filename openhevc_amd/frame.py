@@ -387,7 +387,7 @@ _FRAME_ARRAYS = (("pu", "n_pu", OhPu), ("wp", "n_wp", OhWeights), ("tu", "n_tu",
 def frame_to_arrays(f):
     """{name: numpy uint8 array} holding everything an OhFrame points at plus its scalar fields (dense work lists: no sparse records,
     no cross-component links, no bs_in)"""
-    assert not f.sparse and not f.tu_cross and not f.bs_in and not f.scaling, "only the dense hand-over is stored"
+    assert not f.sparse and not f.bs_in and not f.scaling, "only the dense hand-over is stored (cross-component links included)"
     p = f.p
     n_ctb = ((p.width + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size) * ((p.height + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size)
     n_pu = (p.width >> p.log2_min_pu_size) * (p.height >> p.log2_min_pu_size)
@@ -410,6 +410,8 @@ def frame_to_arrays(f):
     out["is_intra"] = grab(f.is_intra, n_pu)
     out["deblock"] = grab(f.deblock, n_ctb * C.sizeof(OhDeblockCtb))
     out["sao"] = grab(f.sao, n_ctb * C.sizeof(OhSaoCtb))
+    if f.tu_cross:
+        out["tu_cross"] = np.frombuffer(C.string_at(f.tu_cross, int(f.n_tu) * 4), dtype=np.uint32).copy()
     return out
 
 
@@ -440,6 +442,9 @@ class FrameFromArrays:
             f.n_sparse = int(self.a["sparse"].size)
             f.sparse, f.tu_sparse = ptr("sparse", C.c_uint32), ptr("tu_sparse", C.c_uint32)
             assert self.a["tu_sparse"].size == f.n_tu
+        if "tu_cross" in self.a:                          # optional: cross-component links (luma TU index | res_scale_val << 24 per TU)
+            assert self.a["tu_cross"].size == f.n_tu
+            f.tu_cross = ptr("tu_cross", C.c_uint32)
         if "scaling" in self.a:
             assert self.a["scaling"].nbytes == 4 * 6 * 64 + 2 * 6
             f.scaling = self.a["scaling"].ctypes.data

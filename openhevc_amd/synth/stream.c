@@ -78,7 +78,7 @@ enum {
     C_SAO_MERGE = 0, C_SAO_TYPE = 1, C_SPLIT_CU = 2, C_BYPASS_FLAG = 5, C_SKIP = 6, C_QP_DELTA = 9, C_PRED_MODE = 11, C_PART_MODE = 12,
     C_PREV_INTRA = 16, C_CHROMA_MODE = 17, C_MERGE_FLAG = 18, C_MERGE_IDX = 19, C_INTER_DIR = 20, C_REF_IDX = 25, C_MVD_GT0 = 27, C_MVD_GT1 = 28,
     C_MVP = 29, C_ROOT_CBF = 30, C_SPLIT_TU = 31, C_CBF_LUMA = 34, C_CBF_CHROMA = 36, C_TSKIP = 40, C_LAST_X = 42, C_LAST_Y = 60, C_CSBF = 78,
-    C_SIG = 82, C_GT1 = 124, C_GT2 = 148, N_CTX = 154
+    C_SIG = 82, C_GT1 = 124, C_GT2 = 148, C_RES_SCALE = 154, C_RES_SIGN = 162, N_CTX = 164
 };
 #define X 154                                        /* unused in this initialisation type */
 static const uint8_t k_init[3][N_CTX] = {
@@ -91,7 +91,8 @@ static const uint8_t k_init[3][N_CTX] = {
         111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125,
         140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111,
         140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
-        138, 153, 136, 167, 152, 152 },
+        138, 153, 136, 167, 152, 152,
+        154, 154, 154, 154, 154, 154, 154, 154, 154, 154 },            /* log2_res_scale_abs_plus1 (8), res_scale_sign_flag (2): range extension */
     {   /* initType 1 */
         153, 185, 107, 139, 126, 154, 197, 185, 201, 154, 154, 149, 154, 139, 154, 154, 154, 152, 110, 122, 95, 79, 63, 31, 31, 153, 153, 140, 198, 168, 79,
         124, 138, 94, 153, 111, 149, 107, 167, 154, 139, 139,
@@ -101,7 +102,8 @@ static const uint8_t k_init[3][N_CTX] = {
         155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
         170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140,
         154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-        107, 167, 91, 122, 107, 167 },
+        107, 167, 91, 122, 107, 167,
+        154, 154, 154, 154, 154, 154, 154, 154, 154, 154 },
     {   /* initType 2 */
         153, 160, 107, 139, 126, 154, 197, 185, 201, 154, 154, 134, 154, 139, 154, 154, 183, 152, 154, 137, 95, 79, 63, 31, 31, 153, 153, 169, 198, 168, 79,
         224, 167, 122, 153, 111, 149, 92, 167, 154, 139, 139,
@@ -111,7 +113,8 @@ static const uint8_t k_init[3][N_CTX] = {
         170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
         170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140,
         154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
-        107, 167, 91, 107, 107, 167 } };
+        107, 167, 91, 107, 107, 167,
+        154, 154, 154, 154, 154, 154, 154, 154, 154, 154 } };
 #undef X
 /* intra_chroma_pred_mode has one context; the second value of the element's table row belongs to it in no initialisation type */
 
@@ -210,13 +213,13 @@ static void lev_put(uint32_t v)
 size_t oh_stream_levels(const uint32_t **words) { *words = g_lev; return g_lev_n; }
 
 /* chroma QP of a block (8.6.1: qPi -> QpC for ChromaArrayType 1); the writer's PPS carries cb / cr offsets +1 / -2, no slice offsets */
-static int chroma_qp(int qp_y, int c_idx, int bit_depth)
+static int chroma_qp(int qp_y, int c_idx, int bit_depth, int chroma_format_idc)
 {
     static const uint8_t tab[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };     /* qPi 30..43 */
     const int bd_off = 6 * (bit_depth - 8);
     int qpi = qp_y + (c_idx == 1 ? 1 : -2);
     qpi = qpi < -bd_off ? -bd_off : qpi > 57 ? 57 : qpi;
-    const int qpc = qpi < 30 ? qpi : qpi >= 43 ? qpi - 6 : tab[qpi - 30];
+    const int qpc = chroma_format_idc != 1 ? (qpi < 51 ? qpi : 51) : qpi < 30 ? qpi : qpi >= 43 ? qpi - 6 : tab[qpi - 30];
     return qpc + bd_off;
 }
 
@@ -257,6 +260,7 @@ typedef struct W {
     int col_bd[64], row_bd[64], tcols, trows;
     Slice sl;
     int qp_delta_pending, cu_bypass;
+    int cross_pf, res_scale;                           /* cross-component prediction of the chroma block being coded */
     /* SAO parameters of the CTBs (for merge candidates we only need to know that they exist) */
 } W;
 
@@ -283,8 +287,9 @@ static void fill(uint8_t *m, const W *w, int x, int y, int n, int v)
 /* ================================================================================================= parameter sets */
 static void write_ptl(Bits *b, const OhStreamParams *p)
 {
-    put_bits(b, 0, 2); put_bit(b, 0); put_bits(b, p->bit_depth > 8 ? 2 : 1, 5);          /* profile space, tier, Main / Main 10 */
-    for (int i = 0; i < 32; i++) put_bit(b, i == (p->bit_depth > 8 ? 2 : 1) || i == 2);   /* compatibility flags */
+    const int profile = p->chroma_format_idc == 3 ? 4 : p->bit_depth > 8 ? 2 : 1;        /* Main / Main 10 / format range extensions */
+    put_bits(b, 0, 2); put_bit(b, 0); put_bits(b, (uint32_t)profile, 5);                  /* profile space, tier, profile */
+    for (int i = 0; i < 32; i++) put_bit(b, i == profile || (profile < 4 && i == 2));     /* compatibility flags */
     put_bit(b, 1); put_bit(b, 0); put_bit(b, 0); put_bit(b, 1);                           /* progressive, interlaced, non-packed, frame-only */
     put_bits(b, 0, 16); put_bits(b, 0, 16); put_bits(b, 0, 12);                           /* reserved 44 bits */
     put_bits(b, 186, 8);                                                                  /* level 6.2 */
@@ -312,7 +317,8 @@ static void write_sps(W *w)
     put_bits(&b, 0, 4); put_bits(&b, 0, 3); put_bit(&b, 1);                      /* vps id, max_sub_layers_minus1, temporal_id_nesting */
     write_ptl(&b, p);
     put_ue(&b, 0);                                         /* sps id */
-    put_ue(&b, 1);                                         /* chroma_format_idc 4:2:0 */
+    put_ue(&b, (uint32_t)p->chroma_format_idc);            /* 1 = 4:2:0, 3 = 4:4:4 */
+    if (p->chroma_format_idc == 3) put_bit(&b, 0);         /* separate_colour_plane_flag */
     put_ue(&b, (uint32_t)p->width); put_ue(&b, (uint32_t)p->height);
     {   /* conformance window, offsets in chroma sample units (4:2:0: two luma samples) */
         const int any = p->conf_win_left | p->conf_win_right | p->conf_win_top | p->conf_win_bottom;
@@ -375,7 +381,12 @@ static void write_sps(W *w)
     put_bit(&b, p->tmvp != 0);
     put_bit(&b, p->strong_intra_smoothing != 0);
     put_bit(&b, 0);                                        /* VUI */
-    put_bit(&b, 0);                                        /* extension */
+    if (p->chroma_format_idc == 3) {                       /* sps_range_extension with every tool flag off (7.3.2.2.2) */
+        put_bit(&b, 1); put_bit(&b, 1); put_bits(&b, 0, 7);
+        put_bits(&b, 0, 9);                                /* transform_skip_rotation .. cabac_bypass_alignment */
+    } else {
+        put_bit(&b, 0);                                    /* extension */
+    }
     rbsp_trailing(&b);
     emit_nal(&w->out, 33, b.buf, b.n / 8);
     free(b.buf);
@@ -417,7 +428,15 @@ static void write_pps(W *w)
     put_bit(&b, 0);                                        /* lists modification */
     put_ue(&b, 0);                                         /* log2_parallel_merge_level 2 */
     put_bit(&b, 0);                                        /* slice header extension */
-    put_bit(&b, 0);                                        /* pps extension */
+    if (p->chroma_format_idc == 3) {                       /* pps_range_extension (7.3.2.3.2) */
+        put_bit(&b, 1); put_bit(&b, 1); put_bits(&b, 0, 7);
+        if (p->transform_skip) put_ue(&b, 0);              /* log2_max_transform_skip_block_size_minus2 */
+        put_bit(&b, p->cross_component_pred != 0);
+        put_bit(&b, 0);                                    /* chroma_qp_offset_list_enabled_flag */
+        put_ue(&b, 0); put_ue(&b, 0);                      /* log2_sao_offset_scale_luma / chroma */
+    } else {
+        put_bit(&b, 0);                                    /* pps extension */
+    }
     rbsp_trailing(&b);
     emit_nal(&w->out, 34, b.buf, b.n / 8);
     free(b.buf);
@@ -517,6 +536,15 @@ static void code_remaining(Cabac *c, int value, int rice)
     }
 }
 
+/* a chroma block without coefficients whose residual is the scaled luma residual (cross-component prediction with cbf = 0,
+ * hevc.c:1315-1330): no syntax, but a block of the levels log */
+static void log_cross_only(W *w, int log2, int c_idx)
+{
+    if (!g_lev_on) return;
+    lev_put((uint32_t)log2 | (uint32_t)c_idx << 4 | (uint32_t)(w->cu_bypass != 0) << 9 | 1u << 11 | 1u << 12);   /* bit 12: no residual_coding() */
+    lev_put((uint32_t)(w->res_scale & 0xff) << 24);
+}
+
 /* codes one transform block with random coefficients; scan: 0 diagonal, 1 horizontal, 2 vertical */
 static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
 {
@@ -557,14 +585,16 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
     }
     if (last_sb < 0) { lev[0] = 1; last_sb = 0; last_pos = 0; lx = ly = 0; }
     if (g_lev_on) {
-        /* header: log2 | c_idx << 4 | transform_skip << 8 | cu_transquant_bypass << 9 | intra CU << 10 | QP (with QpBdOffset; valid while
-         * cu_qp_delta is off: the slice QP) << 16; then the number of levels; then pos | level << 16 in raster order */
+        /* header: log2 | c_idx << 4 | transform_skip << 8 | cu_transquant_bypass << 9 | intra CU << 10 | cross-component prediction << 11 |
+         * QP (with QpBdOffset; valid while cu_qp_delta is off: the slice QP) << 16; then the number of levels | res_scale_val << 24;
+         * then pos | level << 16 in raster order */
         const int bd_off = 6 * (w->p->bit_depth - 8);
-        const int qp = c_idx ? chroma_qp(w->sl.qp, c_idx, w->p->bit_depth) : w->sl.qp + bd_off;
-        lev_put((uint32_t)log2 | (uint32_t)c_idx << 4 | (uint32_t)tskip << 8 | (uint32_t)(w->cu_bypass != 0) << 9 | (uint32_t)(cu_intra != 0) << 10 | (uint32_t)qp << 16);
+        const int qp = c_idx ? chroma_qp(w->sl.qp, c_idx, w->p->bit_depth, w->p->chroma_format_idc) : w->sl.qp + bd_off;
+        lev_put((uint32_t)log2 | (uint32_t)c_idx << 4 | (uint32_t)tskip << 8 | (uint32_t)(w->cu_bypass != 0) << 9 | (uint32_t)(cu_intra != 0) << 10 |
+                (uint32_t)(w->cross_pf != 0 && c_idx != 0) << 11 | (uint32_t)qp << 16);
         uint32_t cnt = 0;
         for (int i = 0; i < n * n; i++) cnt += lev[i] != 0;
-        lev_put(cnt);
+        lev_put(cnt | (uint32_t)(c_idx ? w->res_scale & 0xff : 0) << 24);
         for (int i = 0; i < n * n; i++)
             if (lev[i]) lev_put((uint32_t)i | (uint32_t)(uint16_t)lev[i] << 16);
     }
@@ -672,11 +702,12 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
 }
 
 /* ---- transform tree ---- */
-typedef struct Cu { int x, y, log2, intra, part, bypass, merge_2Nx2N; int ipm[4], ipm_c; } Cu;
+typedef struct Cu { int x, y, log2, intra, part, bypass, merge_2Nx2N; int ipm[4], ipm_c[4], cm_c[4]; } Cu;   /* ipm_c / cm_c: chroma mode and intra_chroma_pred_mode per partition (one unless 4:4:4 NxN) */
 
+static int g_c444;                                    /* ChromaArrayType == 3 in the stream being written */
 static int scan_of(int mode, int log2, int c_idx)
 {
-    if (!(log2 == 2 || (log2 == 3 && c_idx == 0)))
+    if (!(log2 == 2 || (log2 == 3 && (c_idx == 0 || g_c444))))
         return 0;
     if (mode >= 6 && mode <= 14) return 2;
     if (mode >= 22 && mode <= 30) return 1;
@@ -700,14 +731,32 @@ static void code_tu(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
         }
     }
     const int pu = cu->part == PART_NxN && cu->intra ? blk : 0;
+    const int pc = g_c444 ? pu : 0;                        /* which chroma mode applies */
     if (cbf_luma)
         code_residual(w, log2, 0, cu->intra ? scan_of(cu->ipm[pu], log2, 0) : 0, cu->intra);
-    if (chroma_here) {
-        if (cbf_cb) code_residual(w, log2 - 1, 1, cu->intra ? scan_of(cu->ipm_c, log2 - 1, 1) : 0, cu->intra);
-        if (cbf_cr) code_residual(w, log2 - 1, 2, cu->intra ? scan_of(cu->ipm_c, log2 - 1, 2) : 0, cu->intra);
+    if (g_c444) {
+        /* 4:4:4: chroma blocks have the luma block's size, 4x4 included; cross-component prediction (7.3.8.12) in front of each */
+        const int cross = w->p->cross_component_pred && cbf_luma && (!cu->intra || cu->cm_c[pc] == 4);
+        for (int ci = 1; ci <= 2; ci++) {
+            int scale = 0;
+            if (cross) {
+                const int a = rnd(&w->g, 5), neg = rnd(&w->g, 2);        /* log2_res_scale_abs_plus1: truncated unary, 4 contexts per component */
+                for (int i = 0; i < 4 && i <= a; i++) { if (i < a) enc_bin(c, C_RES_SCALE + 4 * (ci - 1) + i, 1); else enc_bin(c, C_RES_SCALE + 4 * (ci - 1) + i, 0); }
+                tr(OH_SE_RES_SCALE_ABS, a);
+                if (a) { enc_bin(c, C_RES_SIGN + ci - 1, neg); tr(OH_SE_RES_SCALE_SIGN, neg); scale = (1 << (a - 1)) * (1 - 2 * neg); }
+            }
+            w->cross_pf = cross; w->res_scale = scale;
+            const int cbf = ci == 1 ? cbf_cb : cbf_cr;
+            if (cbf) code_residual(w, log2, ci, cu->intra ? scan_of(cu->ipm_c[pc], log2, ci) : 0, cu->intra);
+            else if (cross) log_cross_only(w, log2, ci);
+            w->cross_pf = 0; w->res_scale = 0;
+        }
+    } else if (chroma_here) {
+        if (cbf_cb) code_residual(w, log2 - 1, 1, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 1) : 0, cu->intra);
+        if (cbf_cr) code_residual(w, log2 - 1, 2, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 2) : 0, cu->intra);
     } else if (chroma_parent) {
-        if (cbf_cb) code_residual(w, 2, 1, cu->intra ? scan_of(cu->ipm_c, 2, 1) : 0, cu->intra);
-        if (cbf_cr) code_residual(w, 2, 2, cu->intra ? scan_of(cu->ipm_c, 2, 2) : 0, cu->intra);
+        if (cbf_cb) code_residual(w, 2, 1, cu->intra ? scan_of(cu->ipm_c[0], 2, 1) : 0, cu->intra);
+        if (cbf_cr) code_residual(w, 2, 2, cu->intra ? scan_of(cu->ipm_c[0], 2, 2) : 0, cu->intra);
     }
     (void)x; (void)y; (void)depth;
 }
@@ -726,7 +775,7 @@ static void code_tt(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
         split = log2 > p->log2_max_tb_size || (intra_split && depth == 0) || inter_split;
     }
     int cb = 0, cr = 0;
-    if (log2 > 2) {
+    if (log2 > 2 || g_c444) {
         if (depth == 0 || pcb) { cb = pct(&w->g, p->cbf_pct / 2 + 5); enc_bin(c, C_CBF_CHROMA + depth, cb); tr(OH_SE_CBF_CHROMA, cb); }
         if (depth == 0 || pcr) { cr = pct(&w->g, p->cbf_pct / 2 + 5); enc_bin(c, C_CBF_CHROMA + depth, cr); tr(OH_SE_CBF_CHROMA, cr); }
     } else {
@@ -923,12 +972,15 @@ static void code_cu(W *w, int x, int y, int log2)
             cu.ipm[k] = derive_ipm(w, px, py, prev[k], mpm[k], rem[k]);
             fill(w->pic.ipm, w, px, py, np == 4 ? h : n, cu.ipm[k]);
         }
-        const int cm = rnd(&w->g, 5);                      /* intra_chroma_pred_mode: 4 = derived from luma */
-        enc_bin(c, C_CHROMA_MODE, cm != 4);
-        if (cm != 4) enc_bypass_bits(c, (uint32_t)cm, 2);
-        tr(OH_SE_CHROMA_MODE, cm);
-        static const uint8_t tab[4] = { 0, 26, 10, 1 };
-        cu.ipm_c = cm == 4 ? cu.ipm[0] : (tab[cm] == cu.ipm[0] ? 34 : tab[cm]);
+        for (int k = 0; k < (g_c444 ? np : 1); k++) {      /* 4:4:4: one intra_chroma_pred_mode per partition (7.3.8.5) */
+            const int cm = rnd(&w->g, 5);                  /* 4 = derived from luma */
+            enc_bin(c, C_CHROMA_MODE, cm != 4);
+            if (cm != 4) enc_bypass_bits(c, (uint32_t)cm, 2);
+            tr(OH_SE_CHROMA_MODE, cm);
+            static const uint8_t tab[4] = { 0, 26, 10, 1 };
+            cu.cm_c[k] = cm;
+            cu.ipm_c[k] = cm == 4 ? cu.ipm[k] : (tab[cm] == cu.ipm[k] ? 34 : tab[cm]);
+        }
     } else {
         fill(w->pic.ipm, w, x, y, n, 1);
         const int q = n >> 2, h = n >> 1;
@@ -1192,7 +1244,7 @@ void oh_stream_defaults(OhStreamParams *p, int width, int height, uint64_t seed)
     memset(p, 0, sizeof(*p));
     p->seed = seed; p->width = width; p->height = height; p->bit_depth = 8; p->log2_ctb_size = 6;
     p->log2_min_tb_size = 2; p->log2_max_tb_size = 5; p->max_th_depth_intra = 2; p->max_th_depth_inter = 2;
-    p->n_pictures = 4; p->gop = 2; p->n_refs = 2; p->idr_period = 0; p->qp = 30;
+    p->n_pictures = 4; p->gop = 2; p->n_refs = 2; p->idr_period = 0; p->qp = 30; p->chroma_format_idc = 1;
     p->amp = 1; p->sao = 1; p->strong_intra_smoothing = 1; p->tmvp = 0;
     p->n_slices = 1; p->tile_cols = 1; p->tile_rows = 1; p->lf_across_slices = 1; p->lf_across_tiles = 1;
     p->split_pct = 50; p->intra_pct = 20; p->skip_pct = 25; p->merge_pct = 30; p->bi_pct = 40; p->cbf_pct = 55;
@@ -1206,11 +1258,15 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
         p->log2_max_tb_size < 3 || p->n_refs < 1 || p->n_refs > 4 || p->n_pictures < 1 || p->max_th_depth_intra < 0 || p->max_th_depth_intra > 3 ||
         p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3 || p->dependent_slices || p->sign_data_hiding)
         return -1;
+    if ((p->chroma_format_idc != 1 && p->chroma_format_idc != 3) || (p->cross_component_pred && p->chroma_format_idc != 3) ||
+        (p->chroma_format_idc == 3 && (p->pcm || p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))
+        return -1;                                         /* 4:4:4: no PCM (its chroma sample count differs), no window (the reference doubles the offsets) */
     W w;
     memset(&w, 0, sizeof(w));
     w.p = p;
     g_trace_on = p->trace != 0; g_trace_n = 0;
     g_lev_on = p->levels != 0 && !p->cu_qp_delta; g_lev_n = 0;
+    g_c444 = p->chroma_format_idc == 3;
     w.g.s = p->seed * 0x2545F4914F6CDD1Dull + 77;
     w.lc = p->log2_ctb_size; w.ctb = 1 << w.lc;
     w.ctbw = (p->width + w.ctb - 1) >> w.lc; w.ctbh = (p->height + w.ctb - 1) >> w.lc; w.n_ctb = w.ctbw * w.ctbh;

@@ -84,7 +84,7 @@ int main(int argc, char **argv)
     fseek(fi, 0, SEEK_END);
     const long fsize = ftell(fi);
     fseek(fi, 0, SEEK_SET);
-    uint8_t *data = (uint8_t *)malloc(fsize > 0 ? (size_t)fsize : 1);
+    uint8_t *data = (uint8_t *)calloc((size_t)(fsize > 0 ? fsize : 0) + 64, 1);          /* zero padding behind the last packet (FF_INPUT_BUFFER_PADDING_SIZE) */
     if (!data || fread(data, 1, (size_t)fsize, fi) != (size_t)fsize) { fprintf(stderr, "could not read %s\n", input); return 1; }
     fclose(fi);
 

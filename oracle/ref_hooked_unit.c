@@ -170,6 +170,20 @@ __attribute__((visibility("default"))) int ref_hooked_scaling_list(OhScalingList
     return H.scaling_on;
 }
 
+/* cross-component prediction.  hls_cross_component_pred (hevc.c:1186-1200) gets res_scale_val from these two
+ * CABAC elements; here the elements are parsed as always, the value goes to the recording tables (oh_tables_cross) and the
+ * decoder itself is told "0", so its own additions (hevc.c:1319-1331, 1352-1364, hevc_cabac.c:1942-1947) add nothing: the chroma
+ * block reaches transform_add with its own residual only and the engine adds the scaled luma residual. */
+void oh_tables_cross(int res_scale_val);
+static int hooked_log2_res_scale_abs(HEVCContext *s, int idx)
+{
+    const int a = ff_hevc_log2_res_scale_abs(s, idx);
+    const int neg = a ? ff_hevc_res_scale_sign_flag(s, idx) : 0;
+    oh_tables_cross(a ? (1 << (a - 1)) * (1 - 2 * neg) : 0);
+    return 0;
+}
+#define ff_hevc_log2_res_scale_abs(s, idx) hooked_log2_res_scale_abs(s, idx)
+
 #define ff_hevc_dsp_init(c, bd)   do { ff_hevc_dsp_init(c, bd);  ff_hevcdsp_init_hip((void *)(c), bd); } while (0)
 #define ff_hevc_pred_init(c, bd)  do { ff_hevc_pred_init(c, bd); ff_hevcpred_init_hip((void *)(c), bd); } while (0)
 #define ff_videodsp_init(c, bd)   do { ff_videodsp_init(c, bd);  ff_videodsp_init_hip((void *)(c), bd); } while (0)

@@ -15,22 +15,28 @@ typedef struct TraceRec { int32_t id, v; } TraceRec;
 static TraceRec *g_tr;
 static size_t g_n, g_cap;
 static int g_on;
+static FILE *g_file;
 static int tr_(int id, int v)
 {
+    if (g_file) { int32_t rec[2] = { id, v }; fwrite(rec, 4, 2, g_file); fflush(g_file); }     /* OH_TRACE_FILE: survives a crash of the decoder */
     if (g_on) {
         if (g_n == g_cap) { g_cap = g_cap ? 2 * g_cap : 1 << 16; g_tr = realloc(g_tr, g_cap * sizeof(*g_tr)); }
         g_tr[g_n].id = id; g_tr[g_n].v = v; g_n++;
     }
     return v;
 }
-__attribute__((visibility("default"))) void ref_trace_start(void) { g_n = 0; g_on = 1; }
+__attribute__((visibility("default"))) void ref_trace_start(void)
+{
+    g_n = 0; g_on = 1;
+    if (!g_file && getenv("OH_TRACE_FILE")) g_file = fopen(getenv("OH_TRACE_FILE"), "wb");
+}
 __attribute__((visibility("default"))) size_t ref_trace_get(const void **recs) { *recs = g_tr; return g_n; }
 
 /* ids shared with the writer's trace (include/ohevc_stream.h: OH_SE_*) */
 enum { SE_SAO_MERGE = 1, SE_SAO_TYPE, SE_SAO_OFFSET_ABS, SE_SAO_OFFSET_SIGN, SE_SAO_BAND_POS, SE_SAO_EO_CLASS, SE_END_OF_SLICE, SE_SPLIT_CU,
        SE_BYPASS_FLAG, SE_SKIP, SE_PRED_MODE, SE_PART_MODE, SE_PCM_FLAG, SE_PREV_INTRA, SE_MPM_IDX, SE_REM_INTRA, SE_CHROMA_MODE, SE_MERGE_FLAG,
        SE_MERGE_IDX, SE_INTER_DIR, SE_REF_IDX, SE_MVD_X, SE_MVD_Y, SE_MVP, SE_ROOT_CBF, SE_SPLIT_TU, SE_CBF_LUMA, SE_CBF_CHROMA,
-       SE_QP_DELTA_ABS, SE_QP_DELTA_SIGN, SE_RESIDUAL };
+       SE_QP_DELTA_ABS, SE_QP_DELTA_SIGN, SE_RESIDUAL, SE_RES_SCALE_ABS, SE_RES_SCALE_SIGN };
 
 #define ff_hevc_sao_merge_flag_decode(s)            tr_(SE_SAO_MERGE, ff_hevc_sao_merge_flag_decode(s))
 #define ff_hevc_sao_type_idx_decode(s)              tr_(SE_SAO_TYPE, ff_hevc_sao_type_idx_decode(s))
@@ -60,6 +66,8 @@ enum { SE_SAO_MERGE = 1, SE_SAO_TYPE, SE_SAO_OFFSET_ABS, SE_SAO_OFFSET_SIGN, SE_
 #define ff_hevc_cbf_cb_cr_decode(...)               tr_(SE_CBF_CHROMA, ff_hevc_cbf_cb_cr_decode(__VA_ARGS__))
 #define ff_hevc_cu_qp_delta_abs(s)                  tr_(SE_QP_DELTA_ABS, ff_hevc_cu_qp_delta_abs(s))
 #define ff_hevc_cu_qp_delta_sign_flag(s)            tr_(SE_QP_DELTA_SIGN, ff_hevc_cu_qp_delta_sign_flag(s))
+#define ff_hevc_log2_res_scale_abs(...)             tr_(SE_RES_SCALE_ABS, ff_hevc_log2_res_scale_abs(__VA_ARGS__))
+#define ff_hevc_res_scale_sign_flag(...)            tr_(SE_RES_SCALE_SIGN, ff_hevc_res_scale_sign_flag(__VA_ARGS__))
 #define ff_hevc_hls_mvd_coding(s, x0, y0, l)        do { ff_hevc_hls_mvd_coding(s, x0, y0, l); tr_(SE_MVD_X, (s)->HEVClc->pu.mvd.x); tr_(SE_MVD_Y, (s)->HEVClc->pu.mvd.y); } while (0)
 #define ff_hevc_hls_residual_coding(s, x0, y0, l, sc, c) do { tr_(SE_RESIDUAL, (l) | ((c) << 4) | ((sc) << 8)); ff_hevc_hls_residual_coding(s, x0, y0, l, sc, c); } while (0)
 

@@ -29,6 +29,9 @@ STREAM_CASES = [
                                                     lf_across_tiles=0, lf_across_slices=0)),
     ("p_weighted_cip_lists", 264, 200, 13, dict(n_pictures=3, gop=1, weighted_pred=1, scaling_list=1, constrained_intra_pred=1)),
     ("b_tmvp_3refs", 416, 240, 14, dict(n_pictures=4, gop=2, tmvp=1, cabac_init_present=1, deblocking_override=1, n_refs=3)),
+    # 4:4:4 range extension with cross-component prediction (work lists carry the cross links the hooked decoder's shim records)
+    ("b_444_ccp_8b", 264, 200, 15, dict(n_pictures=3, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1)),
+    ("i_444_ccp_10b_ctb16", 200, 136, 16, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, log2_ctb_size=4, log2_max_tb_size=4)),
 ]
 
 

@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_ref.so")
 REF_TREE = "/root/reference"
+PAD = bytes(64)                                                # zero bytes behind every packet handed to the decoder
 
 
 class Rational(C.Structure):
@@ -158,7 +159,8 @@ def decode(data, threads=1, thread_type=1, check_md5=False, L=None, keep=True):
         dt = np.uint8 if info.nBitDepth == 8 else np.uint16
         bpp = 1 if info.nBitDepth == 8 else 2
         w, hh = info.nWidth, info.nHeight
-        planes = [np.zeros((hh, w), dt), np.zeros((hh // 2, w // 2), dt), np.zeros((hh // 2, w // 2), dt)]
+        hs, vs = ((1, 1), (1, 0), (0, 0))[info.chromat_format]              # OpenHevc_ChromaFormat: YUV420, YUV422, YUV444
+        planes = [np.zeros((hh, w), dt), np.zeros((hh >> vs, w >> hs), dt), np.zeros((hh >> vs, w >> hs), dt)]
         fc = FrameCpy()
         fc.pvY, fc.pvU, fc.pvV = (pl.ctypes.data for pl in planes)
         fc.frameInfo = info
@@ -168,7 +170,7 @@ def decode(data, threads=1, thread_type=1, check_md5=False, L=None, keep=True):
 
     aus = split_access_units(data)
     for k, (a, b) in enumerate(aus):
-        got = L.libOpenHevcDecode(h, bytes(data[a:b]), b - a, k)
+        got = L.libOpenHevcDecode(h, bytes(data[a:b]) + PAD, b - a, k)          # packets are padded (FF_INPUT_BUFFER_PADDING_SIZE, avcodec.h)
         if got < 0:
             L.libOpenHevcClose(h)
             raise RuntimeError(f"reference decoder failed on access unit {k}")
@@ -237,7 +239,7 @@ def record_work_lists(data, on_picture):
     assert L.libOpenHevcStartDecoder(h) == 1
     n = 0
     for k, (a, b) in enumerate(split_access_units(data)):
-        if L.libOpenHevcDecode(h, bytes(data[a:b]), b - a, k) < 0:
+        if L.libOpenHevcDecode(h, bytes(data[a:b]) + PAD, b - a, k) < 0:
             L.libOpenHevcClose(h)
             raise RuntimeError(f"hooked reference decoder failed on access unit {k}")
         cur, poc, bad = C.c_int(), C.c_int(), C.c_int()

@@ -12,12 +12,13 @@ _FIELDS = ("width", "height", "bit_depth", "log2_ctb_size", "log2_min_tb_size", 
 
 
 class OhStreamParams(C.Structure):
-    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in _FIELDS] + [("trace", C.c_int32), ("levels", C.c_int32)] + [(n, C.c_int32) for n in ("conf_win_left", "conf_win_right", "conf_win_top", "conf_win_bottom")] + [("reserved", C.c_int32 * 2)]
+    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in _FIELDS] + [("trace", C.c_int32), ("levels", C.c_int32)] + [(n, C.c_int32) for n in ("conf_win_left", "conf_win_right", "conf_win_top", "conf_win_bottom")] + [("chroma_format_idc", C.c_int32), ("cross_component_pred", C.c_int32)]
 
 
 SE_NAMES = ("", "sao_merge", "sao_type", "sao_offset_abs", "sao_offset_sign", "sao_band_pos", "sao_eo_class", "end_of_slice", "split_cu", "bypass_flag",
             "skip", "pred_mode", "part_mode", "pcm_flag", "prev_intra", "mpm_idx", "rem_intra", "chroma_mode", "merge_flag", "merge_idx", "inter_dir",
-            "ref_idx", "mvd_x", "mvd_y", "mvp", "root_cbf", "split_tu", "cbf_luma", "cbf_chroma", "qp_delta_abs", "qp_delta_sign", "residual")
+            "ref_idx", "mvd_x", "mvd_y", "mvp", "root_cbf", "split_tu", "cbf_luma", "cbf_chroma", "qp_delta_abs", "qp_delta_sign", "residual",
+            "res_scale_abs", "res_scale_sign")
 
 
 class OhStream(C.Structure):

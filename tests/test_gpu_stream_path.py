@@ -74,6 +74,7 @@ STREAMS = [
     ("slices_tiles", 416, 240, 13, dict(n_pictures=5, gop=1, n_slices=3, tile_cols=2, tile_rows=2, lf_across_tiles=0)),
     ("intra_ctb16", 264, 200, 14, dict(n_pictures=3, gop=0, log2_ctb_size=4, log2_max_tb_size=4)),
     ("hd_main10", 1920, 1080, 15, dict(n_pictures=4, gop=2, bit_depth=10, wpp=1)),
+    ("rext444_ccp", 416, 240, 16, dict(n_pictures=4, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1)),
 ]
 
 

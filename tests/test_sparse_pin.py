@@ -25,6 +25,10 @@ CASES = [
     ("default_lists10", 416, 240, 53, dict(n_pictures=4, gop=2, bit_depth=10, scaling_list=1, transform_skip=1)),
     ("coded_lists8", 416, 240, 54, dict(n_pictures=4, gop=2, scaling_list=2, transform_skip=1, transquant_bypass=1, qp=35)),
     ("coded_lists10_ctb16", 264, 200, 55, dict(n_pictures=3, gop=1, bit_depth=10, scaling_list=2, log2_ctb_size=4, log2_max_tb_size=4, qp=18)),
+    # 4:4:4 with cross-component prediction: the chroma blocks' levels are de-quantised and transformed on the GPU and the scaled luma
+    # residual is added there (cross_kernel) — the links come from the hooked decoder's shim
+    ("ccp444_8", 264, 200, 56, dict(n_pictures=3, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1)),
+    ("ccp444_10_lists_intra", 200, 136, 57, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, scaling_list=2, qp=24)),
 ]
 OH_TUF_SPARSE, OH_NO_COEFF, OH_FLAT_MATRIX = 16, 0xFFFFFFFF, 0xFF
 TU_DT = np.dtype([("x", "<u2"), ("y", "<u2"), ("c_idx", "u1"), ("log2", "u1"), ("kind", "u1"), ("flags", "u1"), ("coeff_off", "<u4")])
@@ -53,9 +57,18 @@ def sparse_work_lists(case):
             t = tu[i]
             if t["kind"] == 4:                                   # PCM: not a residual block in the writer's log
                 continue
-            head, n = int(lev[p]), int(lev[p + 1])
+            head, n = int(lev[p]), int(lev[p + 1]) & 0xffffff
             log2, c_idx, tskip, bypass, intra, qp = head & 15, (head >> 4) & 3, (head >> 8) & 1, (head >> 9) & 1, (head >> 10) & 1, head >> 16
+            cross, no_residual = (head >> 11) & 1, (head >> 12) & 1
             assert (log2, c_idx) == (int(t["log2"]), int(t["c_idx"])), (i, head, t)
+            scale = ((int(lev[p + 1]) >> 24) ^ 0x80) - 0x80
+            if "tu_cross" in a and cross and scale:                  # the link the shim recorded = what the writer coded
+                link = int(a["tu_cross"][i])
+                assert link != OH_NO_COEFF and ((link >> 24) ^ 0x80) - 0x80 == scale and (t["flags"] & 32), (i, hex(link), scale)
+            if no_residual:                                           # cross-component block with cbf = 0: a block of zeros, no levels
+                assert t["kind"] == 3 and n == 0
+                p += 2
+                continue
             assert bypass == (t["kind"] == 3) and (tskip == (t["kind"] == 2) or bypass)
             pairs = lev[p + 2:p + 2 + n]
             p += 2 + n

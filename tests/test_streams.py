@@ -39,6 +39,11 @@ CASES = [
     ("tmvp_3refs", 416, 240, 9, dict(n_pictures=4, gop=2, tmvp=1, cabac_init_present=1, deblocking_override=1, n_refs=3)),
     ("partial_ctbs", 200, 136, 5, dict(n_pictures=3, gop=2, n_slices=2, pcm=1)),
     ("far_mvd", 264, 200, 6, dict(n_pictures=3, gop=2, mvd_range=4000, skip_pct=10, merge_pct=10)),
+    # format range extensions, 4:4:4: chroma blocks of luma size (4x4 included), a chroma mode per partition, cross-component prediction
+    ("rext444", 416, 240, 7, dict(n_pictures=3, gop=2, chroma_format_idc=3, transquant_bypass=1)),
+    ("rext444_ccp", 416, 240, 8, dict(n_pictures=3, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, scaling_list=1)),
+    ("rext444_ccp_10_intra_ctb16", 264, 200, 9, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, log2_ctb_size=4, log2_max_tb_size=4)),
+    ("rext444_ccp_slices_p", 200, 136, 10, dict(n_pictures=3, gop=1, chroma_format_idc=3, cross_component_pred=1, n_slices=3, weighted_pred=1, log2_ctb_size=5)),
 ]
 IDS = [c[0] for c in CASES]
 

@@ -140,3 +140,29 @@ def test_output_window_equals_the_reference_decoder_output(bit_depth, win):
     for k in range(3):
         for c in range(3):
             assert np.array_equal(got[k][c], want[k][c]), (k, c)
+
+
+@need_front_end
+@pytest.mark.timeout(1100)
+@pytest.mark.parametrize("name,w,h,kw", [
+    ("4k_main10", 3840, 2160, dict(n_pictures=3, gop=2, bit_depth=10, wpp=1)),
+    ("8k_444_10bit_ccp", 7680, 4320, dict(n_pictures=2, gop=1, bit_depth=10, chroma_format_idc=3, cross_component_pred=1)),
+], ids=["4k_main10", "8k_444_10bit_ccp"])
+def test_harness_at_baseline_geometries(name, w, h, kw, tmp_path):
+    """BASELINE.json configs[3] (3840x2160 Main 10) and the range-extension half of configs[4] (7680x4320 4:4:4 10 bit) as real
+    streams: written here, decoded by the reference decoder for the SEI digests, then file -> access units -> hooked reference decoder
+    as front end -> work lists -> MI355X passes -> MD5 on the GPU: every plane of every picture "Correct MD5" """
+    import refdec
+    import streamgen
+    data, aus = streamgen.write_stream(w, h, 77, **kw)
+    pics = refdec.decode(data, threads=8, thread_type=2)
+    assert len(pics) == kw["n_pictures"]
+    with_sei, _ = streamgen.add_md5(data, aus, [refdec.md5_of(p) for p in pics])
+    del pics
+    path = tmp_path / (name + ".bin")
+    path.write_bytes(with_sei)
+    r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-n"], capture_output=True, text=True, timeout=1000)
+    n = kw["n_pictures"]
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("Correct MD5") == 3 * n and "Incorrect MD5" not in r.stdout
+    assert r.stdout.strip().splitlines()[-1].startswith(f"frame= {n} fps= ")

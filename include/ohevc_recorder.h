@@ -62,6 +62,9 @@ OhScalingList *oh_rec_scaling_list(OhRecorder *r);
 /* intra block; tu = index returned by oh_rec_tu for the same block or OH_NO_COEFF.
  * Computes the block's dependency level from the levels of the neighbours it reads. */
 int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu);
+/* the same, returning the block's index for oh_rec_intra_attach_tu (OH_NO_COEFF on failure) — what a caller needs when several
+ * threads append to one recorder (the reference's slice / wavefront threads): every appending entry point takes the recorder's lock */
+uint32_t oh_rec_intra_idx(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu);
 
 /* two-step form for callers that learn the residual after the prediction (the table slots):
  * record with tu = OH_NO_COEFF, then attach.  index = value of oh_rec_n_intra() before the record. */

@@ -13,11 +13,13 @@
  * Pass 3 launches one kernel per CTU level, one workgroup per CTU; sub-levels are separated by
  * workgroup barriers inside the CU instead of kernel launches.
  */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../../include/ohevc_recorder.h"
 
 struct OhRecorder {
+    pthread_mutex_t mu;                         /* the appending entry points may be called from the reference's slice / wavefront threads */
     OhFrame  f;
     /* growable item lists */
     OhPu      *pu;      uint32_t cap_pu;
@@ -77,6 +79,7 @@ void oh_rec_destroy(OhRecorder *r);
 OhRecorder *oh_rec_create(const OhPicParams *p)
 {
     OhRecorder *r = (OhRecorder *)calloc(1, sizeof(*r));
+    if (r) pthread_mutex_init(&r->mu, NULL);
     if (!r)
         return NULL;
     r->f.p = *p;
@@ -119,6 +122,7 @@ const OhPicParams *oh_rec_params(const OhRecorder *r) { return &r->f.p; }
 
 void oh_rec_destroy(OhRecorder *r)
 {
+    if (r) pthread_mutex_destroy(&r->mu);
     if (!r)
         return;
     free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->it_ctu); free(r->it_sub);
@@ -158,7 +162,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     memset(r->decoded, 0, (size_t)r->dw * r->dh);
 }
 
-int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,
+static int oh_rec_pu_u(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,
               int ref1, int mv1x, int mv1y, const OhWeights *wp)
 {
     const OhPicParams *p = &r->f.p;
@@ -185,7 +189,7 @@ int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int
     return 0;
 }
 
-uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+static uint32_t oh_rec_tu_u(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
                    const int16_t *coeffs)
 {
     uint32_t n2 = 1u << (2 * log2_size);
@@ -206,7 +210,7 @@ uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int ki
     return r->f.n_tu++;
 }
 
-uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+static uint32_t oh_rec_tu_sparse_u(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
                           int qp, int matrix_id, int n, const uint32_t *pairs)
 {
     uint32_t n2 = 1u << (2 * log2_size);
@@ -286,7 +290,7 @@ OhCtbMaps *oh_rec_ctb_maps(OhRecorder *r)
 
 const OhCtbMaps *oh_rec_ctb_maps_in_use(const OhRecorder *r) { return r->ctb_maps_on ? &r->ctb_maps : NULL; }
 
-int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
+static int oh_rec_tu_cross_u(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
 {
     if (tu_c >= r->f.n_tu || tu_y >= r->f.n_tu || tu_y >= (1u << 24) || r->tu[tu_y].c_idx != 0 || r->tu[tu_c].c_idx == 0 ||
         r->tu[tu_y].log2_size != r->tu[tu_c].log2_size)
@@ -321,7 +325,7 @@ static inline void visit(OhRecorder *r, int c, int x, int y, int cx, int cy, uns
     }
 }
 
-int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
+static int oh_rec_intra_u(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
 {
     const OhPicParams *p = &r->f.p;
     int n = 1 << log2_size, c = c_idx;
@@ -372,7 +376,7 @@ int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode
 
 uint32_t oh_rec_n_intra(const OhRecorder *r) { return r->f.n_intra; }
 
-int oh_rec_intra_attach_tu(OhRecorder *r, uint32_t intra_index, uint32_t tu)
+static int oh_rec_intra_attach_tu_u(OhRecorder *r, uint32_t intra_index, uint32_t tu)
 {
     if (intra_index >= r->f.n_intra || tu >= r->f.n_tu)
         return -1;
@@ -521,9 +525,70 @@ int oh_rec_avail(const OhRecorder *r, int x, int y, int w, int h)
     return a;
 }
 
-void oh_rec_mark_decoded(OhRecorder *r, int x, int y, int w, int h)
+static void oh_rec_mark_decoded_u(OhRecorder *r, int x, int y, int w, int h)
 {
     for (int yy = y; yy < y + h && yy < r->f.p.height; yy += 4)
         for (int xx = x; xx < x + w && xx < r->f.p.width; xx += 4)
             r->decoded[(yy >> 2) * r->dw + (xx >> 2)] = 1;
+}
+
+/* ---- the public appending entry points: the bodies above under the recorder's lock ---- */
+int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,
+              int ref1, int mv1x, int mv1y, const OhWeights *wp)
+{
+    pthread_mutex_lock(&r->mu);
+    int v = oh_rec_pu_u(r, x, y, w, h, ref0, mv0x, mv0y, ref1, mv1x, mv1y, wp);
+    pthread_mutex_unlock(&r->mu);
+    return v;
+}
+uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+                   const int16_t *coeffs)
+{
+    pthread_mutex_lock(&r->mu);
+    uint32_t v = oh_rec_tu_u(r, c_idx, x, y, log2_size, kind, flags, coeffs);
+    pthread_mutex_unlock(&r->mu);
+    return v;
+}
+uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+                          int qp, int matrix_id, int n, const uint32_t *pairs)
+{
+    pthread_mutex_lock(&r->mu);
+    uint32_t v = oh_rec_tu_sparse_u(r, c_idx, x, y, log2_size, kind, flags, qp, matrix_id, n, pairs);
+    pthread_mutex_unlock(&r->mu);
+    return v;
+}
+int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
+{
+    pthread_mutex_lock(&r->mu);
+    int v = oh_rec_tu_cross_u(r, tu_c, tu_y, res_scale_val);
+    pthread_mutex_unlock(&r->mu);
+    return v;
+}
+int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
+{
+    pthread_mutex_lock(&r->mu);
+    int v = oh_rec_intra_u(r, c_idx, x, y, log2_size, mode, avail, tu);
+    pthread_mutex_unlock(&r->mu);
+    return v;
+}
+int oh_rec_intra_attach_tu(OhRecorder *r, uint32_t intra_index, uint32_t tu)
+{
+    pthread_mutex_lock(&r->mu);
+    int v = oh_rec_intra_attach_tu_u(r, intra_index, tu);
+    pthread_mutex_unlock(&r->mu);
+    return v;
+}
+void oh_rec_mark_decoded(OhRecorder *r, int x, int y, int w, int h)
+{
+    pthread_mutex_lock(&r->mu);
+    oh_rec_mark_decoded_u(r, x, y, w, h);
+    pthread_mutex_unlock(&r->mu);
+}
+uint32_t oh_rec_intra_idx(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
+{
+    pthread_mutex_lock(&r->mu);
+    const uint32_t idx = r->f.n_intra;
+    const int rc = oh_rec_intra_u(r, c_idx, x, y, log2_size, mode, avail, tu);
+    pthread_mutex_unlock(&r->mu);
+    return rc ? OH_NO_COEFF : idx;
 }

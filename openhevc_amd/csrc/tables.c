@@ -4,7 +4,11 @@
  *
  * State is per decoding thread (the reference gives every slice/frame thread its own
  * HEVCContext copy, hevc.c:3067-3075, but the table slots carry no context argument,
- * SURVEY.md §8b "Threading"): a __thread binding set by oh_tables_bind().
+ * SURVEY.md §8b "Threading"): a __thread binding set by oh_tables_bind().  A FRAME thread binds its own picture on its own
+ * thread.  The reference's SLICE / WAVEFRONT workers (pthread_slice.c: hls_decode_entry_wpp on worker threads, one CTU row each)
+ * never bind: a thread without a binding of its own adopts the latest binding made by any thread (the picture in flight) — the
+ * transient state (PU being assembled, last intra block, emulation buffers) stays per thread, the recorder takes its lock.
+ * Frame threads AND slice threads at once (thread_type 4) would need the slots to tell pictures apart: not supported.
  */
 #include <string.h>
 #include "../../include/ohevc_tables.h"
@@ -35,6 +39,23 @@ typedef struct Tables {
 } Tables;
 
 static __thread Tables T;
+static __thread unsigned T_adopted;               /* generation of the shared binding this thread copied; 0: bound by itself or never */
+static Tables G;                                  /* the latest binding (binding part only), for threads that never bind */
+static volatile unsigned G_gen;
+static volatile int G_untranslated, G_why[8];     /* what workers could not translate (oh_tables_finish runs on another thread) */
+
+/* every slot starts here: a thread that never called oh_tables_bind() works on the picture in flight */
+static inline void adopt(void)
+{
+    if ((T.rec && !T_adopted) || T_adopted == G_gen)
+        return;
+    oh_intra_accessor fn = G.intra_fn;
+    memset(&T, 0, sizeof(T));
+    T.rec = G.rec; T.p = G.p; T.bpp = G.bpp; T.cur = G.cur; T.intra_fn = fn;
+    memcpy(T.refs, G.refs, sizeof(T.refs));
+    T_adopted = G_gen;
+}
+#define UNTRANSLATED(k) do { T.untranslated++; T.why[k]++; if (T_adopted) { __sync_fetch_and_add(&G_untranslated, 1); __sync_fetch_and_add(&G_why[k], 1); } } while (0)
 
 /* ---- pointer resolution ---- */
 static int resolve(const Planes *pl, int plane, const uint8_t *ptr, int bpp, int *x, int *y)
@@ -101,7 +122,7 @@ static void flush_pu(void)
         return;
     if (oh_rec_pu(T.rec, T.pu.x, T.pu.y, T.pu.w, T.pu.h, T.pu.ref[0], T.pu.mv[0][0], T.pu.mv[0][1],
                   T.pu.ref[1], T.pu.mv[1][0], T.pu.mv[1][1], T.pu.weighted ? &T.pu.wp : NULL) != 0) {
-        T.untranslated++; T.why[7]++;
+        UNTRANSLATED(7);
     }
     T.pu.valid = 0;
 }
@@ -117,6 +138,11 @@ void oh_tables_bind(OhRecorder *rec, uint8_t *const cur_data[3], const int cur_l
     T.bpp = T.p.bit_depth > 8 ? 2 : 1;
     for (int c = 0; c < 3; c++) { T.cur.data[c] = cur_data[c]; T.cur.linesize[c] = cur_linesize[c]; }
     T.cur.bound = 1;
+    T_adopted = 0;
+    G = T;                                               /* the picture in flight, for threads that never bind (slice / wavefront workers) */
+    G_untranslated = 0; memset((void *)G_why, 0, sizeof(G_why));
+    __sync_synchronize();
+    G_gen = G_gen + 1 ? G_gen + 1 : 1;
 }
 
 void oh_tables_bind_ref(int slot, uint8_t *const data[3], const int linesize[3])
@@ -125,24 +151,26 @@ void oh_tables_bind_ref(int slot, uint8_t *const data[3], const int linesize[3])
         return;
     for (int c = 0; c < 3; c++) { T.refs[slot].data[c] = data[c]; T.refs[slot].linesize[c] = linesize[c]; }
     T.refs[slot].bound = 1;
+    G.refs[slot] = T.refs[slot];                         /* bound before the first slot call of the picture: workers adopt afterwards */
 }
 
-void oh_tables_set_intra_accessor(oh_intra_accessor fn) { T.intra_fn = fn; }
+void oh_tables_set_intra_accessor(oh_intra_accessor fn) { T.intra_fn = fn; G.intra_fn = fn; }
 
 int oh_tables_finish(void)
 {
     flush_pu();
-    return T.untranslated;
+    return T.untranslated + G_untranslated;              /* this thread's and the adopting workers' */
 }
 
 void oh_tables_untranslated_by_family(int out[8])
 {
-    for (int i = 0; i < 8; i++) out[i] = T.why[i];
+    for (int i = 0; i < 8; i++) out[i] = T.why[i] + G_why[i];
 }
 
 /* ---- residual slots (hevc_cabac.c:1868-1949) ---- */
 static void note_transform(const int16_t *coeffs, int kind, int flags)
 {
+    adopt();
     if (T.tr_coeffs != coeffs) { T.tr_coeffs = coeffs; T.tr_kind = OH_TU_BYPASS; T.tr_flags = 0; }
     if (kind >= 0) T.tr_kind = kind;
     T.tr_flags |= flags;
@@ -157,8 +185,9 @@ static void s_idct_dc(int16_t *coeffs) { note_transform(coeffs, OH_TU_IDCT, 0); 
 static void transform_add_n(uint8_t *dst, int16_t *coeffs, ptrdiff_t stride, int log2)
 {
     int c, x, y;
+    adopt();
     flush_pu();
-    if (!T.rec || !resolve_dst(dst, stride, &c, &x, &y)) { T.untranslated++; T.why[0]++; return; }
+    if (!T.rec || !resolve_dst(dst, stride, &c, &x, &y)) { UNTRANSLATED(0); return; }
     int kind = OH_TU_BYPASS, flags = 0;
     if (T.tr_coeffs == coeffs) { kind = T.tr_kind; flags = T.tr_flags; }
     T.tr_coeffs = NULL;
@@ -173,13 +202,14 @@ static void transform_add_n(uint8_t *dst, int16_t *coeffs, ptrdiff_t stride, int
     } else if (T.cross_pending) {
         /* the host decoder left the chroma block WITHOUT the scaled luma residual: link it, the engine adds
          * (res_scale_val * luma residual) >> 3 once the luma residual exists */
-        if (!T.last_y_valid || tu == OH_NO_COEFF || oh_rec_tu_cross(T.rec, tu, T.last_y_tu, T.cross_scale) != 0) { T.untranslated++; T.why[0]++; }
+        if (!T.last_y_valid || tu == OH_NO_COEFF || oh_rec_tu_cross(T.rec, tu, T.last_y_tu, T.cross_scale) != 0) { UNTRANSLATED(0); }
         T.cross_pending = 0;
     }
 }
 
 void oh_tables_cross(int res_scale_val)
 {
+    adopt();
     T.cross_pending = res_scale_val != 0;                 /* scale 0 adds nothing */
     T.cross_scale = res_scale_val;
 }
@@ -201,9 +231,10 @@ static void s_put_pcm(uint8_t *dst, ptrdiff_t stride, int width, int height, str
 {
     int c, x, y;
     flush_pu();
+    adopt();
     if (!T.rec || !gb || width < 4 || height < 4 || width > 32 || height > 32 || (width & (width - 1)) || (height & (height - 1)) ||
         !resolve_dst(dst, stride, &c, &x, &y)) {
-        T.untranslated++; T.why[1]++;
+        UNTRANSLATED(1);
         return;
     }
     int16_t rect[32 * 32], blk[32 * 32];
@@ -224,12 +255,13 @@ static void s_put_pcm(uint8_t *dst, ptrdiff_t stride, int width, int height, str
 static void intra_pred_n(struct HEVCContext *s, int x0, int y0, int c_idx, int log2)
 {
     int mode = 1, avail = 0;
+    adopt();
     flush_pu();
-    if (!T.rec || !T.intra_fn) { T.untranslated++; T.why[2]++; return; }
+    if (!T.rec || !T.intra_fn) { UNTRANSLATED(2); return; }
     T.intra_fn(s, x0, y0, c_idx, log2, &mode, &avail);
     int x = x0 >> oh_hshift(&T.p, c_idx), y = y0 >> oh_vshift(&T.p, c_idx);   /* x0,y0 are luma units, hevcpred_template.c:86-87 */
-    uint32_t idx = oh_rec_n_intra(T.rec);
-    if (oh_rec_intra(T.rec, c_idx, x, y, log2, mode, avail, OH_NO_COEFF) != 0) { T.untranslated++; T.why[3]++; return; }
+    const uint32_t idx = oh_rec_intra_idx(T.rec, c_idx, x, y, log2, mode, avail, OH_NO_COEFF);
+    if (idx == OH_NO_COEFF) { UNTRANSLATED(3); return; }
     T.li_valid = 1; T.li_c = c_idx; T.li_x = x; T.li_y = y; T.li_log2 = log2; T.li_index = idx;
 }
 static void s_intra_pred2(struct HEVCContext *s, int x0, int y0, int c) { intra_pred_n(s, x0, y0, c, 2); }
@@ -242,6 +274,7 @@ static void s_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_l
                                int block_w, int block_h, int src_x, int src_y, int w, int h)
 {
     (void)h;
+    adopt();
     /* which reference plane?  The pointer may be far outside the allocation, so it is matched by
      * stride and by being consistent with (src_x, src_y): base + src_y*linesize + src_x*bpp == src */
     int slot = -1, plane = -1;
@@ -259,7 +292,7 @@ static void s_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_l
     else if (T.emu[1].valid && T.emu[1].buf == buf) e = 1;
     else { e = T.emu_next; T.emu_next ^= 1; }
     T.emu[e].valid = slot >= 0;
-    if (slot < 0) { T.untranslated++; T.why[4]++; return; }
+    if (slot < 0) { UNTRANSLATED(4); return; }
     T.emu[e].buf = buf; T.emu[e].linesize = buf_linesize; T.emu[e].slot = slot; T.emu[e].plane = plane;
     T.emu[e].src_x = src_x; T.emu[e].src_y = src_y; T.emu[e].bw = block_w; T.emu[e].bh = block_h;
 }
@@ -269,9 +302,10 @@ static void mc_luma(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdi
                     int h, int mx, int my, int w, int weighted, int denom, int wa, int wb, int oa, int ob)
 {
     int c, x, y, slot, sx, sy;
+    adopt();
     flush_pu();
     if (!T.rec || !resolve_dst(dst, dststride, &c, &x, &y) || c != 0 || !resolve_src(src, srcstride, 0, &slot, &sx, &sy)) {
-        T.untranslated++; T.why[5]++;
+        UNTRANSLATED(5);
         return;
     }
     int mvx = ((sx - x) << 2) + mx, mvy = ((sy - y) << 2) + my;
@@ -279,7 +313,7 @@ static void mc_luma(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdi
     T.pu.valid = 1; T.pu.x = x; T.pu.y = y; T.pu.w = w; T.pu.h = h;
     T.pu.ref[0] = T.pu.ref[1] = -1;
     if (src2) {                                          /* second half of a bi-predicted block */
-        if (!T.l0.valid || T.l0.tmp != src2) { T.untranslated++; T.why[6]++; T.pu.valid = 0; return; }
+        if (!T.l0.valid || T.l0.tmp != src2) { UNTRANSLATED(6); T.pu.valid = 0; return; }
         T.pu.ref[0] = T.l0.slot; T.pu.mv[0][0] = T.l0.mvx; T.pu.mv[0][1] = T.l0.mvy;
         T.pu.ref[1] = slot; T.pu.mv[1][0] = mvx; T.pu.mv[1][1] = mvy;
         T.l0.valid = 0;
@@ -295,6 +329,10 @@ static void mc_luma(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdi
             T.pu.wp.w[0][0] = (int16_t)wa; T.pu.wp.o[0][0] = (int16_t)oa;
         }
     }
+    /* complete unless explicit chroma weights are still to come (the Cr call closes it, chroma_weights): a worker thread's last PU
+     * must not wait for a "next call" that never comes on that thread */
+    if (!T.pu.weighted || !T.p.chroma_format_idc)
+        flush_pu();
 }
 
 static void mc_luma_put(int16_t *dst, const uint8_t *src, ptrdiff_t srcstride, int mx, int my, int cur_x_unknown)
@@ -303,8 +341,9 @@ static void mc_luma_put(int16_t *dst, const uint8_t *src, ptrdiff_t srcstride, i
     /* list-0 half: the destination is a stack array, so the block position is not known yet; keep
      * the SOURCE position and turn it into an MV when the bi call names the destination */
     int slot, sx, sy;
+    adopt();
     flush_pu();
-    if (!resolve_src(src, srcstride, 0, &slot, &sx, &sy)) { T.untranslated++; T.why[6]++; T.l0.valid = 0; return; }
+    if (!resolve_src(src, srcstride, 0, &slot, &sx, &sy)) { UNTRANSLATED(6); T.l0.valid = 0; return; }
     T.l0.tmp = dst; T.l0.slot = slot; T.l0.mvx = (sx << 2) + mx; T.l0.mvy = (sy << 2) + my; T.l0.valid = 2;   /* absolute, fixed up below */
 }
 
@@ -341,6 +380,8 @@ static void chroma_weights(const uint8_t *dst, ptrdiff_t ds, int bi, int denom, 
     T.pu.wp.log2_denom[1] = (uint8_t)denom;
     T.pu.wp.w[0][c] = (int16_t)wa; T.pu.wp.o[0][c] = (int16_t)oa;
     if (bi) { T.pu.wp.w[1][c] = (int16_t)wb; T.pu.wp.o[1][c] = (int16_t)ob; }
+    if (c == 2)
+        flush_pu();
 }
 static void e_put(int16_t *dst, ptrdiff_t ds, uint8_t *src, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
 { (void)dst; (void)ds; (void)src; (void)ss; (void)h; (void)mx; (void)my; (void)w; }

@@ -63,7 +63,7 @@ def test_writer_syntax_is_what_the_reference_parses(case):
     assert len(wrote) > 20
 
 
-def decode_through_hooks(data):
+def decode_through_hooks(data, threads=1, thread_type=1):
     """pictures (decode order) reconstructed by the CHECKER from the work lists the hooked reference decoder records"""
     pics, got = {}, []
 
@@ -73,7 +73,7 @@ def decode_through_hooks(data):
                 pics[i] = F.HostPic(f.p)
         assert oracle().oh_or_frame(C.byref(f), host_pic_array(pics)) == 0
         got.append([pics[cur].visible(c).copy() for c in range(3)])
-    refdec.record_work_lists(data, on_picture)
+    refdec.record_work_lists(data, on_picture, threads, thread_type)
     return got
 
 
@@ -159,3 +159,20 @@ def test_conformance_window_is_cropped_by_the_reference_output():
             s = 1 if c else 0
             crop = full[k][c][top >> s:(240 >> s) - (bottom >> s), left >> s:(416 >> s) - (right >> s)]
             assert np.array_equal(crop, want[k][c]), (k, c)
+
+
+@pytest.mark.parametrize("kw", [dict(wpp=1, log2_ctb_size=4, log2_max_tb_size=4), dict(wpp=1, log2_ctb_size=5, n_slices=2, weighted_pred=1, pcm=1),
+                                dict(wpp=1, log2_ctb_size=4, log2_max_tb_size=4, chroma_format_idc=3, cross_component_pred=1)],
+                         ids=["wpp_ctb16", "wpp_slices_weighted_pcm", "wpp_444_ccp"])
+def test_recording_slots_under_the_reference_wavefront_threads(kw):
+    """the reference's slice threads (pthread_slice.c: one CTU row per job, hls_decode_entry_wpp on 4 worker threads) call the recording
+    slots concurrently: workers adopt the picture's binding, the recorder takes its lock, every PU is complete when its last slot call
+    returns — and the recorded work lists still reconstruct the reference decoder's pictures (the items arrive in another order)"""
+    data, _ = streamgen.write_stream(416, 240, 33, n_pictures=4, gop=2, **kw)
+    want = refdec.decode(data)
+    for rep in range(3):
+        got = decode_through_hooks(data, threads=4, thread_type=2)
+        assert len(got) == len(want) == 4
+        for k in range(4):
+            for c in range(3):
+                assert np.array_equal(want[k][c], got[k][c]), (rep, "picture", k, "plane", c)

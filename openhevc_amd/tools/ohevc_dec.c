@@ -2,7 +2,7 @@
  * ohevc_dec — SDL-free counterpart of the reference's `hevc` test harness (main_hm/main.c:134-311, options main_hm/getopt.c:47-62)
  * for the MI355X engine:
  *
- *     ohevc_dec -i stream.bin -F <front-end.so> [-c] [-n] [-o out.yuv] [-s frames]
+ *     ohevc_dec -i stream.bin -F <front-end.so> [-c] [-n] [-o out.yuv] [-s frames] [-p threads -f 2]
  *
  * reads a raw Annex-B file, splits it into access units (oh_annexb_split: what the reference's harness gets from libavformat's raw
  * HEVC demuxer through hevc_parser.c), hands every access unit to the FRONT END — the host decoder that does what stays on the host
@@ -19,7 +19,8 @@
  *     const OhFrame *ref_hooked_finish(int *cur_id, int *poc, int *untranslated);
  * which returns the work list of the access unit just decoded (picture ids = the front end's DPB slots).  -c: do not check MD5
  * (as the reference's flag), -n: accepted and ignored (there is no display), -o: write the decoded pictures (whole coded planes,
- * decode order), -s: stop after so many pictures.
+ * decode order), -s: stop after so many pictures, -p / -f: threads of the front end as in the reference's harness — -f 2 (slice /
+ * wavefront threads) is what the recording slots support with more than one thread.
  */
 #include <dlfcn.h>
 #include <stdio.h>
@@ -46,6 +47,8 @@ static void usage(const char *prog)
     printf("     -n : no display (there is none)\n");
     printf("     -o <output file>\n");
     printf("     -s <num> Stop after num frames \n");
+    printf("     -p <number of threads of the front end> \n");
+    printf("     -f <thread type> (2: slice; with -p 1 anything)\n");
 }
 
 static double now_s(void)
@@ -60,11 +63,11 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
     const char *input = NULL, *front = NULL, *output = NULL;
-    int check_md5 = 1, num_frames = 0;
+    int check_md5 = 1, num_frames = 0, nb_pthreads = 1, thread_type = 1;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         if (a[0] != '-' || !a[1] || a[2]) { usage(argv[0]); return 2; }
-        const int need = strchr("iFos", a[1]) != NULL;
+        const int need = strchr("iFospf", a[1]) != NULL;
         if (need && i + 1 >= argc) { usage(argv[0]); return 2; }
         switch (a[1]) {
         case 'c': check_md5 = 0; break;
@@ -73,11 +76,17 @@ int main(int argc, char **argv)
         case 'F': front = argv[++i]; break;
         case 'o': output = argv[++i]; break;
         case 's': num_frames = atoi(argv[++i]); break;
+        case 'p': nb_pthreads = atoi(argv[++i]); break;
+        case 'f': thread_type = atoi(argv[++i]); break;
         default: usage(argv[0]); return 2;
         }
     }
     if (!input) { printf("No input file specified.\nSpecify it with: -i <filename>\n"); return 1; }
     if (!front) { printf("No front end specified.\nSpecify it with: -F <shared object>\n"); return 1; }
+    if (nb_pthreads < 1 || (nb_pthreads > 1 && thread_type != 2)) {
+        printf("the recording table slots support several front-end threads as slice / wavefront threads only (-f 2)\n");
+        return 2;
+    }
 
     FILE *fi = fopen(input, "rb");
     if (!fi) { printf("%s", input); return 1; }
@@ -105,7 +114,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s does not export libOpenHevcInit / StartDecoder / Decode / Close / ref_hooked_finish\n", front);
         return 1;
     }
-    void *h = fe_init(1, 1);
+    void *h = fe_init(nb_pthreads, thread_type);
     if (!h || fe_start(h) != 1) { fprintf(stderr, "could not open OpenHevc\n"); return 1; }
 
     OhEngine *e = NULL;

@@ -107,6 +107,11 @@ def test_harness_decodes_streams_and_the_gpu_md5_matches_the_sei(case, tmp_path)
     path.write_bytes(bad)
     r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED], capture_output=True, text=True, timeout=600)
     assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1
+    if kw.get("wpp"):                                        # the front end on 4 slice threads (wavefront entry points): same verdict
+        r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-p", "4", "-f", "2"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1
+        r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-p", "4", "-f", "1"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 2                             # frame threads are not what the recording slots support
     # -c: no check, -s: stop early
     r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-c", "-s", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MD5" not in r.stdout and r.stdout.strip().splitlines()[-1].startswith("frame= 2 ")
@@ -157,11 +162,12 @@ def test_harness_at_baseline_geometries(name, w, h, kw, tmp_path):
     data, aus = streamgen.write_stream(w, h, 77, **kw)
     pics = refdec.decode(data, threads=8, thread_type=2)
     assert len(pics) == kw["n_pictures"]
+    threads = ["-p", "8", "-f", "2"] if kw.get("wpp") else []
     with_sei, _ = streamgen.add_md5(data, aus, [refdec.md5_of(p) for p in pics])
     del pics
     path = tmp_path / (name + ".bin")
     path.write_bytes(with_sei)
-    r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-n"], capture_output=True, text=True, timeout=1000)
+    r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-n"] + threads, capture_output=True, text=True, timeout=1000)
     n = kw["n_pictures"]
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("Correct MD5") == 3 * n and "Incorrect MD5" not in r.stdout

@@ -161,7 +161,8 @@ struct DevFrame {
     uint32_t *tu_cursor;              /* [0..3] blocks per size, [4..7] scatter cursors, [8] cross-component blocks, [9] their cursor */
     uint32_t *intra_perm;             /* [n_intra]: position of block i after the <= 8x8-first partition of its sub-level */
     uint32_t *sub_small_w;            /* = sub_small, writable */
-    uint32_t *ctu_seen;               /* [CTBs]: a CTU may head one schedule entry only */
+    uint32_t *ctu_seen;               /* [CTBs]: index + 1 of the schedule entry the CTU heads (one at most), 0: no intra block in it */
+    uint32_t *row_progress;           /* [CTB rows]: CTUs of the row finished by intra_rows_kernel */
     uint32_t *ctu_aux;                /* [n_ictu]: wave passes of the entry | its residual is not stageable << 31 */
     void     *summary;                /* DevSummary + DevLevelStat[n_levels] */
     void     *summary_host;           /* pinned host copy, written by prep_finish (no D2H copy on the stream) */

@@ -70,6 +70,7 @@ struct OhDevFrame {
 
 struct OhEngine {
     int         device = 0;
+    int         n_cu = 256;              /* compute units of the device */
     hipStream_t stream = nullptr;
     bool        own_stream = true;
     std::vector<Pic> pics;
@@ -183,6 +184,8 @@ static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_e
         delete e;
         return OH_E_HIP;
     }
+    if (hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || e->n_cu <= 0)
+        e->n_cu = 256;
     if (getenv("OHEVC_STAMPS")) {
         const size_t bytes = (16 + 4000 * 16) * sizeof(uint64_t);
         if (hipMalloc((void **)&e->dbg, bytes) == hipSuccess)
@@ -908,6 +911,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_ictu = add(nullptr, (size_t)cnt.n_ictu * sizeof(DevIntraCtu));
     int s_small = add(nullptr, (size_t)cnt.n_sub * sizeof(uint32_t));
     int s_perm = add(nullptr, (size_t)f->n_intra * sizeof(uint32_t));
+    int s_rowp = add(nullptr, cnt.n_intra ? (size_t)oh_ctb_height(&p) * sizeof(uint32_t) : 0);
     const size_t res_off = total;
     total += align_up((size_t)(f->n_coeff ? f->n_coeff : 1) * sizeof(int16_t), 256);
     const bool stale_cfg = has_db && has_sao && oh_sao_stale_config(&p);       /* see DevFrame.sao_stale */
@@ -990,6 +994,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.sao = has_sao ? AT(const OhSaoCtb *, s_sao) : nullptr;
     hd.pu_off = AT(const uint32_t *, s_puoff); hd.ctu_aux = AT(uint32_t *, s_aux); hd.tu_keep = AT(uint8_t *, s_keep); hd.tu_cursor = AT(uint32_t *, s_cursor);
     hd.intra_perm = AT(uint32_t *, s_perm); hd.ctu_seen = AT(uint32_t *, s_seen); hd.summary = AT(void *, s_sum);
+    hd.row_progress = AT(uint32_t *, s_rowp);
 #undef AT
     hd.n_pu = f->n_pu; hd.n_mc_luma = cnt.n_mc_luma; hd.n_mc_chroma = cnt.n_mc_chroma; hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
     hd.n_ictu = cnt.n_ictu; hd.n_sub = cnt.n_sub; hd.n_levels = cnt.n_levels; hd.n_wp = f->n_wp; hd.n_sparse = f->sparse ? f->n_sparse : 0;
@@ -1272,6 +1277,62 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
         }
         MARK(OH_PASS_RESIDUAL);
         const OhCtuAreas areas = oh_ctu_areas(p->log2_ctb_size, p->chroma_format_idc);
+        /* pictures whose levels are (nearly) the full CTU wavefront — I pictures — may run as CTU rows in ONE launch (intra.hip:
+         * intra_rows_kernel): their cost is then the critical path at the average CTU length, not the sum of the levels' slowest
+         * CTUs plus a launch per level (4K I picture alone: 6.6 ms against 9.1 ms).  A row's workgroup holds its slot while it
+         * waits for the row above, so this only pays while the rows of the batch's I pictures leave the chip room (one
+         * workgroup per CU at most); larger batches fill the level launches anyway and keep them, as do the pictures with a
+         * handful of levels (measured: 32 I pictures per batch as rows cost the 4-stream bench 22 %). */
+        static const char *renv = getenv("OHEVC_INTRA_ROWS");
+        const size_t row_threshold = renv && !atoi(renv) ? (size_t)-1 : (size_t)oh_ctb_width(p);
+        bool in_rows[OH_MAX_BATCH] = {};
+        {
+            OhBatch rows;
+            memset(&rows, 0, sizeof(rows));
+            int nr = 0;
+            uint32_t max_items = 1, max_sub = 1, max_res = 0;
+            bool staged = true;
+            int deep = 0;
+            for (int i = 0; i < nb; i++)
+                deep += fr[i]->levels.size() >= row_threshold && !fr[i]->levels.empty();
+            if (deep * oh_ctb_height(p) > e->n_cu)
+                deep = 0;
+            for (int i = 0; i < nb && deep; i++) {
+                if (fr[i]->levels.size() < row_threshold || fr[i]->levels.empty())
+                    continue;
+                in_rows[i] = true;
+                rows.f[nr++] = fr[i]->d;
+                for (const OhDevFrame::Level &L : fr[i]->levels) {
+                    max_items = std::max(max_items, L.max_items); max_sub = std::max(max_sub, L.max_sub); max_res = std::max(max_res, L.max_res);
+                    staged = staged && (L.staged || !L.n_ctu);
+                }
+            }
+            if (nr) {
+                OhIntraLaunch IL;
+                IL.staged = staged; IL.level = 0; IL.waves = 8; IL.phases = 2;
+                size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
+                IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
+                IL.off_sub = (uint32_t)off;   off += ((size_t)max_sub + 1) * sizeof(uint32_t);
+                IL.off_small = (uint32_t)off; off = align_up(off + (size_t)max_sub * sizeof(uint32_t), 16);
+                IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)(staged ? max_res : 0) * sizeof(int16_t), 16);
+                IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
+                IL.lds_bytes = (uint32_t)off;
+                hipEvent_t a = nullptr, b = nullptr;
+                if (prof_launch) {                            /* counted like a level launch: one launch of the pass */
+                    for (hipEvent_t *pe : { &a, &b }) {
+                        if (!e->lev_pool.empty()) { *pe = e->lev_pool.back(); e->lev_pool.pop_back(); }
+                        else HIPCHK(e, hipEventCreate(pe));
+                    }
+                    HIPCHK(e, hipEventRecord(a, st));
+                }
+                ohk_intra_rows(&rows, nr, p, &IL, st);
+                if (prof_launch) {
+                    HIPCHK(e, hipEventRecord(b, st));
+                    e->lev_pending.push_back(a);
+                    e->lev_pending.push_back(b);
+                }
+            }
+        }
         for (size_t l = 0; l < max_levels; l++) {
             /* the pictures that have this level, and the LDS carve-up that fits all of them */
             OhBatch sub;
@@ -1281,7 +1342,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             bool staged = true;
             uint64_t sum_items = 0, sum_sub = 0;
             for (int i = 0; i < nb; i++) {
-                if (l >= fr[i]->levels.size())
+                if (l >= fr[i]->levels.size() || in_rows[i])
                     continue;
                 const OhDevFrame::Level &L = fr[i]->levels[l];
                 sub.f[ns++] = fr[i]->d;
@@ -1290,6 +1351,8 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
                 sum_items += L.sum_items; sum_sub += L.sum_sub;
                 staged = staged && L.staged;
             }
+            if (!ns)
+                continue;                                  /* every picture that has this level runs as rows */
             OhIntraLaunch IL;
             IL.staged = staged;
             IL.level = (uint32_t)l;

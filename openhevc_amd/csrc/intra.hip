@@ -529,24 +529,19 @@ static __device__ __forceinline__ void slots_finish(const SlotState &st, const i
     ACC(5, sa, sb); ACC(6, sb, sc); ACC(7, sc, sd); ACC(8, sd, se);
 }
 
-/* waves_per_eu(6, 8): 80 VGPRs instead of 86, i.e. six waves per SIMD instead of five for the wide B-picture launches (no spills;
- * asking for seven or eight spills and loses more than the occupancy gains) */
+/* one CTU by the whole workgroup: schedule entry `entry` of picture f.  Every thread of the workgroup calls it (barriers inside). */
 template <typename PX, bool CIP, bool STAGED>
-__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
+static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict__ f, const OhIntraLaunch &L, const uint32_t entry, unsigned char *smem)
 {
-    const DevFrame *__restrict__ f = B.f[blockIdx.y];
-    const uint32_t first_ctu = f->lvl_start[L.level];
-    if (blockIdx.x >= f->lvl_start[L.level + 1] - first_ctu)
-        return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *__restrict__ M = (uint16_t *)smem;                                  /* sample area, oh_ctu_areas() */
     DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
     uint32_t *__restrict__ sub = (uint32_t *)(smem + L.off_sub);
     uint32_t *__restrict__ small = (uint32_t *)(smem + L.off_small);              /* per sub-level: leading blocks that go four per wave */
     int16_t *__restrict__ res_l = (int16_t *)(smem + L.off_res);                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x, nwaves = nthr >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                    /* wave-uniform: the phase bookkeeping derived from it lives in scalar registers */
     IntraLds &edges = *(IntraLds *)(smem + L.off_wave + wave * OH_INTRA_WAVE_LDS);
-    const DevIntraCtu ctu = gload(f->ictu + first_ctu + blockIdx.x);
+    const DevIntraCtu ctu = gload(f->ictu + entry);
     const GLOBAL uint32_t *__restrict__ ss = G_CONST(uint32_t, f->sub_start) + ctu.sub_first;
     const OhPicParams &pp = f->pp;
     const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc;
@@ -556,7 +551,17 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
     const OhCtuAreas ar = oh_ctu_areas(lc, pp.chroma_format_idc);
 
     /* stage: block descriptors, sub-level table, residual blocks */
-    const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items & 0xffffu, (uint32_t)OH_MAX_CTU_BLOCKS), area64 = ctu.n_items >> 16;
+    const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items & 0xffffu, (uint32_t)OH_MAX_CTU_BLOCKS);
+    /* write-back form, decided while the entry is at hand and kept in a scalar register: blocks (mostly-inter CTU) or rectangle */
+    int blockwise;
+    {
+        uint32_t rect = 0;
+        for (int c = 0; c < (pp.chroma_format_idc ? 3 : 1); c++) {
+            const int hs = hsh(pp, c), vs = vsh(pp, c);
+            rect += (uint32_t)(max(((ctu.bx1 + (1 << hs) - 1) >> hs) - max(ctu.bx0 >> hs, 0), 0) * max(((ctu.by1 + (1 << vs) - 1) >> vs) - max(ctu.by0 >> vs, 0), 0));
+        }
+        blockwise = __builtin_amdgcn_readfirstlane((int)((ctu.n_items >> 16) * 128u < rect));
+    }
     {
         const GLOBAL uint4v *__restrict__ src = (const GLOBAL uint4v *)(f->intra + item0);
         uint4v *dst = (uint4v *)items;
@@ -647,12 +652,7 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
     /* The last sub-level's barrier has been passed.  A CTU that is mostly INTER (B pictures: a few intra blocks scattered over a
      * rectangle that spans the CTU) stores its blocks, a quarter wave per block, instead of the rectangle: measured on the
      * >= 16 k-workgroup launches of B pictures the rectangle's write-back was 19 % of the launch (profiles/r02_intra_staging_experiment.txt) */
-    uint32_t rect = 0;
-    for (int c = 0; c < nplanes; c++) {
-        const int hs = hsh(pp, c), vs = vsh(pp, c);
-        rect += (uint32_t)(max(((ctu.bx1 + (1 << hs) - 1) >> hs) - max(ctu.bx0 >> hs, 0), 0) * max(((ctu.by1 + (1 << vs) - 1) >> vs) - max(ctu.by0 >> vs, 0), 0));
-    }
-    if (area64 * 64u * 2u < rect) {
+    if (blockwise) {
         const uint64_t gp0 = (uint64_t)f->cur.p[0], gp1 = (uint64_t)f->cur.p[1], gp2 = (uint64_t)f->cur.p[2];
         const int st0 = f->cur.stride[0], st1 = f->cur.stride[1];
         const int quarter = tid >> 4, sl = tid & 15, nq = nthr >> 4;
@@ -705,6 +705,77 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
 #endif
 }
 
+/* waves_per_eu(6, 8): 80 VGPRs instead of 86, i.e. six waves per SIMD instead of five for the wide B-picture launches (no spills;
+ * asking for seven or eight spills and loses more than the occupancy gains) */
+template <typename PX, bool CIP, bool STAGED>
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void intra_ctu_kernel(const OhBatch B, const OhIntraLaunch L)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t first_ctu = f->lvl_start[L.level];
+    if (blockIdx.x >= f->lvl_start[L.level + 1] - first_ctu)
+        return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    intra_ctu_body<PX, CIP, STAGED>(f, L, first_ctu + blockIdx.x, smem);
+}
+
+/* =========================================================================================
+ * The same pass for pictures whose CTUs nearly all depend on their neighbours (I pictures: 126 levels for 4K): instead of one
+ * launch per wavefront level — each as long as its slowest CTU, plus launch and staging overhead, 126 times — ONE launch whose
+ * workgroups are the CTU ROWS (what pthread_slice.c's wavefront threads are, hevc.c:2829-2990): row y walks its CTUs left to right
+ * and starts CTU x when row y-1 has finished min(x + 2, ctbw) CTUs (ff_thread_await_progress2 / the two-CTB lag of WPP, a superset
+ * of the dependencies the recorder found).  A picture then costs its critical path (ctbw + 2 (ctbh - 1) CTU times at the AVERAGE
+ * CTU length) instead of the sum of the levels' maxima.
+ *
+ * Progress is a counter per row in HBM: the finishing workgroup makes its samples visible (release fence at agent scope behind a
+ * barrier) and stores x + 1; the waiting workgroup polls it (one lane, relaxed agent-scope loads) and every wave then takes an acquire fence (L1 and the XCD's non-coherent L2 lines dropped) before it stages.  Workgroup
+ * ids are row-major over (row, picture), rows ascending: a waiting workgroup only ever waits for a LOWER id, and the dispatcher of
+ * each XCD hands workgroups out in id order, so the lowest unfinished workgroup is always resident and never waits on a
+ * non-resident one — no deadlock whatever the occupancy.  The poll is bounded all the same (a wave that gives up continues with
+ * what is there: wrong samples, caught by every test, instead of a hung GPU).
+ * ======================================================================================= */
+template <typename PX, bool CIP, bool STAGED>
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_rows_kernel(const OhBatch B, const OhIntraLaunch L, const int n_pics)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int row = blockIdx.x / n_pics, pic = blockIdx.x - row * n_pics;
+    const DevFrame *__restrict__ f = B.f[pic];
+    const OhPicParams &pp = f->pp;
+    const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc, ctbh = (pp.height + (1 << lc) - 1) >> lc;
+    if (row >= ctbh)
+        return;
+    uint32_t *__restrict__ progress = f->row_progress;
+    const GLOBAL uint32_t *__restrict__ entry_of = G_CONST(uint32_t, f->ctu_seen);
+    for (int x = 0; x < ctbw; x++) {
+        const uint32_t e = entry_of[row * ctbw + x];                 /* index + 1 of the CTU's schedule entry, 0: no intra block */
+        if (e) {
+            if (row > 0) {
+                const uint32_t need = (uint32_t)min(x + 2, ctbw);
+                if (threadIdx.x == 0) {
+                    for (int spin = 0; spin < (1 << 22); spin++) {       /* ~1 s at worst: never reached while the rows above make progress */
+                        if (__hip_atomic_load(&progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need)   /* the acquire is the fence below */
+                            break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   /* samples written by other workgroups: not from this CU's L1 */
+            }
+            intra_ctu_body<PX, CIP, STAGED>(f, L, e - 1, smem);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       /* every thread's stores of the CTU */
+            __syncthreads();                                         /* ... and the LDS is free for the next CTU */
+        }
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&progress[row], (uint32_t)x + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(64) void intra_rows_reset_kernel(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.x];
+    const int lc = f->pp.log2_ctb_size, ctbh = (f->pp.height + (1 << lc) - 1) >> lc;
+    for (int r = threadIdx.x; r < ctbh; r += 64) f->row_progress[r] = 0;
+}
+
 /* =========================================================================================
  * launcher
  * ======================================================================================= */
@@ -717,10 +788,36 @@ int ohk_init_intra(void)
         (const void *)intra_ctu_kernel<uint8_t, true, false>, (const void *)intra_ctu_kernel<uint8_t, true, true>,
         (const void *)intra_ctu_kernel<uint16_t, false, false>, (const void *)intra_ctu_kernel<uint16_t, false, true>,
         (const void *)intra_ctu_kernel<uint16_t, true, false>, (const void *)intra_ctu_kernel<uint16_t, true, true> };
+    const void *row_kernels[8] = {
+        (const void *)intra_rows_kernel<uint8_t, false, false>, (const void *)intra_rows_kernel<uint8_t, false, true>,
+        (const void *)intra_rows_kernel<uint8_t, true, false>, (const void *)intra_rows_kernel<uint8_t, true, true>,
+        (const void *)intra_rows_kernel<uint16_t, false, false>, (const void *)intra_rows_kernel<uint16_t, false, true>,
+        (const void *)intra_rows_kernel<uint16_t, true, false>, (const void *)intra_rows_kernel<uint16_t, true, true> };
     for (const void *k : intra_kernels)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
             return -1;
+    for (const void *k : row_kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+            return -1;
     return 0;
+}
+
+/* n pictures whose intra pass runs as CTU rows (intra_rows_kernel); l: the LDS carve-up that fits every CTU of all of them */
+extern "C" void ohk_intra_rows(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, hipStream_t st)
+{
+    if (n <= 0) return;
+    const int lc = p->log2_ctb_size, ctbh = (p->height + (1 << lc) - 1) >> lc;
+    hipLaunchKernelGGL(intra_rows_reset_kernel, dim3(n), dim3(64), 0, st, *B);
+    dim3 g(ctbh * n), b(64 * l->waves);
+#define ROWS_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_rows_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l, n)
+#define ROWS_BY_FLAGS(PX)                                                                      \
+    do {                                                                                       \
+        if (p->constrained_intra_pred) { if (l->staged) ROWS_LAUNCH(PX, true, true); else ROWS_LAUNCH(PX, true, false); }   \
+        else                           { if (l->staged) ROWS_LAUNCH(PX, false, true); else ROWS_LAUNCH(PX, false, false); } \
+    } while (0)
+    if (p->bit_depth == 8) ROWS_BY_FLAGS(uint8_t); else ROWS_BY_FLAGS(uint16_t);
+#undef ROWS_BY_FLAGS
+#undef ROWS_LAUNCH
 }
 
 extern "C" void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st)

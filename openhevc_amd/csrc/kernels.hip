@@ -12,6 +12,7 @@
  *   pass 1  mc.hip        mc_kernel         a wave runs four <=8x8 blocks of one plane (16 lanes each): windows in LDS, v_dot2 h- and v-pass
  *   pass 2  residual.hip  residual_kernel   one launch per size; sixteen 4x4 / four 8x8 / one 16x16 / one 32x32 block per wave, two LDS matrix passes
  *   pass 3  intra.hip     intra_ctu_kernel  one workgroup per CTU of one wavefront level; <=8x8 blocks four per wave, prepared one sub-level ahead
+ *                         intra_rows_kernel one workgroup per CTU row of an I picture, rows two CTUs apart like the reference's WPP threads (one launch)
  *   pass 4  deblock.hip   deblock_*_kernel  one lane per 4-line edge segment, V pass then H pass, in place
  *   pass 5  sao.hip       sao_kernel        eight samples per lane, CTB-uniform waves, half 0 -> half 1
  *   BS      bs.hip        bs_kernel         optional: both boundary-strength grids from the motion field, one lane per 4x4 cell

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
         c.ctu >= (uint32_t)(ctbw * ctbh) || c.n_sub > OH_MAX_CTU_BLOCKS) { if (!lane) fail(f, OH_PE_INTRA_TABLES, k); return; }
     const uint32_t b0 = f->sub_start[c.sub_first], b1 = f->sub_start[c.sub_first + c.n_sub];
     if (b1 < b0 || b1 - b0 > OH_MAX_CTU_BLOCKS) { if (!lane) fail(f, OH_PE_INTRA_TABLES, k); return; }
-    if (!lane && atomicExch(&f->ctu_seen[c.ctu], 1u) != 0u) fail(f, OH_PE_INTRA_TABLES, k);      /* a CTU heads ONE entry: its level is one number */
+    if (!lane && atomicExch(&f->ctu_seen[c.ctu], k + 1) != 0u) fail(f, OH_PE_INTRA_TABLES, k);   /* a CTU heads ONE entry: its level is one number */
     unsigned long long lo = ~0ull, hi = 0;
     int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
     int any_res = 0, bad = 0;

@@ -530,6 +530,22 @@ def test_intra_wave_layouts(waves, phases):
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("rows", [0, 1])
+def test_intra_rows_and_levels(rows):
+    """a picture whose wavefront is (nearly) full — an I picture — runs its intra pass as CTU rows in one launch
+    (intra_rows_kernel) while the batch's rows leave the chip room, as one launch per level otherwise; OHEVC_INTRA_ROWS=0
+    forces the levels.  Both ways over the same I / B pictures (child process: the switch is read once)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OHEVC_INTRA_ROWS=str(rows))
+    env.pop("OHEVC_INTRA_WAVES", None)
+    env.pop("OHEVC_INTRA_PHASES", None)
+    r = subprocess.run([sys.executable, "-c", _WAVES_SCRIPT.format(tests=here, root=os.path.dirname(here))], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("w,h,bd,lc,lcb,seed", [(416, 240, 8, 6, 3, 1), (416, 240, 10, 4, 3, 2), (200, 136, 8, 5, 3, 3), (1920, 1080, 10, 6, 3, 4),
                                                 (272, 144, 8, 6, 4, 5), (3840, 2160, 10, 6, 3, 6)])
 def test_boundary_strengths_from_motion_field(eng, w, h, bd, lc, lcb, seed):

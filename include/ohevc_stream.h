@@ -53,6 +53,15 @@ typedef struct OhStreamParams {
     int32_t chroma_format_idc;          /* 1 (4:2:0, Main / Main 10) or 3 (4:4:4, format range extensions profile: chroma blocks of luma size incl. 4x4,
                                            one intra_chroma_pred_mode per partition, chroma QP = min(qPi, 51)) */
     int32_t cross_component_pred;       /* 4:4:4 only: cross_component_prediction_enabled_flag, random log2_res_scale_abs_plus1 / sign per chroma block */
+    /* range-extension coding tools (sps_range_extension 7.3.2.2.2; any of them selects the format range extensions profile, also for 4:2:0): */
+    int32_t tskip_rotation;             /* transform_skip_rotation_enabled_flag: 4x4 intra transform-skip blocks rotated by 180 degrees (hevc_cabac.c:1877-1884) */
+    int32_t tskip_context;              /* transform_skip_context_enabled_flag: one sig_coeff_flag context for skip / bypass blocks (hevc_cabac.c:1633-1680) */
+    int32_t implicit_rdpcm;             /* implicit_rdpcm_enabled_flag: intra bypass blocks predicted along mode 10 / 26 (hevc_cabac.c:1868-1874) */
+    int32_t explicit_rdpcm;             /* explicit_rdpcm_enabled_flag: explicit_rdpcm_flag / _dir_flag on inter skip / bypass blocks (hevc_cabac.c:1502-1508) */
+    int32_t intra_smoothing_disabled;   /* intra_smoothing_disabled_flag (hevcpred_template.c:289) */
+    int32_t persistent_rice;            /* persistent_rice_adaptation_enabled_flag (hevc_cabac.c:1719-1725, 1779-1807); not with wpp: the reference does not
+                                           synchronise StatCoeff with the contexts, its threaded and serial decodes would differ */
+    int32_t log2_max_tskip_size;        /* 0 or 2..5: log2_max_transform_skip_block_size (pps_range_extension); > 2 needs one of the tools above or 4:4:4 */
 } OhStreamParams;
 
 /* syntax elements of the slice data as (id, value) pairs in coding order — the writer's side of tests/test_streams.py; the ids are

@@ -78,7 +78,7 @@ enum {
     C_SAO_MERGE = 0, C_SAO_TYPE = 1, C_SPLIT_CU = 2, C_BYPASS_FLAG = 5, C_SKIP = 6, C_QP_DELTA = 9, C_PRED_MODE = 11, C_PART_MODE = 12,
     C_PREV_INTRA = 16, C_CHROMA_MODE = 17, C_MERGE_FLAG = 18, C_MERGE_IDX = 19, C_INTER_DIR = 20, C_REF_IDX = 25, C_MVD_GT0 = 27, C_MVD_GT1 = 28,
     C_MVP = 29, C_ROOT_CBF = 30, C_SPLIT_TU = 31, C_CBF_LUMA = 34, C_CBF_CHROMA = 36, C_TSKIP = 40, C_LAST_X = 42, C_LAST_Y = 60, C_CSBF = 78,
-    C_SIG = 82, C_GT1 = 124, C_GT2 = 148, C_RES_SCALE = 154, C_RES_SIGN = 162, N_CTX = 164
+    C_SIG = 82, C_GT1 = 124, C_GT2 = 148, C_RES_SCALE = 154, C_RES_SIGN = 162, C_SIG_TS = 164, C_RDPCM = 166, C_RDPCM_DIR = 168, N_CTX = 170
 };
 #define X 154                                        /* unused in this initialisation type */
 static const uint8_t k_init[3][N_CTX] = {
@@ -92,7 +92,8 @@ static const uint8_t k_init[3][N_CTX] = {
         140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111,
         140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
         138, 153, 136, 167, 152, 152,
-        154, 154, 154, 154, 154, 154, 154, 154, 154, 154 },            /* log2_res_scale_abs_plus1 (8), res_scale_sign_flag (2): range extension */
+        154, 154, 154, 154, 154, 154, 154, 154, 154, 154,              /* log2_res_scale_abs_plus1 (8), res_scale_sign_flag (2): range extension */
+        141, 111, 139, 139, 139, 139 },                                /* sig_coeff_flag of skip / bypass blocks (luma, chroma), explicit_rdpcm_flag (2), _dir_flag (2) */
     {   /* initType 1 */
         153, 185, 107, 139, 126, 154, 197, 185, 201, 154, 154, 149, 154, 139, 154, 154, 154, 152, 110, 122, 95, 79, 63, 31, 31, 153, 153, 140, 198, 168, 79,
         124, 138, 94, 153, 111, 149, 107, 167, 154, 139, 139,
@@ -103,7 +104,8 @@ static const uint8_t k_init[3][N_CTX] = {
         170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140,
         154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
         107, 167, 91, 122, 107, 167,
-        154, 154, 154, 154, 154, 154, 154, 154, 154, 154 },
+        154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+        140, 140, 139, 139, 139, 139 },
     {   /* initType 2 */
         153, 160, 107, 139, 126, 154, 197, 185, 201, 154, 154, 134, 154, 139, 154, 154, 183, 152, 154, 137, 95, 79, 63, 31, 31, 153, 153, 169, 198, 168, 79,
         224, 167, 122, 153, 111, 149, 92, 167, 154, 139, 139,
@@ -114,7 +116,8 @@ static const uint8_t k_init[3][N_CTX] = {
         170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140,
         154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
         107, 167, 91, 107, 107, 167,
-        154, 154, 154, 154, 154, 154, 154, 154, 154, 154 } };
+        154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+        140, 140, 139, 139, 139, 139 } };
 #undef X
 /* intra_chroma_pred_mode has one context; the second value of the element's table row belongs to it in no initialisation type */
 
@@ -261,6 +264,7 @@ typedef struct W {
     Slice sl;
     int qp_delta_pending, cu_bypass;
     int cross_pf, res_scale;                           /* cross-component prediction of the chroma block being coded */
+    int stat_coeff[4];                                 /* StatCoeff (9.3.3.11): reset with the contexts */
     /* SAO parameters of the CTBs (for merge candidates we only need to know that they exist) */
 } W;
 
@@ -285,9 +289,17 @@ static void fill(uint8_t *m, const W *w, int x, int y, int n, int v)
 }
 
 /* ================================================================================================= parameter sets */
+static int rext_profile(const OhStreamParams *p)
+{
+    return p->chroma_format_idc == 3 || p->tskip_rotation || p->tskip_context || p->implicit_rdpcm || p->explicit_rdpcm || p->intra_smoothing_disabled ||
+           p->persistent_rice || p->log2_max_tskip_size > 2;
+}
+
+static int max_tskip(const OhStreamParams *p) { return p->log2_max_tskip_size > 2 ? p->log2_max_tskip_size : 2; }
+
 static void write_ptl(Bits *b, const OhStreamParams *p)
 {
-    const int profile = p->chroma_format_idc == 3 ? 4 : p->bit_depth > 8 ? 2 : 1;        /* Main / Main 10 / format range extensions */
+    const int profile = rext_profile(p) ? 4 : p->bit_depth > 8 ? 2 : 1;                  /* Main / Main 10 / format range extensions */
     put_bits(b, 0, 2); put_bit(b, 0); put_bits(b, (uint32_t)profile, 5);                  /* profile space, tier, profile */
     for (int i = 0; i < 32; i++) put_bit(b, i == profile || (profile < 4 && i == 2));     /* compatibility flags */
     put_bit(b, 1); put_bit(b, 0); put_bit(b, 0); put_bit(b, 1);                           /* progressive, interlaced, non-packed, frame-only */
@@ -381,9 +393,15 @@ static void write_sps(W *w)
     put_bit(&b, p->tmvp != 0);
     put_bit(&b, p->strong_intra_smoothing != 0);
     put_bit(&b, 0);                                        /* VUI */
-    if (p->chroma_format_idc == 3) {                       /* sps_range_extension with every tool flag off (7.3.2.2.2) */
+    if (rext_profile(p)) {                                 /* sps_range_extension (7.3.2.2.2) */
         put_bit(&b, 1); put_bit(&b, 1); put_bits(&b, 0, 7);
-        put_bits(&b, 0, 9);                                /* transform_skip_rotation .. cabac_bypass_alignment */
+        put_bit(&b, p->tskip_rotation != 0); put_bit(&b, p->tskip_context != 0);
+        put_bit(&b, p->implicit_rdpcm != 0); put_bit(&b, p->explicit_rdpcm != 0);
+        put_bit(&b, 0);                                    /* extended_precision_processing: not in the reference's kernels */
+        put_bit(&b, p->intra_smoothing_disabled != 0);
+        put_bit(&b, 0);                                    /* high_precision_offsets */
+        put_bit(&b, p->persistent_rice != 0);
+        put_bit(&b, 0);                                    /* cabac_bypass_alignment */
     } else {
         put_bit(&b, 0);                                    /* extension */
     }
@@ -428,9 +446,9 @@ static void write_pps(W *w)
     put_bit(&b, 0);                                        /* lists modification */
     put_ue(&b, 0);                                         /* log2_parallel_merge_level 2 */
     put_bit(&b, 0);                                        /* slice header extension */
-    if (p->chroma_format_idc == 3) {                       /* pps_range_extension (7.3.2.3.2) */
+    if (rext_profile(p)) {                                 /* pps_range_extension (7.3.2.3.2) */
         put_bit(&b, 1); put_bit(&b, 1); put_bits(&b, 0, 7);
-        if (p->transform_skip) put_ue(&b, 0);              /* log2_max_transform_skip_block_size_minus2 */
+        if (p->transform_skip) put_ue(&b, (uint32_t)(max_tskip(p) - 2));   /* log2_max_transform_skip_block_size_minus2 */
         put_bit(&b, p->cross_component_pred != 0);
         put_bit(&b, 0);                                    /* chroma_qp_offset_list_enabled_flag */
         put_ue(&b, 0); put_ue(&b, 0);                      /* log2_sao_offset_scale_luma / chroma */
@@ -566,11 +584,17 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
         }
     }
     tr(OH_SE_RESIDUAL, log2 | (c_idx << 4) | (scan << 8));
-    int tskip = 0;
-    if (w->p->transform_skip && !w->cu_bypass && log2 == 2) {
+    int tskip = 0, rdpcm = 0, rdpcm_dir = 0;
+    if (w->p->transform_skip && !w->cu_bypass && log2 <= max_tskip(w->p)) {
         tskip = pct(g, w->p->tskip_pct);
         enc_bin(c, C_TSKIP + (c_idx ? 1 : 0), tskip);
     }
+    if (!cu_intra && w->p->explicit_rdpcm && (tskip || w->cu_bypass)) {
+        rdpcm = rnd(g, 2);
+        enc_bin(c, C_RDPCM + (c_idx ? 1 : 0), rdpcm);
+        if (rdpcm) { rdpcm_dir = rnd(g, 2); enc_bin(c, C_RDPCM_DIR + (c_idx ? 1 : 0), rdpcm_dir); }
+    }
+    const int ts_ctx = w->p->tskip_context && (tskip || w->cu_bypass);       /* one sig_coeff_flag context for the whole block */
     /* last significant coefficient in scan order */
     int last_sb = -1, last_pos = -1, lx = 0, ly = 0;
     const int n_sb = 1 << (2 * n_sb_log2);
@@ -591,7 +615,7 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
         const int bd_off = 6 * (w->p->bit_depth - 8);
         const int qp = c_idx ? chroma_qp(w->sl.qp, c_idx, w->p->bit_depth, w->p->chroma_format_idc) : w->sl.qp + bd_off;
         lev_put((uint32_t)log2 | (uint32_t)c_idx << 4 | (uint32_t)tskip << 8 | (uint32_t)(w->cu_bypass != 0) << 9 | (uint32_t)(cu_intra != 0) << 10 |
-                (uint32_t)(w->cross_pf != 0 && c_idx != 0) << 11 | (uint32_t)qp << 16);
+                (uint32_t)(w->cross_pf != 0 && c_idx != 0) << 11 | (uint32_t)rdpcm << 13 | (uint32_t)rdpcm_dir << 14 | (uint32_t)qp << 16);
         uint32_t cnt = 0;
         for (int i = 0; i < n * n; i++) cnt += lev[i] != 0;
         lev_put(cnt | (uint32_t)(c_idx ? w->res_scale & 0xff : 0) << 24);
@@ -656,7 +680,7 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
                 if (c_idx == 0) { if (sx || sy) sc += 3; sc += log2 == 3 ? (scan == 0 ? 9 : 15) : 21; }
                 else sc += log2 == 3 ? 9 : 12;
             }
-            enc_bin(c, C_SIG + (c_idx ? 27 : 0) + sc, s);
+            enc_bin(c, ts_ctx ? C_SIG_TS + (c_idx ? 1 : 0) : C_SIG + (c_idx ? 27 : 0) + sc, s);
             if (s) { sig[n_sig++] = k; infer_dc = 0; }
         }
         if (!n_sig)
@@ -689,13 +713,21 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
             enc_bypass(c, lev[(sy * 4 + py) * n + sx * 4 + px] < 0);
         }
         /* remaining levels */
-        int rice = 0;
+        const int persist = w->p->persistent_rice != 0, sb_type = 2 * (c_idx == 0) + (tskip || w->cu_bypass);
+        int rice = persist ? w->stat_coeff[sb_type] / 4 : 0, rice_init = 0;
         for (int m = 0; m < n_sig; m++) {
             const int base = m < 8 ? (m == first_g1 ? 3 : 2) : 1;
             const int have = m < 8 ? 1 + g1[m] + (m == first_g1 ? g2 : 0) : 1;
             if (have == base) {
-                code_remaining(c, absv[m] - base, rice);
-                if (absv[m] > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
+                const int rem = absv[m] - base;
+                code_remaining(c, rem, rice);
+                if (absv[m] > 3 * (1 << rice)) rice = persist ? rice + 1 : rice < 4 ? rice + 1 : 4;
+                if (persist && !rice_init) {               /* the sub-block's first escape value moves the statistic (9.3.3.11) */
+                    const int r0 = w->stat_coeff[sb_type] / 4;
+                    if (rem >= (3 << r0)) w->stat_coeff[sb_type]++;
+                    else if (2 * rem < (1 << r0) && w->stat_coeff[sb_type] > 0) w->stat_coeff[sb_type]--;
+                    rice_init = 1;
+                }
             }
         }
     }
@@ -1128,6 +1160,7 @@ static void write_slice_data(W *w, Bits *data, int ts_first, int ts_end, uint32_
     *n_entry = 0;
     cabac_start(c, data);
     cabac_init_contexts(c, init_type, w->sl.qp);
+    memset(w->stat_coeff, 0, sizeof(w->stat_coeff));
     for (int ts = ts_first; ts < ts_end; ts++) {
         const int rs = w->rs_of_ts[ts], rx = rs % w->ctbw, ry = rs / w->ctbw;
         const int tile_start = ts > ts_first && w->tile_of[rs] != w->tile_of[w->rs_of_ts[ts - 1]];
@@ -1137,7 +1170,7 @@ static void write_slice_data(W *w, Bits *data, int ts_first, int ts_end, uint32_
             entry[(*n_entry)++] = (uint32_t)(data->n / 8 - sub_start);
             sub_start = data->n / 8;
             cabac_start(c, data);
-            if (tile_start) cabac_init_contexts(c, init_type, w->sl.qp);
+            if (tile_start) { cabac_init_contexts(c, init_type, w->sl.qp); memset(w->stat_coeff, 0, sizeof(w->stat_coeff)); }
             else if (have_wpp && ry > 0 && rx + 1 < w->ctbw && avail(w, rx << w->lc, ry << w->lc, (rx + 1) << w->lc, (ry - 1) << w->lc))
                 memcpy(c->state, wpp_ctx, N_CTX);          /* synchronisation: the states after the second CTB of the row above */
             else cabac_init_contexts(c, init_type, w->sl.qp);
@@ -1261,6 +1294,8 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     if ((p->chroma_format_idc != 1 && p->chroma_format_idc != 3) || (p->cross_component_pred && p->chroma_format_idc != 3) ||
         (p->chroma_format_idc == 3 && (p->pcm || p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))
         return -1;                                         /* 4:4:4: no PCM (its chroma sample count differs), no window (the reference doubles the offsets) */
+    if ((p->log2_max_tskip_size && (p->log2_max_tskip_size < 2 || p->log2_max_tskip_size > 5)) || (p->persistent_rice && p->wpp))
+        return -1;
     W w;
     memset(&w, 0, sizeof(w));
     w.p = p;

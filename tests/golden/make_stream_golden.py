@@ -32,6 +32,13 @@ STREAM_CASES = [
     # 4:4:4 range extension with cross-component prediction (work lists carry the cross links the hooked decoder's shim records)
     ("b_444_ccp_8b", 264, 200, 15, dict(n_pictures=3, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1)),
     ("i_444_ccp_10b_ctb16", 200, 136, 16, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, log2_ctb_size=4, log2_max_tb_size=4)),
+    # range-extension coding tools: transform skip up to 32x32 (rotation, own significance context), implicit / explicit residual DPCM on
+    # skip and bypass blocks, persistent Rice adaptation, intra smoothing off
+    ("b_rext_tskip_rdpcm_8b", 264, 200, 17, dict(n_pictures=3, gop=2, transform_skip=1, transquant_bypass=1, tskip_rotation=1, tskip_context=1, implicit_rdpcm=1,
+                                                 explicit_rdpcm=1, log2_max_tskip_size=5, tskip_pct=50, bypass_pct=25)),
+    ("i_444_rext_tools_10b", 200, 136, 18, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1,
+                                                tskip_rotation=1, tskip_context=1, implicit_rdpcm=1, persistent_rice=1, intra_smoothing_disabled=1,
+                                                log2_max_tskip_size=4, tskip_pct=40, bypass_pct=30)),
 ]
 
 
@@ -53,7 +60,10 @@ def build(name, w, h, seed, kw):
 
 
 def main():
+    only = set(sys.argv[1:])                                  # names: regenerate just these
     for name, w, h, seed, kw in STREAM_CASES:
+        if only and name not in only:
+            continue
         path = os.path.join(HERE, "streams", name + ".npz")
         np.savez_compressed(path, **build(name, w, h, seed, kw))
         print(name, os.path.getsize(path), "bytes")

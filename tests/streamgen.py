@@ -11,8 +11,11 @@ _FIELDS = ("width", "height", "bit_depth", "log2_ctb_size", "log2_min_tb_size", 
            "coeff_density")
 
 
+_REXT = ("tskip_rotation", "tskip_context", "implicit_rdpcm", "explicit_rdpcm", "intra_smoothing_disabled", "persistent_rice", "log2_max_tskip_size")
+
+
 class OhStreamParams(C.Structure):
-    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in _FIELDS] + [("trace", C.c_int32), ("levels", C.c_int32)] + [(n, C.c_int32) for n in ("conf_win_left", "conf_win_right", "conf_win_top", "conf_win_bottom")] + [("chroma_format_idc", C.c_int32), ("cross_component_pred", C.c_int32)]
+    _fields_ = [("seed", C.c_uint64)] + [(n, C.c_int32) for n in _FIELDS] + [("trace", C.c_int32), ("levels", C.c_int32)] + [(n, C.c_int32) for n in ("conf_win_left", "conf_win_right", "conf_win_top", "conf_win_bottom")] + [("chroma_format_idc", C.c_int32), ("cross_component_pred", C.c_int32)] + [(n, C.c_int32) for n in _REXT]
 
 
 SE_NAMES = ("", "sao_merge", "sao_type", "sao_offset_abs", "sao_offset_sign", "sao_band_pos", "sao_eo_class", "end_of_slice", "split_cu", "bypass_flag",

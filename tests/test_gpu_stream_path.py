@@ -75,6 +75,8 @@ STREAMS = [
     ("intra_ctb16", 264, 200, 14, dict(n_pictures=3, gop=0, log2_ctb_size=4, log2_max_tb_size=4)),
     ("hd_main10", 1920, 1080, 15, dict(n_pictures=4, gop=2, bit_depth=10, wpp=1)),
     ("rext444_ccp", 416, 240, 16, dict(n_pictures=4, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1)),
+    ("rext_tools", 416, 240, 17, dict(n_pictures=5, gop=2, bit_depth=10, transform_skip=1, transquant_bypass=1, tskip_rotation=1, tskip_context=1, implicit_rdpcm=1,
+                                      explicit_rdpcm=1, persistent_rice=1, intra_smoothing_disabled=1, log2_max_tskip_size=5, tskip_pct=45, bypass_pct=20)),
 ]
 
 

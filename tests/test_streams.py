@@ -44,6 +44,19 @@ CASES = [
     ("rext444_ccp", 416, 240, 8, dict(n_pictures=3, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, scaling_list=1)),
     ("rext444_ccp_10_intra_ctb16", 264, 200, 9, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, log2_ctb_size=4, log2_max_tb_size=4)),
     ("rext444_ccp_slices_p", 200, 136, 10, dict(n_pictures=3, gop=1, chroma_format_idc=3, cross_component_pred=1, n_slices=3, weighted_pred=1, log2_ctb_size=5)),
+    # range-extension coding tools (sps / pps_range_extension), on 4:2:0 and 4:4:4: transform skip up to 32x32 with the rotation of 4x4
+    # intra blocks and its own significance context, implicit / explicit residual DPCM on bypass and skip blocks, no intra smoothing,
+    # persistent Rice adaptation
+    ("rext_tskip_rdpcm", 416, 240, 11, dict(n_pictures=3, gop=2, transform_skip=1, transquant_bypass=1, tskip_rotation=1, tskip_context=1,
+                                            implicit_rdpcm=1, explicit_rdpcm=1, log2_max_tskip_size=5, tskip_pct=50, bypass_pct=25)),
+    ("rext_rice_nosmooth_10", 264, 200, 12, dict(n_pictures=3, gop=1, bit_depth=10, persistent_rice=1, intra_smoothing_disabled=1, transform_skip=1,
+                                                 transquant_bypass=1, explicit_rdpcm=1, log2_max_tskip_size=3, qp=20, coeff_density=60)),
+    ("rext444_tools_intra", 200, 136, 13, dict(n_pictures=2, gop=0, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1,
+                                               tskip_rotation=1, tskip_context=1, implicit_rdpcm=1, persistent_rice=1, log2_max_tskip_size=4,
+                                               tskip_pct=40, bypass_pct=30)),
+    ("rext_tools_tiles_slices", 416, 240, 14, dict(n_pictures=3, gop=2, tile_cols=2, tile_rows=2, n_slices=3, log2_ctb_size=5, transform_skip=1,
+                                                   transquant_bypass=1, explicit_rdpcm=1, implicit_rdpcm=1, tskip_rotation=1, persistent_rice=1,
+                                                   log2_max_tskip_size=4, tskip_pct=40)),
 ]
 IDS = [c[0] for c in CASES]
 

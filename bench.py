@@ -156,6 +156,7 @@ def main():
                     help="gloo: REHEARSAL of the N>1 control flow with several ranks on one GPU (transfers staged through host memory)")
     ap.add_argument("--bs-from-motion", action="store_true", help="work lists carry the motion field instead of finished boundary-strength grids; "
                     "the engine derives the grids at upload (bs_kernel: inside the timed region in decode mode)")
+    ap.add_argument("--host-threads", type=int, default=0, help="1: a single host thread enqueues every stream (default: one thread per stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
     ap.add_argument("--no-check", action="store_true", help="skip the picture check after the timed region")
@@ -200,6 +201,20 @@ def main():
     n_chains = max(1, args.chains)
     if args.scaling == "strong" and world > 1:
         n_chains = max(1, n_chains // world)               # the same pictures per step as one GPU decodes alone, split over the ranks
+    # the chains' picture buffers (every rank keeps the reference pictures of all ranks, parallel.GroupStore) must fit the HBM
+    # that is free now; a default that does not fit is cut (and said so) rather than left to die in the allocator
+    half_bytes = F.half_layout(params)[0]
+    per_chain = (args.waves * 2 * world + max(args.tail, 1) * 2) * half_bytes
+    free_b, _total_b = torch.cuda.mem_get_info()
+    chains_asked = n_chains
+    if n_chains * per_chain > 0.85 * free_b:
+        n_chains = max(1, int(0.85 * free_b // per_chain))
+        if world > 1:                                      # the same number on every rank
+            t = torch.tensor([n_chains], device=torch.device("cuda", local_rank))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_chains = int(t.item())
+        if rank == 0:
+            print(f"bench.py: {chains_asked} chains x {per_chain / 1e9:.2f} GB do not fit {free_b / 1e9:.0f} GB of free HBM: {n_chains} chains in flight", file=sys.stderr)
     n_streams = max(1, min(args.streams, n_chains))
     knobs = dict(sparse_pct=args.sparse_pct, bs_from_motion=int(args.bs_from_motion))
     # host work lists: --host-gops distinct GOPs (seeds), generated once — the stand-in for what the reference's CTU loop records
@@ -209,6 +224,9 @@ def main():
         plan_m = P.make_step_plan(world, rank, n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + m, gop=args.gop)
         host.append((plan_m, P.host_work_lists(params, plan_m, knobs)))
     host_bytes = sum(fc.bytes for _, (lists, _) in host for fc in lists.values())
+    # N > 1: every stream keeps its own host thread (one thread hands over 3.2 k 4K pictures/s, four 8.5 k); their exchanges are
+    # issued through a turnstile in one order on every rank (parallel.Turnstile)
+    turnstile = P.Turnstile(n_streams) if world > 1 and not args.host_threads == 1 else None
     groups = [[] for _ in range(n_streams)]                # per stream: [(stream, engine, process group), (plan, backend, group)...]
     chains = []
     for k in range(n_chains):
@@ -223,7 +241,7 @@ def main():
             n_here = len(range(k, n_chains, n_streams))
             gstore = P.GroupStore(torch, torch.device("cuda", local_rank), params, world, n_here, args.waves, args.tail)
             g.append((stream, Engine(local_rank, stream=stream.cuda_stream), dist.new_group() if world > 1 else None, gstore,
-                      P.Comm(torch, torch.device("cuda", local_rank)) if world > 1 else None))
+                      P.Comm(torch, torch.device("cuda", local_rank), turnstile, k % n_streams) if world > 1 else None))
         stream, engine, group, gstore, comm = g[0]
         with torch.cuda.stream(stream):
             be_k = P.EngineBackend(torch, local_rank, params, plan_k, engine=engine, host_lists=lists_k, resident=False,
@@ -243,8 +261,8 @@ def main():
     exchange = P.exchange_map(world, rank, args.waves, args.tail, gop=args.gop) if world > 1 and args.exchange == "readers" else None
     comms = [g[0][4] for g in groups if g and g[0][4] is not None]
     # one host thread per engine / stream (an engine is a single-submitter object).  With N > 1 the streams' collectives must be
-    # issued in the same relative order on every rank, so one thread enqueues all streams.
-    host_threads = n_streams if world == 1 else 1
+    # issued in the same relative order on every rank: the turnstile does that (--host-threads 1: one thread enqueues everything)
+    host_threads = 1 if args.host_threads == 1 else n_streams
 
     def run_group(g, n_steps):
         with torch.cuda.stream(g[0][0]):
@@ -266,6 +284,8 @@ def main():
                 run_group(g, n_steps)
             except BaseException as exc:        # noqa: BLE001 - re-raised on the main thread
                 errs.append(exc)
+                if turnstile is not None:
+                    turnstile.fail(exc)
         ths = [threading.Thread(target=work, args=(g,)) for g in groups]
         for t in ths:
             t.start()
@@ -439,7 +459,7 @@ def main():
                        "chroma_format_idc": params.chroma_format_idc, "pictures_per_step_per_gpu": pics_per_step,
                        "step": f"every chain in flight advances by one closed GOP (1 I + {args.waves - 1} reference B + {args.tail} "
                                f"non-reference B pictures): {n_chains} GOPs per GPU and step",
-                       "chains_in_flight_per_gpu": n_chains, "streams_per_gpu": n_streams,
+                       "chains_in_flight_per_gpu": n_chains, "chains_asked_per_gpu": chains_asked, "streams_per_gpu": n_streams,
                        "host_work_lists": f"{n_host} distinct GOPs, {round(host_bytes / n_host / P.pictures_per_step(plan) / 1e6, 2)} MB per picture on average",
                        "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
                        "gop": args.gop,

@@ -143,14 +143,61 @@ def _staged(dist, group, tensor):
 P2P_CHAINS = 8          # chains per batch_isend_irecv call (bounds the operations inside one RCCL group call)
 
 
+class Turnstile:
+    """One issue order for the exchanges of several host threads, the same on every rank.
+
+    Each lockstep group of chains has its own host thread (hand-over and launches of one HIP stream), its own communicator and its
+    own exchange stream; RCCL wants the operations of different communicators ENQUEUED in the same relative order on every rank
+    (their kernels may share hardware queues).  Lane l's k-th exchange holds ticket k * lanes + l and is issued when every smaller
+    ticket has been: all lanes make the same number of calls (same plan), a lane only ever waits for lanes that do not wait for it,
+    and only the short enqueue is serialised — hand-over and launches of the lanes stay concurrent."""
+
+    def __init__(self, lanes, timeout=600.0):
+        import threading
+        self.lanes, self.timeout = lanes, timeout
+        self.calls = [0] * lanes
+        self.next = 0
+        self.failed = None
+        self.cv = threading.Condition()
+
+    def run(self, lane, fn):
+        import time
+        with self.cv:
+            ticket = self.calls[lane] * self.lanes + lane
+            deadline = time.monotonic() + self.timeout
+            while self.next != ticket and self.failed is None:
+                if not self.cv.wait(timeout=1.0) and time.monotonic() > deadline:
+                    self.failed = TimeoutError(f"exchange ticket {ticket}: ticket {self.next} was never issued")
+                    self.cv.notify_all()
+            if self.failed is not None:
+                raise RuntimeError("exchange order broken: another stream's thread failed") from self.failed
+        try:
+            fn()
+        except BaseException as exc:
+            self.fail(exc)
+            raise
+        with self.cv:
+            self.calls[lane] += 1
+            self.next += 1
+            self.cv.notify_all()
+
+    def fail(self, exc):
+        """a lane's thread died: release the others (they raise)"""
+        with self.cv:
+            if self.failed is None:
+                self.failed = exc
+            self.cv.notify_all()
+
+
 class Comm:
     """The exchange's own stream and its account.  The transfers of a wave are enqueued on `stream` behind an event recorded on the
     engine's stream after the wave's passes, and the engine's stream waits for the event that ends them — hipStreamWaitEvent both
     ways, no host wait — so the copy engines / xGMI links work while the other streams' passes (and this stream's hand-over of the
     next batch) go on.  bytes / messages / time are per rank (bench.py prints them)."""
 
-    def __init__(self, torch, device=None):
+    def __init__(self, torch, device=None, turnstile=None, lane=0):
         self.torch = torch
+        self.turnstile, self.lane = turnstile, lane        # several groups on threads of their own: issue order (Turnstile)
         self.stream = torch.cuda.Stream(device) if device is not None and torch.cuda.is_available() else None
         self.bytes_sent = self.bytes_recv = self.messages = self.collectives = 0
         self.host_s = 0.0                                  # time of exchanges that ran on the host (CPU tensors / staged rehearsal)
@@ -263,7 +310,10 @@ def run_steps_batched(chains, dist=None, exchange=None, comm=None):
         else:
             be0.execute_batch(batches[w])
         if plan0.world > 1 and getattr(be0.store, "group", None) is not None:
-            _exchange_grouped(chains, w, dist, exchange, comm)
+            if comm is not None and comm.turnstile is not None:
+                comm.turnstile.run(comm.lane, lambda: _exchange_grouped(chains, w, dist, exchange, comm))
+            else:
+                _exchange_grouped(chains, w, dist, exchange, comm)
         elif plan0.world > 1 and exchange is None:        # everybody gets everything: one all-gather per chain
             for pl, be, group in chains:
                 half = be.final_half(pl.waves[w].name)

@@ -23,8 +23,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("extra", [[], ["--exchange", "allgather"], ["--gop", "ldp"], ["--gop", "intra"], ["--scaling", "strong"]],
-                         ids=["ra_readers", "ra_allgather", "ldp", "intra", "strong"])
+@pytest.mark.parametrize("extra", [[], ["--exchange", "allgather"], ["--gop", "ldp"], ["--gop", "intra"], ["--scaling", "strong"], ["--host-threads", "1"]],
+                         ids=["ra_readers", "ra_allgather", "ldp", "intra", "strong", "one_host_thread"])
 def test_two_ranks_on_one_gpu(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "480p_main8",
@@ -46,5 +46,6 @@ def test_two_ranks_on_one_gpu(extra):
         else:
             # one message per peer, wave and stream: 2 streams x 4 waves x (1 send + 1 receive) at most
             assert all(0 < e["messages_per_step"] <= 2 * 4 * 2 for e in ex)
+    assert out["host_threads"] == (1 if "--host-threads" in extra else 2)       # a host thread per stream, exchanges ordered by P.Turnstile
     chains = 2 if "strong" in extra else 4
     assert out["config"]["chains_in_flight_per_gpu"] == chains

@@ -209,3 +209,45 @@ def test_plan_is_balanced_and_cross_rank():
             for pic in p.pictures():
                 for ref in pic.refs:
                     assert ref[0] == "ref" and ref != pic.name
+
+
+def test_turnstile_orders_the_exchanges_of_concurrent_threads():
+    """bench.py at N > 1: every stream's host thread issues its own exchanges, P.Turnstile puts them in ONE order
+    (call k of lane l = ticket k * lanes + l) whatever the threads' pace; a failing lane releases the others"""
+    import random
+    import threading
+    import time
+    from openhevc_amd import parallel as P
+    lanes, calls = 4, 25
+    ts = P.Turnstile(lanes, timeout=30.0)
+    order, errs = [], []
+
+    def work(lane):
+        rng = random.Random(lane)
+        try:
+            for k in range(calls):
+                time.sleep(rng.random() * 0.002 * (lane + 1))
+                ts.run(lane, lambda: order.append((k, lane)))
+        except BaseException as exc:            # noqa: BLE001
+            errs.append(exc)
+    ths = [threading.Thread(target=work, args=(lane,)) for lane in range(lanes)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs and order == [(k, lane) for k in range(calls) for lane in range(lanes)]
+
+    ts = P.Turnstile(2, timeout=30.0)
+    got = []
+
+    def waiter():
+        try:
+            ts.run(1, lambda: got.append("ran"))
+        except RuntimeError as exc:
+            got.append(type(exc.__cause__).__name__)
+    t = threading.Thread(target=waiter)
+    t.start()
+    with pytest.raises(ValueError):
+        ts.run(0, lambda: (_ for _ in ()).throw(ValueError("lane 0 dies")))
+    t.join(timeout=10)
+    assert got == ["ValueError"]

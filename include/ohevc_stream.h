@@ -30,7 +30,9 @@ typedef struct OhStreamParams {
     int32_t log2_min_tb_size, log2_max_tb_size;   /* 2..5 */
     int32_t max_th_depth_intra, max_th_depth_inter;   /* max_transform_hierarchy_depth_* */
     int32_t n_pictures;
-    int32_t gop;                        /* 0 all intra, 1 low-delay P, 2 low-delay B (both lists from past pictures) */
+    int32_t gop;                        /* 0 all intra, 1 low-delay P, 2 low-delay B (both lists from past pictures), 3 hierarchical B: mini-GOPs of four
+                                           in decode order +4, +2, +1, +3 (output order != decode order, two pictures of reordering; +1 / +3 are
+                                           sub-layer non-reference pictures); n_refs >= 2 */
     int32_t n_refs;                     /* reference pictures kept (1..4) */
     int32_t idr_period;                 /* > 0: an IDR picture every so many pictures */
     int32_t qp;                         /* slice QP */

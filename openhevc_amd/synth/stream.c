@@ -313,7 +313,7 @@ static void write_vps(W *w)
     put_bits(&b, 0, 4); put_bits(&b, 3, 2); put_bits(&b, 0, 6); put_bits(&b, 0, 3); put_bit(&b, 1); put_bits(&b, 0xffff, 16);
     write_ptl(&b, w->p);
     put_bit(&b, 1);                                        /* sub_layer_ordering_info_present */
-    put_ue(&b, (uint32_t)w->p->n_refs + 1); put_ue(&b, 0); put_ue(&b, 0);       /* max_dec_pic_buffering_minus1, num_reorder, max_latency_plus1 */
+    put_ue(&b, (uint32_t)w->p->n_refs + 1); put_ue(&b, w->p->gop == 3 ? 2 : 0); put_ue(&b, 0);   /* max_dec_pic_buffering_minus1, num_reorder, max_latency_plus1 */
     put_bits(&b, 0, 6); put_ue(&b, 0);                     /* max_layer_id, num_layer_sets_minus1 */
     put_bit(&b, 0);                                        /* timing info */
     put_bit(&b, 0);                                        /* extension */
@@ -343,7 +343,7 @@ static void write_sps(W *w)
     put_ue(&b, (uint32_t)p->bit_depth - 8); put_ue(&b, (uint32_t)p->bit_depth - 8);
     put_ue(&b, 4);                                         /* log2_max_poc_lsb = 8 */
     put_bit(&b, 1);
-    put_ue(&b, (uint32_t)p->n_refs + 1); put_ue(&b, 0); put_ue(&b, 0);
+    put_ue(&b, (uint32_t)p->n_refs + 1); put_ue(&b, p->gop == 3 ? 2 : 0); put_ue(&b, 0);
     put_ue(&b, 0);                                         /* log2_min_cb 3 */
     put_ue(&b, (uint32_t)p->log2_ctb_size - 3);
     put_ue(&b, (uint32_t)p->log2_min_tb_size - 2);
@@ -1087,9 +1087,16 @@ static void write_slice_header(W *w, Bits *b, int nal_type, int first, int poc, 
         if (!idr) {
             put_bits(b, (uint32_t)poc & 255, 8);
             put_bit(b, 0);                                 /* short_term_ref_pic_set_sps_flag: the set follows */
-            put_ue(b, (uint32_t)dpb->n); put_ue(b, 0);     /* negative pictures only (low delay) */
+            /* the pictures kept, all of them usable by this picture: earlier ones nearest first, then later ones nearest first (7.3.7) */
+            int neg[8], pos[8], nn = 0, np_ = 0;
+            for (int i = 0; i < dpb->n; i++) { if (dpb->poc[i] < poc) neg[nn++] = dpb->poc[i]; else pos[np_++] = dpb->poc[i]; }
+            for (int i = 1; i < nn; i++) for (int j = i; j > 0 && neg[j] > neg[j - 1]; j--) { const int t = neg[j]; neg[j] = neg[j - 1]; neg[j - 1] = t; }
+            for (int i = 1; i < np_; i++) for (int j = i; j > 0 && pos[j] < pos[j - 1]; j--) { const int t = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = t; }
+            put_ue(b, (uint32_t)nn); put_ue(b, (uint32_t)np_);
             int prev = poc;
-            for (int i = 0; i < dpb->n; i++) { put_ue(b, (uint32_t)(prev - dpb->poc[i] - 1)); put_bit(b, 1); prev = dpb->poc[i]; }
+            for (int i = 0; i < nn; i++) { put_ue(b, (uint32_t)(prev - neg[i] - 1)); put_bit(b, 1); prev = neg[i]; }
+            prev = poc;
+            for (int i = 0; i < np_; i++) { put_ue(b, (uint32_t)(pos[i] - prev - 1)); put_bit(b, 1); prev = pos[i]; }
             if (p->tmvp) put_bit(b, sl->tmvp);
         }
         if (p->sao) { put_bit(b, sl->sao_luma); put_bit(b, sl->sao_chroma); }
@@ -1193,7 +1200,7 @@ static void write_slice_data(W *w, Bits *data, int ts_first, int ts_end, uint32_
     byte_align_zero(data);                                 /* the flush wrote the stop bit */
 }
 
-static void write_picture(W *w, int idx, int poc, int type, Dpb *dpb, int idr)
+static void write_picture(W *w, int idx, int poc, int type, Dpb *dpb, int idr, int nonref)
 {
     const OhStreamParams *p = w->p;
     memset(w->pic.depth, 0xff, (size_t)w->pic.w4 * w->pic.h4);
@@ -1222,7 +1229,7 @@ static void write_picture(W *w, int idx, int poc, int type, Dpb *dpb, int idr)
     for (int i = 1; i < ns; i++)
         for (int j = i; j > 0 && starts[j] < starts[j - 1]; j--) { int t = starts[j]; starts[j] = starts[j - 1]; starts[j - 1] = t; }
     starts[ns] = w->n_ctb;
-    const int nal_type = idr ? 19 : 1;                     /* IDR_W_RADL / TRAIL_R */
+    const int nal_type = idr ? 19 : nonref ? 0 : 1;        /* IDR_W_RADL / TRAIL_N / TRAIL_R */
     for (int s = 0; s < ns; s++) {
         Slice *sl = &w->sl;
         memset(sl, 0, sizeof(*sl));
@@ -1296,6 +1303,8 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
         return -1;                                         /* 4:4:4: no PCM (its chroma sample count differs), no window (the reference doubles the offsets) */
     if ((p->log2_max_tskip_size && (p->log2_max_tskip_size < 2 || p->log2_max_tskip_size > 5)) || (p->persistent_rice && p->wpp))
         return -1;
+    if (p->gop < 0 || p->gop > 3 || (p->gop == 3 && p->n_refs < 2))
+        return -1;                                         /* the hierarchical GOP keeps three pictures beside the current one */
     W w;
     memset(&w, 0, sizeof(w));
     w.p = p;
@@ -1329,14 +1338,35 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     }
     out->au_offset = (size_t *)calloc((size_t)p->n_pictures + 1, sizeof(size_t));
     Dpb dpb = { { 0 }, 0 };
-    int poc = 0;
+    int poc = 0, idr_at = 0;
     for (int i = 0; i < p->n_pictures; i++) {
         byte_align_zero(&w.out);
         out->au_offset[i] = w.out.n / 8;
         const int idr = i == 0 || (p->idr_period > 0 && i % p->idr_period == 0);
         if (idr) { write_vps(&w); write_sps(&w); write_pps(&w); dpb.n = 0; poc = 0; }
+        if (idr) idr_at = i;
         const int type = idr || p->gop == 0 ? SLICE_I : (p->gop == 1 ? SLICE_P : SLICE_B);
-        write_picture(&w, i, poc, type, &dpb, idr);
+        if (p->gop == 3) {
+            /* hierarchical B, mini-GOPs of four behind the IDR picture, decode order anchor +4, +2, +1, +3 (output order differs from
+             * decode order: two pictures of reordering).  Reference picture sets: the anchor keeps the anchor before it, +2 both
+             * anchors, +1 and +3 (sub-layer non-reference pictures) those and +2 */
+            int nonref = 0;
+            Dpb rps = { { 0 }, 0 };
+            if (!idr) {
+                static const int ofs[4] = { 4, 2, 1, 3 };
+                const int j = i - idr_at - 1, base = 4 * (j / 4), r = j % 4;
+                poc = base + ofs[r];
+                nonref = r >= 2;
+                rps.poc[rps.n++] = base;
+                if (r >= 1) rps.poc[rps.n++] = base + 4;
+                if (r >= 2) rps.poc[rps.n++] = base + 2;
+            }
+            write_picture(&w, i, poc, type, &rps, idr, nonref);
+            dpb = rps;
+            if (!nonref) dpb.poc[dpb.n++] = poc;
+            continue;
+        }
+        write_picture(&w, i, poc, type, &dpb, idr, 0);
         /* every picture is a reference; the newest n_refs are kept */
         for (int k = dpb.n < p->n_refs ? dpb.n : p->n_refs - 1; k > 0; k--) dpb.poc[k] = dpb.poc[k - 1];
         dpb.poc[0] = poc;

@@ -37,6 +37,19 @@ typedef int (*fe_start_fn)(void *h);
 typedef int (*fe_decode_fn)(void *h, const unsigned char *buf, int len, int64_t pts);
 typedef void (*fe_close_fn)(void *h);
 typedef const OhFrame *(*fe_finish_fn)(int *cur_id, int *poc, int *untranslated);
+/* the output side of the front end's public API (openHevcWrapper.h:38-66, :86): the frame libOpenHevcDecode just released for
+ * output — in OUTPUT order, inside its conformance window — as plane pointers into the front end's picture buffers; the harness
+ * only uses them to learn WHICH picture that is (fe_locate) and takes the samples from the engine's copy */
+typedef struct FeRational { int num, den; } FeRational;
+typedef struct FeFrameInfo {
+    int nYPitch, nUPitch, nVPitch, nBitDepth, nWidth, nHeight, chromat_format;
+    FeRational sample_aspect_ratio, frameRate;
+    int display_picture_number, flag;
+    int64_t nTimeStamp;
+} FeFrameInfo;
+typedef struct FeFrame { void **pvY, **pvU, **pvV; FeFrameInfo frameInfo; } FeFrame;
+typedef int (*fe_output_fn)(void *h, int got_picture, FeFrame *frame);
+typedef int (*fe_locate_fn)(const void *luma, int *x, int *y);     /* DPB slot (= picture id of the work lists) and the window's origin */
 
 static void usage(const char *prog)
 {
@@ -110,8 +123,10 @@ int main(int argc, char **argv)
     fe_decode_fn fe_decode = (fe_decode_fn)dlsym(so, "libOpenHevcDecode");
     fe_close_fn fe_close = (fe_close_fn)dlsym(so, "libOpenHevcClose");
     fe_finish_fn fe_finish = (fe_finish_fn)dlsym(so, "ref_hooked_finish");
-    if (!fe_init || !fe_start || !fe_decode || !fe_close || !fe_finish) {
-        fprintf(stderr, "%s does not export libOpenHevcInit / StartDecoder / Decode / Close / ref_hooked_finish\n", front);
+    fe_output_fn fe_output = (fe_output_fn)dlsym(so, "libOpenHevcGetOutput");
+    fe_locate_fn fe_locate = (fe_locate_fn)dlsym(so, "ref_hooked_locate");
+    if (!fe_init || !fe_start || !fe_decode || !fe_close || !fe_finish || !fe_output || !fe_locate) {
+        fprintf(stderr, "%s does not export libOpenHevcInit / StartDecoder / Decode / GetOutput / Close / ref_hooked_finish / ref_hooked_locate\n", front);
         return 1;
     }
     void *h = fe_init(nb_pthreads, thread_type);
@@ -124,16 +139,16 @@ int main(int argc, char **argv)
     OhPicParams engine_p[MAX_DPB];
     for (int i = 0; i < MAX_DPB; i++) engine_id[i] = -1;
     FILE *fo = NULL;
-    int nb_frame = 0, width = 0, height = 0, bad_planes = 0, hashed = 0, rc = 0;
+    int nb_frame = 0, nb_decoded = 0, width = 0, height = 0, bad_planes = 0, hashed = 0, rc = 0;
     uint8_t *planes[3] = { NULL, NULL, NULL };
     const double t0 = now_s();
 
-    for (long k = 0; k < n_au && !rc; k++) {
-        const uint8_t *buf = data + au[k];
-        const size_t len = au[k + 1] - au[k];
+    for (long k = 0; !rc; k++) {                             /* k >= n_au: flushing, one released picture per call */
+        const uint8_t *buf = k < n_au ? data + au[k] : NULL;
+        const size_t len = k < n_au ? au[k + 1] - au[k] : 0;
         OhPictureHash want;
         memset(&want, 0, sizeof(want));
-        if (check_md5) {
+        if (check_md5 && k < n_au) {
             OhNal units[256];
             long nu = oh_annexb_nal_units(buf, len, units, 256);
             for (long u = 0; u < nu && u < 256; u++)
@@ -143,48 +158,63 @@ int main(int argc, char **argv)
                         want = ph;
                 }
         }
-        if (fe_decode(h, buf, (int)len, k) < 0) { fprintf(stderr, "front end failed on access unit %ld\n", k); rc = 1; break; }
+        const int got_picture = k < n_au ? fe_decode(h, buf, (int)len, k) : fe_decode(h, NULL, 0, k);      /* past the last access unit: flush (main.c:225) */
+        if (got_picture < 0) { fprintf(stderr, "front end failed on access unit %ld\n", k); rc = 1; break; }
         int cur = -1, poc = 0, untranslated = 0;
-        const OhFrame *f = fe_finish(&cur, &poc, &untranslated);
-        if (!f)
-            continue;                                         /* an access unit without a picture (parameter sets only) */
-        if (untranslated) { fprintf(stderr, "%d table-slot calls of picture %d could not be turned into work-list items\n", untranslated, nb_frame); rc = 1; break; }
-        /* engine pictures for the DPB slots this work list names */
-        OhFrame g = *f;
-        int ids[1 + OH_MAX_REFS], n_ids = 0;
-        ids[n_ids++] = cur;
-        for (int r = 0; r < OH_MAX_REFS; r++)
-            if (f->ref_pics[r] >= 0) ids[n_ids++] = f->ref_pics[r];
-        for (int q = 0; q < n_ids && !rc; q++) {
-            const int d = ids[q];
-            if (d < 0 || d >= MAX_DPB) { fprintf(stderr, "DPB slot %d out of range\n", d); rc = 1; break; }
-            const int same = engine_id[d] >= 0 && engine_p[d].width == f->p.width && engine_p[d].height == f->p.height &&
-                             engine_p[d].bit_depth == f->p.bit_depth && engine_p[d].chroma_format_idc == f->p.chroma_format_idc;
-            if (!same) {
-                if (engine_id[d] >= 0) oh_pic_free(e, engine_id[d]);
-                if (oh_pic_alloc(e, &f->p, &engine_id[d]) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
-                engine_p[d] = f->p;
+        const OhFrame *f = k < n_au ? fe_finish(&cur, &poc, &untranslated) : NULL;
+        if (f) {
+            if (untranslated) { fprintf(stderr, "%d table-slot calls of picture %d could not be turned into work-list items\n", untranslated, nb_decoded); rc = 1; break; }
+            /* engine pictures for the DPB slots this work list names */
+            OhFrame g = *f;
+            int ids[1 + OH_MAX_REFS], n_ids = 0;
+            ids[n_ids++] = cur;
+            for (int r = 0; r < OH_MAX_REFS; r++)
+                if (f->ref_pics[r] >= 0) ids[n_ids++] = f->ref_pics[r];
+            for (int q = 0; q < n_ids && !rc; q++) {
+                const int d = ids[q];
+                if (d < 0 || d >= MAX_DPB) { fprintf(stderr, "DPB slot %d out of range\n", d); rc = 1; break; }
+                const int same = engine_id[d] >= 0 && engine_p[d].width == f->p.width && engine_p[d].height == f->p.height &&
+                                 engine_p[d].bit_depth == f->p.bit_depth && engine_p[d].chroma_format_idc == f->p.chroma_format_idc;
+                if (!same) {
+                    if (engine_id[d] >= 0) oh_pic_free(e, engine_id[d]);
+                    if (oh_pic_alloc(e, &f->p, &engine_id[d]) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
+                    engine_p[d] = f->p;
+                }
             }
-        }
-        if (rc) break;
-        g.cur_pic = engine_id[cur];
-        for (int r = 0; r < OH_MAX_REFS; r++)
-            g.ref_pics[r] = f->ref_pics[r] >= 0 ? engine_id[f->ref_pics[r]] : -1;
-        if (oh_frame_submit(e, &g) != OH_OK) { fprintf(stderr, "picture %d: %s\n", nb_frame, oh_engine_last_error(e)); rc = 1; break; }
-        if (check_md5 && want.present && want.hash_type == 0) {
-            uint8_t got[48];
-            if (oh_pics_md5(e, &g.cur_pic, 1, got) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
-            for (int c = 0; c < (f->p.chroma_format_idc ? 3 : 1); c++) {
-                if (memcmp(got + 16 * c, want.md5[c], 16)) {
-                    printf("Incorrect MD5 (poc: %d, plane: %d)\n", poc, c);
-                    bad_planes++;
-                } else
-                    printf("Correct MD5 (poc: %d, plane: %d)\n", poc, c);
+            if (rc) break;
+            g.cur_pic = engine_id[cur];
+            for (int r = 0; r < OH_MAX_REFS; r++)
+                g.ref_pics[r] = f->ref_pics[r] >= 0 ? engine_id[f->ref_pics[r]] : -1;
+            if (oh_frame_submit(e, &g) != OH_OK) { fprintf(stderr, "picture %d: %s\n", nb_decoded, oh_engine_last_error(e)); rc = 1; break; }
+            if (check_md5 && want.present && want.hash_type == 0) {
+                uint8_t got[48];
+                if (oh_pics_md5(e, &g.cur_pic, 1, got) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
+                for (int c = 0; c < (f->p.chroma_format_idc ? 3 : 1); c++) {
+                    if (memcmp(got + 16 * c, want.md5[c], 16)) {
+                        printf("Incorrect MD5 (poc: %d, plane: %d)\n", poc, c);
+                        bad_planes++;
+                    } else
+                        printf("Correct MD5 (poc: %d, plane: %d)\n", poc, c);
+                }
+                hashed++;
             }
-            hashed++;
+            nb_decoded++;
         }
-        if (width != f->p.width || height != f->p.height) {
-            width = f->p.width; height = f->p.height;
+        if (got_picture == 0) {
+            if (k >= n_au)
+                break;                                        /* flushed */
+            continue;                                         /* nothing released for output yet (reordering), or no picture in the access unit */
+        }
+        /* the picture the front end released for output (bumping and cropping are its host logic: hevc_refs.c:182-290) */
+        FeFrame fr;
+        memset(&fr, 0, sizeof(fr));
+        fe_output(h, 1, &fr);
+        int ox = 0, oy = 0;
+        const int slot = fe_locate((const void *)fr.pvY, &ox, &oy);
+        if (slot < 0 || slot >= MAX_DPB || engine_id[slot] < 0) { fprintf(stderr, "output picture %d is not a picture of the engine (slot %d)\n", nb_frame, slot); rc = 1; break; }
+        const OhPicParams *op = &engine_p[slot];
+        if (width != fr.frameInfo.nWidth || height != fr.frameInfo.nHeight) {
+            width = fr.frameInfo.nWidth; height = fr.frameInfo.nHeight;
             if (fo) fclose(fo);
             fo = NULL;
             if (output) {
@@ -199,8 +229,8 @@ int main(int argc, char **argv)
             }
         }
         if (fo) {
-            const size_t bpp = f->p.bit_depth > 8 ? 2 : 1;
-            const int cf = f->p.chroma_format_idc;
+            const size_t bpp = op->bit_depth > 8 ? 2 : 1;
+            const int cf = op->chroma_format_idc;
             const int hs = cf == 1 || cf == 2, vs = cf == 1;
             ptrdiff_t strides[3];
             size_t bytes[3];
@@ -210,7 +240,9 @@ int main(int argc, char **argv)
                 bytes[c] = cf || !c ? w * bpp * hh : 0;
                 planes[c] = (uint8_t *)realloc(planes[c], bytes[c] ? bytes[c] : 1);
             }
-            if (oh_pic_download(e, g.cur_pic, planes, strides) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
+            const OhWindow win = { ox, op->width - ox - width, oy, op->height - oy - height };
+            if (win.right < 0 || win.bottom < 0) { fprintf(stderr, "output window %dx%d+%d+%d leaves the %dx%d picture\n", width, height, ox, oy, op->width, op->height); rc = 1; break; }
+            if (oh_pic_download_window(e, engine_id[slot], &win, planes, strides) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
             for (int c = 0; c < 3; c++)
                 fwrite(planes[c], 1, bytes[c], fo);
         }

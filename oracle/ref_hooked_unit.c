@@ -161,6 +161,29 @@ __attribute__((visibility("default"))) const OhFrame *ref_hooked_finish(int *cur
     return oh_rec_finish(H.rec);
 }
 
+/* which picture an OUTPUT frame is: `luma` = plane 0 of the frame libOpenHevcGetOutput hands out, i.e. a DPB frame's data[0] moved
+ * to the conformance window's origin (hevc_refs.c:248-254).  Returns the DPB slot (the picture id of the work lists) and the origin
+ * in luma samples, -1 if the pointer lies in no picture of the DPB. */
+__attribute__((visibility("default"))) int ref_hooked_locate(const void *luma, int *x, int *y)
+{
+    HEVCContext *s = H.s;
+    if (!s || !s->sps || !luma)
+        return -1;
+    const uint8_t *p = (const uint8_t *)luma;
+    for (int i = 0; i < (int)FF_ARRAY_ELEMS(s->DPB); i++) {
+        const AVFrame *fr = s->DPB[i].frame;
+        if (!fr || !fr->data[0] || fr->linesize[0] <= 0)
+            continue;
+        const ptrdiff_t off = p - fr->data[0];
+        if (off < 0 || off >= (ptrdiff_t)fr->linesize[0] * s->sps->height)
+            continue;
+        *y = (int)(off / fr->linesize[0]);
+        *x = (int)(off % fr->linesize[0]) >> s->sps->pixel_shift;
+        return i;
+    }
+    return -1;
+}
+
 /* the scaling lists of the picture ref_hooked_finish just returned (as the decoder holds them after hevc_ps.c parsed or defaulted
  * them); returns 0 when the SPS has them off (flat 16).  tests/test_sparse_pin.py hands them over with the sparse levels. */
 __attribute__((visibility("default"))) int ref_hooked_scaling_list(OhScalingList *out)

@@ -39,6 +39,8 @@ STREAM_CASES = [
     ("i_444_rext_tools_10b", 200, 136, 18, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1,
                                                 tskip_rotation=1, tskip_context=1, implicit_rdpcm=1, persistent_rice=1, intra_smoothing_disabled=1,
                                                 log2_max_tskip_size=4, tskip_pct=40, bypass_pct=30)),
+    # hierarchical B: decode order +4 +2 +1 +3, references from the future, sub-layer non-reference pictures, an IDR picture in the middle
+    ("b_hier_tmvp_idr_10b", 264, 200, 19, dict(n_pictures=9, gop=3, bit_depth=10, tmvp=1, n_refs=3, idr_period=6)),
 ]
 
 
@@ -55,7 +57,9 @@ def build(name, w, h, seed, kw):
     n = refdec.record_work_lists(data, on_picture)
     assert n == len(want), (n, len(want))
     out["n_pictures"] = np.array([n])
-    out["md5"] = np.frombuffer(b"".join(b"".join(refdec.md5_of(p)) for p in want), dtype=np.uint8).copy()
+    # the digests in DECODE order, like the work lists (the reference hands its pictures out in output order)
+    rank = streamgen.output_rank(n, kw.get("gop", 2), kw.get("idr_period", 0))
+    out["md5"] = np.frombuffer(b"".join(b"".join(refdec.md5_of(want[rank[i]])) for i in range(n)), dtype=np.uint8).copy()
     return out
 
 

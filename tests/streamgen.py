@@ -93,3 +93,29 @@ def add_md5(data, aus, digests):
     res_aus = [(out.au_offset[i], out.au_offset[i + 1]) for i in range(out.n_pictures)]
     H.oh_stream_free(C.byref(out))
     return res, res_aus
+
+
+def decode_order_pocs(n_pictures, gop=2, idr_period=0):
+    """[(IDR period, POC)] of the pictures of a written stream in DECODE order (the writer's structures, ohevc_stream.h: gop 3 is
+    hierarchical B in mini-GOPs of four, decode order +4 +2 +1 +3; every other gop codes in output order)"""
+    out, period, at = [], -1, 0
+    for i in range(n_pictures):
+        if i == 0 or (idr_period > 0 and i % idr_period == 0):
+            period, at = period + 1, i
+            out.append((period, 0))
+        elif gop == 3:
+            j = i - at - 1
+            out.append((period, 4 * (j // 4) + (4, 2, 1, 3)[j % 4]))
+        else:
+            out.append((period, i - at))
+    return out
+
+
+def output_rank(n_pictures, gop=2, idr_period=0):
+    """rank[k] = position of decode-order picture k in OUTPUT order (ascending POC inside an IDR period)"""
+    keys = decode_order_pocs(n_pictures, gop, idr_period)
+    order = sorted(range(n_pictures), key=lambda k: keys[k])
+    rank = [0] * n_pictures
+    for pos, k in enumerate(order):
+        rank[k] = pos
+    return rank

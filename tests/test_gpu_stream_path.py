@@ -75,6 +75,8 @@ STREAMS = [
     ("intra_ctb16", 264, 200, 14, dict(n_pictures=3, gop=0, log2_ctb_size=4, log2_max_tb_size=4)),
     ("hd_main10", 1920, 1080, 15, dict(n_pictures=4, gop=2, bit_depth=10, wpp=1)),
     ("rext444_ccp", 416, 240, 16, dict(n_pictures=4, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1)),
+    ("hier_b_reordered", 416, 240, 18, dict(n_pictures=11, gop=3, tmvp=1, n_refs=3, idr_period=7)),
+    ("main10_window", 416, 240, 19, dict(n_pictures=4, gop=2, bit_depth=10, conf_win_left=6, conf_win_right=10, conf_win_top=4, conf_win_bottom=12)),
     ("rext_tools", 416, 240, 17, dict(n_pictures=5, gop=2, bit_depth=10, transform_skip=1, transquant_bypass=1, tskip_rotation=1, tskip_context=1, implicit_rdpcm=1,
                                       explicit_rdpcm=1, persistent_rice=1, intra_smoothing_disabled=1, log2_max_tskip_size=5, tskip_pct=45, bypass_pct=20)),
 ]
@@ -87,19 +89,24 @@ def test_harness_decodes_streams_and_the_gpu_md5_matches_the_sei(case, tmp_path)
     import streamgen
     name, w, h, seed, kw = case
     data, aus = streamgen.write_stream(w, h, seed, **kw)
-    pics = refdec.decode(data)
-    digests = [refdec.md5_of(p) for p in pics]
+    pics = refdec.decode(data)                                # output order
+    n = kw["n_pictures"]
+    rank = streamgen.output_rank(n, kw.get("gop", 2), kw.get("idr_period", 0))
+    coded = pics
+    if any(k.startswith("conf_win") for k in kw):            # the SEI hashes the CODED picture: the same stream written without the window
+        coded = refdec.decode(streamgen.write_stream(w, h, seed, **{k: v for k, v in kw.items() if not k.startswith("conf_win")})[0])
+        w, h = pics[0][0].shape[1], pics[0][0].shape[0]       # what the decoder hands out (and the harness reports) is the window
+    digests = [refdec.md5_of(coded[rank[k]]) for k in range(n)]   # the SEI of an access unit describes ITS picture: decode order
     with_sei, _ = streamgen.add_md5(data, aus, digests)
     path = tmp_path / (name + ".bin")
     path.write_bytes(with_sei)
     out = tmp_path / "out.yuv"
     r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-n", "-o", str(out)], capture_output=True, text=True, timeout=600)
-    n = kw["n_pictures"]
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("Correct MD5") == 3 * n and "Incorrect MD5" not in r.stdout
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith(f"frame= {n} fps= ") and last.endswith(f"video_size= {w}x{h}"), last
-    # -o: the pictures themselves (decode order = output order for these low-delay structures)
+    # -o: the pictures themselves, in the order and inside the window the front end releases them for output
     raw = (tmp_path / f"out_{w}x{h}.yuv").read_bytes()
     assert raw == b"".join(np.ascontiguousarray(pl).tobytes() for p in pics for pl in p)
     # a wrong digest in the stream is reported per plane and fails the run (exit code 3)

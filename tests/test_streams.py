@@ -57,6 +57,9 @@ CASES = [
     ("rext_tools_tiles_slices", 416, 240, 14, dict(n_pictures=3, gop=2, tile_cols=2, tile_rows=2, n_slices=3, log2_ctb_size=5, transform_skip=1,
                                                    transquant_bypass=1, explicit_rdpcm=1, implicit_rdpcm=1, tskip_rotation=1, persistent_rice=1,
                                                    log2_max_tskip_size=4, tskip_pct=40)),
+    # hierarchical B (decode order != output order, two pictures of reordering, sub-layer non-reference pictures, references from the future)
+    ("hier_b", 416, 240, 15, dict(n_pictures=9, gop=3)),
+    ("hier_b_tmvp_weighted_10_idr", 264, 200, 16, dict(n_pictures=11, gop=3, bit_depth=10, tmvp=1, weighted_pred=1, n_refs=3, idr_period=6, n_slices=2)),
 ]
 IDS = [c[0] for c in CASES]
 
@@ -77,8 +80,9 @@ def test_writer_syntax_is_what_the_reference_parses(case):
 
 
 def decode_through_hooks(data, threads=1, thread_type=1):
-    """pictures (decode order) reconstructed by the CHECKER from the work lists the hooked reference decoder records"""
-    pics, got = {}, []
+    """pictures reconstructed by the CHECKER from the work lists the hooked reference decoder records, in OUTPUT order
+    (ascending POC inside an IDR period — the order the plain decoder hands its pictures out in)"""
+    pics, got, keys = {}, [], []
 
     def on_picture(f, cur, poc):
         for i in [cur] + [f.ref_pics[k] for k in range(F.OH_MAX_REFS) if f.ref_pics[k] >= 0]:
@@ -86,8 +90,9 @@ def decode_through_hooks(data, threads=1, thread_type=1):
                 pics[i] = F.HostPic(f.p)
         assert oracle().oh_or_frame(C.byref(f), host_pic_array(pics)) == 0
         got.append([pics[cur].visible(c).copy() for c in range(3)])
+        keys.append((sum(1 for _, q in keys if q == 0) + (poc == 0), poc))       # POC 0 only at IDR pictures in the written streams
     refdec.record_work_lists(data, on_picture, threads, thread_type)
-    return got
+    return [got[k] for k in sorted(range(len(got)), key=lambda k: keys[k])]
 
 
 @pytest.mark.parametrize("case", CASES, ids=IDS)
@@ -157,7 +162,8 @@ def test_committed_fixtures_are_current():
         data, _ = streamgen.write_stream(w, h, seed, **kw)
         assert hashlib.md5(data).digest() == have["stream_md5"].tobytes(), name
         want = refdec.decode(data)
-        assert b"".join(b"".join(refdec.md5_of(p)) for p in want) == have["md5"].tobytes(), name
+        rank = streamgen.output_rank(len(want), kw.get("gop", 2), kw.get("idr_period", 0))       # the fixture keeps decode order
+        assert b"".join(b"".join(refdec.md5_of(want[rank[i]])) for i in range(len(want))) == have["md5"].tobytes(), name
 
 
 def test_conformance_window_is_cropped_by_the_reference_output():

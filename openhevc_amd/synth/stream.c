@@ -564,7 +564,7 @@ static void log_cross_only(W *w, int log2, int c_idx)
 }
 
 /* codes one transform block with random coefficients; scan: 0 diagonal, 1 horizontal, 2 vertical */
-static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
+static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra, int mode)      /* mode: the block's intra prediction mode (-1: inter) */
 {
     Cabac *c = &w->c;
     Rng *g = &w->g;
@@ -608,6 +608,29 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
         }
     }
     if (last_sb < 0) { lev[0] = 1; last_sb = 0; last_pos = 0; lx = ly = 0; }
+    /* sign data hiding (9.3.4.3 / hevc_cabac.c:1745-1760, 1810-1814): in a sub-block whose first and last non-zero positions are at
+     * least four scan positions apart the sign of the FIRST one is not coded, it is the parity of the sub-block's sum of magnitudes —
+     * the writer owns the content, so it gives that coefficient the sign the parity says */
+    const int sdh = w->p->sign_data_hiding && !w->cu_bypass && !rdpcm &&
+                    !(cu_intra && w->p->implicit_rdpcm && tskip && (mode == 10 || mode == 26));
+    if (sdh)
+        for (int i = 0; i < n_sb; i++) {
+            int sx, sy, first = -1, last = -1, sum = 0, fx = 0, fy = 0;
+            scan_pos(scan, n_sb_log2, i, &sx, &sy);
+            for (int k = 0; k < 16; k++) {
+                int px, py;
+                scan_pos(scan, 2, k, &px, &py);
+                const int v = lev[(sy * 4 + py) * n + sx * 4 + px];
+                if (!v) continue;
+                if (first < 0) { first = k; fx = sx * 4 + px; fy = sy * 4 + py; }
+                last = k;
+                sum += abs(v);
+            }
+            if (first >= 0 && last - first >= 4) {
+                const int a = abs(lev[fy * n + fx]);
+                lev[fy * n + fx] = (int16_t)((sum & 1) ? -a : a);
+            }
+        }
     if (g_lev_on) {
         /* header: log2 | c_idx << 4 | transform_skip << 8 | cu_transquant_bypass << 9 | intra CU << 10 | cross-component prediction << 11 |
          * QP (with QpBdOffset; valid while cu_qp_delta is off: the slice QP) << 16; then the number of levels | res_scale_val << 24;
@@ -706,8 +729,9 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra)
         }
         int g2 = 0;
         if (first_g1 >= 0) { g2 = absv[first_g1] > 2; enc_bin(c, C_GT2 + (c_idx ? 4 : 0) + ctx_set, g2); }
-        /* signs (sign data hiding is off in this writer) */
-        for (int m = 0; m < n_sig; m++) {
+        /* signs; with sign data hiding the last one coded (the sub-block's first position) is inferred */
+        const int hidden = sdh && sig[0] - sig[n_sig - 1] >= 4;
+        for (int m = 0; m < n_sig - hidden; m++) {
             int px, py;
             scan_pos(scan, 2, sig[m], &px, &py);
             enc_bypass(c, lev[(sy * 4 + py) * n + sx * 4 + px] < 0);
@@ -765,7 +789,7 @@ static void code_tu(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
     const int pu = cu->part == PART_NxN && cu->intra ? blk : 0;
     const int pc = g_c444 ? pu : 0;                        /* which chroma mode applies */
     if (cbf_luma)
-        code_residual(w, log2, 0, cu->intra ? scan_of(cu->ipm[pu], log2, 0) : 0, cu->intra);
+        code_residual(w, log2, 0, cu->intra ? scan_of(cu->ipm[pu], log2, 0) : 0, cu->intra, cu->intra ? cu->ipm[pu] : -1);
     if (g_c444) {
         /* 4:4:4: chroma blocks have the luma block's size, 4x4 included; cross-component prediction (7.3.8.12) in front of each */
         const int cross = w->p->cross_component_pred && cbf_luma && (!cu->intra || cu->cm_c[pc] == 4);
@@ -779,16 +803,16 @@ static void code_tu(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
             }
             w->cross_pf = cross; w->res_scale = scale;
             const int cbf = ci == 1 ? cbf_cb : cbf_cr;
-            if (cbf) code_residual(w, log2, ci, cu->intra ? scan_of(cu->ipm_c[pc], log2, ci) : 0, cu->intra);
+            if (cbf) code_residual(w, log2, ci, cu->intra ? scan_of(cu->ipm_c[pc], log2, ci) : 0, cu->intra, cu->intra ? cu->ipm_c[pc] : -1);
             else if (cross) log_cross_only(w, log2, ci);
             w->cross_pf = 0; w->res_scale = 0;
         }
     } else if (chroma_here) {
-        if (cbf_cb) code_residual(w, log2 - 1, 1, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 1) : 0, cu->intra);
-        if (cbf_cr) code_residual(w, log2 - 1, 2, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 2) : 0, cu->intra);
+        if (cbf_cb) code_residual(w, log2 - 1, 1, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 1) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
+        if (cbf_cr) code_residual(w, log2 - 1, 2, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 2) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
     } else if (chroma_parent) {
-        if (cbf_cb) code_residual(w, 2, 1, cu->intra ? scan_of(cu->ipm_c[0], 2, 1) : 0, cu->intra);
-        if (cbf_cr) code_residual(w, 2, 2, cu->intra ? scan_of(cu->ipm_c[0], 2, 2) : 0, cu->intra);
+        if (cbf_cb) code_residual(w, 2, 1, cu->intra ? scan_of(cu->ipm_c[0], 2, 1) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
+        if (cbf_cr) code_residual(w, 2, 2, cu->intra ? scan_of(cu->ipm_c[0], 2, 2) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
     }
     (void)x; (void)y; (void)depth;
 }
@@ -1296,7 +1320,7 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     if (!p || !out || p->width < 8 || p->height < 8 || (p->width & 7) || (p->height & 7) || (p->bit_depth != 8 && p->bit_depth != 10) ||
         p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_tb_size != 2 || p->log2_max_tb_size > 5 || p->log2_max_tb_size > p->log2_ctb_size ||
         p->log2_max_tb_size < 3 || p->n_refs < 1 || p->n_refs > 4 || p->n_pictures < 1 || p->max_th_depth_intra < 0 || p->max_th_depth_intra > 3 ||
-        p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3 || p->dependent_slices || p->sign_data_hiding)
+        p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3 || p->dependent_slices)
         return -1;
     if ((p->chroma_format_idc != 1 && p->chroma_format_idc != 3) || (p->cross_component_pred && p->chroma_format_idc != 3) ||
         (p->chroma_format_idc == 3 && (p->pcm || p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))

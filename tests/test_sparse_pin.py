@@ -28,6 +28,7 @@ CASES = [
     # 4:4:4 with cross-component prediction: the chroma blocks' levels are de-quantised and transformed on the GPU and the scaled luma
     # residual is added there (cross_kernel) — the links come from the hooked decoder's shim
     ("ccp444_8", 264, 200, 56, dict(n_pictures=3, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1)),
+    ("sdh8_lists", 264, 200, 58, dict(n_pictures=3, gop=2, sign_data_hiding=1, scaling_list=2, transform_skip=1, cbf_pct=80)),
     ("ccp444_10_lists_intra", 200, 136, 57, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, scaling_list=2, qp=24)),
 ]
 OH_TUF_SPARSE, OH_NO_COEFF, OH_FLAT_MATRIX = 16, 0xFFFFFFFF, 0xFF

@@ -57,6 +57,10 @@ CASES = [
     ("rext_tools_tiles_slices", 416, 240, 14, dict(n_pictures=3, gop=2, tile_cols=2, tile_rows=2, n_slices=3, log2_ctb_size=5, transform_skip=1,
                                                    transquant_bypass=1, explicit_rdpcm=1, implicit_rdpcm=1, tskip_rotation=1, persistent_rice=1,
                                                    log2_max_tskip_size=4, tskip_pct=40)),
+    # sign data hiding (the sign of a sub-block's first coefficient is the parity of its magnitudes), also next to the tools that switch it off per block
+    ("sdh", 416, 240, 17, dict(n_pictures=3, gop=2, sign_data_hiding=1, coeff_density=100, cbf_pct=80)),
+    ("sdh_10_tools", 264, 200, 18, dict(n_pictures=3, gop=1, bit_depth=10, sign_data_hiding=1, transform_skip=1, transquant_bypass=1, implicit_rdpcm=1,
+                                        explicit_rdpcm=1, tskip_rotation=1, scaling_list=2, cu_qp_delta=1, log2_max_tskip_size=4)),
     # hierarchical B (decode order != output order, two pictures of reordering, sub-layer non-reference pictures, references from the future)
     ("hier_b", 416, 240, 15, dict(n_pictures=9, gop=3)),
     ("hier_b_tmvp_weighted_10_idr", 264, 200, 16, dict(n_pictures=11, gop=3, bit_depth=10, tmvp=1, weighted_pred=1, n_refs=3, idr_period=6, n_slices=2)),

@@ -377,8 +377,20 @@ def main():
                     if kname.startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0]):
                         traffic, traffic_source = rec["hbm_bytes_per_launch_corrected"], os.path.relpath(tpath, ROOT)
                         break
+        # the committed rocprofv3 --kernel-trace --stats summary of this command, beside the live figure: the kernel's own duration
+        # there is shorter than the event-to-event time above, which also holds the dispatch and the wait for the other streams' kernels
+        trace_us, trace_source = None, None
+        spath = os.path.join(ROOT, "profiles", f"r02_kernel_stats_{args.workload}.csv")
+        if os.path.exists(spath):
+            import csv
+            with open(spath) as fh:
+                rows = [r for r in csv.DictReader(fh) if r["Name"].startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0])]
+            calls = sum(int(r["Calls"]) for r in rows)
+            if calls:
+                trace_us, trace_source = round(sum(float(r["TotalDurationNs"]) for r in rows) / calls / 1e3, 3), os.path.relpath(spath, ROOT)
         return dict(bound="hbm", kernel=PASS_KERNEL[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_source,
+                    kernel_trace_avg_launch_us=trace_us, kernel_trace_source=trace_source,
                     dominant_pass=dom, dominant_by="largest sum of stream-elapsed pass time between HIP events, this run",
                     launches_per_step=round(n_launch_total / steps_timed, 3), avg_launch_us=round(avg_launch_us, 3), avg_launch_source=launch_source,
                     algorithmic_bytes_per_launch=round(abytes[dom] * steps_timed / n_launch_total, 1),

@@ -189,6 +189,12 @@ typedef struct OhFrame {
     /* boundary strengths derived on the GPU: when set, vertical_bs / horizontal_bs may be NULL and the
      * engine computes both grids from these maps, bit-exact with ff_hevc_deblocking_boundary_strengths (hevc_filter.c:584-941) */
     const struct OhBsInputs *bs_in;
+    /* 16x16 CTBs with horizontally subsampled chroma only, else ignored.  In that configuration the reference's CTB driver runs a
+     * CTB's SAO before the horizontal chroma edges reached the first chroma column of its right neighbour: per CTB,
+     * bit 0 = the edges of the CTB's own row were still pending there, bit 1 = those of the CTB row below (oh_sao_pending_driver
+     * simulates ff_hevc_hls_filters / ff_hevc_hls_filter, hevc_filter.c:1027-1064, over the picture's decoding order).
+     * NULL: CTBs decoded in raster order, one thread — the engine derives the same bits in closed form. */
+    const uint8_t      *sao_pending;  /* ctb_width x ctb_height, may be NULL */
 } OhFrame;
 
 /* one entry of the reference's motion field = MvField as compiled (TEST_MV_POC defined, hevc.h:73, 1032-1041): 24 bytes, compared

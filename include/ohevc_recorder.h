@@ -97,6 +97,11 @@ typedef struct OhCtbMaps {
     int32_t  tiles_enabled;         /* pps->tiles_enabled_flag                                                                 */
     int32_t  loop_filter_across_tiles;   /* pps->loop_filter_across_tiles_enabled_flag                                         */
 } OhCtbMaps;
+/* OhFrame.sao_pending for a picture decoded in tile scan by ONE thread (hls_decode_entry, hevc.c:2643-2697: ff_hevc_hls_filters after
+ * every CTB in decoding order, the bottom-right CTB's ff_hevc_hls_filter at the end): replays the calls over the decoding order the
+ * tile ids imply and notes, for each CTB's sao_filter_CTB, whether deblocking_filter_CTB(cx + 2, cy) and (cx + 2, cy + 1) — the
+ * calls that filter the horizontal chroma edges of the right neighbour's columns (hevc_filter.c:526-530) — had run.  out: ctbs bytes */
+void oh_sao_pending_driver(const int32_t *tile_id, int ctb_width, int ctb_height, uint8_t *out);
 /* recorder-owned maps, reset at the first call after oh_rec_begin() (slice 0, tile 0, filtering across slices on) */
 OhCtbMaps *oh_rec_ctb_maps(OhRecorder *r);
 /* the maps if the current / last finished picture used them, else NULL (does not switch them on) */

@@ -52,8 +52,9 @@ typedef struct OhStreamParams {
     int32_t trace;                      /* 1: keep the list of syntax elements written (oh_stream_trace) */
     int32_t levels;                     /* 1: keep the quantised levels of every residual block written (oh_stream_levels); needs cu_qp_delta = 0 */
     int32_t conf_win_left, conf_win_right, conf_win_top, conf_win_bottom;   /* conformance window in luma samples (even), 0 = none */
-    int32_t chroma_format_idc;          /* 1 (4:2:0, Main / Main 10) or 3 (4:4:4, format range extensions profile: chroma blocks of luma size incl. 4x4,
-                                           one intra_chroma_pred_mode per partition, chroma QP = min(qPi, 51)) */
+    int32_t chroma_format_idc;          /* 1 (4:2:0, Main / Main 10), 2 (4:2:2: two square chroma blocks per transform unit one above the other, two
+                                           chroma cbf flags, mode mapping of table 8-3) or 3 (4:4:4: chroma blocks of luma size incl. 4x4, one
+                                           intra_chroma_pred_mode per partition); 2 and 3: format range extensions profile, chroma QP = min(qPi, 51) */
     int32_t cross_component_pred;       /* 4:4:4 only: cross_component_prediction_enabled_flag, random log2_res_scale_abs_plus1 / sign per chroma block */
     /* range-extension coding tools (sps_range_extension 7.3.2.2.2; any of them selects the format range extensions profile, also for 4:2:0): */
     int32_t tskip_rotation;             /* transform_skip_rotation_enabled_flag: 4x4 intra transform-skip blocks rotated by 180 degrees (hevc_cabac.c:1877-1884) */

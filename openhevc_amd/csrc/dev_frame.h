@@ -171,6 +171,7 @@ struct DevFrame {
      * every horizontal chroma edge as it was BEFORE the horizontal-edge pass — the reference's CTB driver lets the SAO of the
      * left neighbour read exactly that (deblock.hip: oh_sao_stale_*) */
     uint16_t *sao_stale;              /* [plane - 1][edge row / 8][CTB column][p0, q0] */
+    const uint8_t *sao_pending;       /* OhFrame.sao_pending (pictures not decoded in raster order), or null: closed form in sao.hip */
 };
 static __host__ __device__ inline bool oh_sao_stale_config(const OhPicParams *p) { return p->log2_ctb_size == 4 && (p->chroma_format_idc == 1 || p->chroma_format_idc == 2); }
 static __host__ __device__ inline size_t oh_sao_stale_index(const OhPicParams *p, int plane, int edge_row8, int ctb_col)

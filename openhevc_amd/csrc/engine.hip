@@ -891,6 +891,8 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_pcm = add(need_pcm ? f->is_pcm : nullptr, need_pcm ? n_pcm : 0);
     int s_db = add(has_db ? f->deblock : nullptr, has_db ? n_ctb * sizeof(OhDeblockCtb) : 0);
     int s_sao = add(has_sao ? f->sao : nullptr, has_sao ? n_ctb * sizeof(OhSaoCtb) : 0);
+    const bool has_pend = has_sao && f->sao_pending && oh_sao_stale_config(&p);     /* tiled pictures: the driver order as bits per CTB */
+    int s_pend = add(has_pend ? f->sao_pending : nullptr, has_pend ? n_ctb : 0);
     int s_coef = add(f->coeffs, (size_t)f->n_coeff * sizeof(int16_t));
     /* the dense pool is the last copied segment: when every block came as levels nothing of it crosses PCIe */
     const size_t copy_bytes = any_dense || !f->n_tu ? total : seg[s_coef].off;
@@ -992,6 +994,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.is_pcm = need_pcm ? AT(const uint8_t *, s_pcm) : nullptr;
     hd.db = AT(const OhDeblockCtb *, s_db);
     hd.sao = has_sao ? AT(const OhSaoCtb *, s_sao) : nullptr;
+    hd.sao_pending = has_pend ? AT(const uint8_t *, s_pend) : nullptr;
     hd.pu_off = AT(const uint32_t *, s_puoff); hd.ctu_aux = AT(uint32_t *, s_aux); hd.tu_keep = AT(uint8_t *, s_keep); hd.tu_cursor = AT(uint32_t *, s_cursor);
     hd.intra_perm = AT(uint32_t *, s_perm); hd.ctu_seen = AT(uint32_t *, s_seen); hd.summary = AT(void *, s_sum);
     hd.row_progress = AT(uint32_t *, s_rowp);

@@ -46,6 +46,7 @@ struct OhRecorder {
     OhBsInputs own_bs; OhMvField *bs_mvf; uint8_t *bs_cbf, *bs_call, *bs_flags;     /* recorder-owned maps (oh_rec_bs_maps) */
     OhScalingList scaling;
     OhCtbMaps ctb_maps; int ctb_maps_on;                       /* slices / tiles (oh_rec_ctb_maps); off = one slice, one tile */
+    uint8_t *sao_pending;                                     /* OhFrame.sao_pending of tiled pictures with 16x16 CTBs (oh_sao_pending_driver) */
     int8_t  *qp;
     OhDeblockCtb *deblock;
     OhSaoCtb *sao;
@@ -130,6 +131,7 @@ void oh_rec_destroy(OhRecorder *r)
     free(r->sub_start); free(r->level_start);
     free(r->bs_mvf); free(r->bs_cbf); free(r->bs_call); free(r->bs_flags);
     free(r->ctb_maps.slice_addr); free(r->ctb_maps.filter_slice_edges); free(r->ctb_maps.deblock_disabled); free(r->ctb_maps.tile_id);
+    free(r->sao_pending);
     free(r->vbs); free(r->hbs); free(r->is_pcm); free(r->is_intra); free(r->sparse); free(r->tu_sparse); free(r->tu_cross); free(r->qp); free(r->deblock); free(r->sao);
     for (int c = 0; c < 3; c++)
         free(r->lvl[c]);
@@ -263,6 +265,55 @@ OhBsInputs *oh_rec_bs_maps(OhRecorder *r)
         r->bs_in = &r->own_bs;
     }
     return &r->own_bs;
+}
+
+/* see ohevc_recorder.h.  ff_hevc_hls_filters (hevc_filter.c:1055-1064) after decoding CTB (X, Y) calls ff_hevc_hls_filter for
+ * (X-1, Y-1), for (X, Y-1) at the end of a CTB row and for (X-1, Y) in the last CTB row; the bottom-right CTB gets its call when the
+ * slice data ends (hevc.c:2693-2695).  ff_hevc_hls_filter(x, y) (:1027-1052) = deblocking_filter_CTB(x, y), then sao_filter_CTB of
+ * (x-1, y-1), of (x-1, y) in the last row, of (x, y-1) in the last column and of (x, y) in the corner. */
+void oh_sao_pending_driver(const int32_t *tile_id, int W, int H, uint8_t *out)
+{
+    const int n = W * H;
+    uint32_t *t_db = (uint32_t *)calloc((size_t)n * 2, sizeof(uint32_t)), *t_sao = t_db ? t_db + n : NULL;
+    int *order = (int *)malloc((size_t)n * sizeof(int));
+    memset(out, 0, (size_t)n);
+    if (!t_db || !order) { free(t_db); free(order); return; }
+    /* decoding order: tile after tile (ids grow in tile scan), raster inside a tile — a stable counting sort by id */
+    int max_id = 0;
+    for (int i = 0; i < n; i++) if (tile_id[i] > max_id) max_id = tile_id[i];
+    int *start = (int *)calloc((size_t)max_id + 2, sizeof(int));
+    if (!start) { free(t_db); free(order); return; }
+    for (int i = 0; i < n; i++) start[(tile_id[i] < 0 ? 0 : tile_id[i]) + 1]++;
+    for (int k = 0; k <= max_id; k++) start[k + 1] += start[k];
+    for (int i = 0; i < n; i++) order[start[tile_id[i] < 0 ? 0 : tile_id[i]]++] = i;
+    free(start);
+    uint32_t t = 0;
+#define OH_FILTER_(x, y)                                                                   \
+    do {                                                                                   \
+        const int fx = (x), fy = (y), xe = fx == W - 1, ye = fy == H - 1;                  \
+        t_db[fy * W + fx] = ++t;                                                           \
+        if (fy && fx) t_sao[(fy - 1) * W + fx - 1] = ++t;                                  \
+        if (fx && ye) t_sao[fy * W + fx - 1] = ++t;                                        \
+        if (fy && xe) t_sao[(fy - 1) * W + fx] = ++t;                                      \
+        if (xe && ye) t_sao[fy * W + fx] = ++t;                                            \
+    } while (0)
+    for (int k = 0; k < n; k++) {
+        const int X = order[k] % W, Y = order[k] / W, xe = X == W - 1, ye = Y == H - 1;
+        if (Y && X) OH_FILTER_(X - 1, Y - 1);
+        if (Y && xe) OH_FILTER_(X, Y - 1);
+        if (X && ye) OH_FILTER_(X - 1, Y);
+    }
+    OH_FILTER_(W - 1, H - 1);
+#undef OH_FILTER_
+    for (int cy = 0; cy < H; cy++)
+        for (int cx = 0; cx + 2 < W; cx++) {
+            const uint32_t me = t_sao[cy * W + cx];
+            int bits = 0;
+            if (!(t_db[cy * W + cx + 2] < me)) bits |= 1;
+            if (cy + 1 < H && !(t_db[(cy + 1) * W + cx + 2] < me)) bits |= 2;
+            out[cy * W + cx] = (uint8_t)bits;
+        }
+    free(t_db); free(order);
 }
 
 OhCtbMaps *oh_rec_ctb_maps(OhRecorder *r)
@@ -466,9 +517,19 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
         r->sorted[pos[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1]++] = r->intra[i];
     free(pos);
 
+    f->sao_pending = NULL;
     if (r->ctb_maps_on) {                                  /* slices / tiles: what the SAO and BS passes need of them */
         for (int i = 0; i < r->n_ctb; i++)
             r->sao[i].edge_flags = (uint8_t)oh_ctb_sao_edge_flags(&r->ctb_maps, r->ctbw, r->ctbh, i);
+        /* tiles change the order of the reference's filter calls; it shows in one configuration (ohevc_frame.h: sao_pending) */
+        if (r->ctb_maps.tiles_enabled && f->p.log2_ctb_size == 4 && oh_hshift(&f->p, 1)) {
+            if (!r->sao_pending)
+                r->sao_pending = (uint8_t *)malloc((size_t)r->n_ctb);
+            if (r->sao_pending) {
+                oh_sao_pending_driver(r->ctb_maps.tile_id, r->ctbw, r->ctbh, r->sao_pending);
+                f->sao_pending = r->sao_pending;
+            }
+        }
         if (r->bs_in == &r->own_bs) {
             for (int i = 0; i < r->n_ctb; i++)
                 r->bs_flags[i] = (uint8_t)oh_ctb_bs_flags(&r->ctb_maps, r->ctbw, i);

@@ -44,11 +44,11 @@ static __device__ __forceinline__ void store8(GLOBAL PX *p, const int v[8])
 struct SaoEdgeCtx { int x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd; const GLOBAL uint16_t *stale; int stale_r, vs; };
 
 /* 16x16 CTBs with subsampled chroma (DevFrame.sao_stale): sample (x0 + 8, yr) — first column of the right neighbour — as
- * sao_filter_CTB of this CTB saw it: rows touched by a horizontal chroma edge of a CTB row >= stale_r were not filtered yet */
+ * sao_filter_CTB of this CTB saw it: rows touched by a horizontal chroma edge of a pending CTB row (stale_r bit 0: row cy, bit 1: row cy + 1) were not filtered yet */
 static __device__ __forceinline__ int sao_stale_or(const SaoEdgeCtx &e, const OhPicParams &pp, int c, int yr, int v)
 {
     const int p0 = (yr & 7) == 7, ye = p0 ? yr + 1 : yr;
-    if ((ye & 7) == 0 && ye > 0 && ye < e.ph && ((ye << e.vs) >> 4) >= e.stale_r)
+    if ((ye & 7) == 0 && ye > 0 && ye < e.ph && ((e.stale_r >> ((((ye << e.vs) >> 4) > e.cy) ? 1 : 0)) & 1))
         return e.stale[oh_sao_stale_index(&pp, c, ye >> 3, e.cx + 1) + (p0 ? 0 : 1)];
     return v;
 }
@@ -153,8 +153,13 @@ __global__ __launch_bounds__(256) void sao_kernel(const OhBatch B, const int str
         for (int k = 0; k < 5; k++) off[k] = s->offset_val[c][k];
         /* the chroma CTB is one 8-sample group wide in that configuration: x + 8 is the neighbour's first column */
         const GLOBAL uint16_t *stale = c && pp.deblock_enabled ? G_CONST(uint16_t, f->sao_stale) : nullptr;
-        const SaoEdgeCtx ec = { x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd, stale,
-                                cy + 1 < ctbh - 2 ? cy + 1 : (ctbh >= 2 ? ctbh - 2 : 0), vs };
+        /* rows pending when the reference's driver ran this CTB's SAO: from min(cy + 1, ctbh - 2) on — from min(cy + 1, ctbh - 1) on when
+         * the CTB after the neighbour is the last of its row (its deblocking call comes a CTB earlier, hevc_filter.c:1058-1059) */
+        const int r_lag = cx + 2 == ctbw - 1 ? ctbh - 1 : (ctbh >= 2 ? ctbh - 2 : 0), r_pending = min(cy + 1, r_lag);
+        /* as bits: 0 = the edges of CTB row cy pending, 1 = those of row cy + 1; handed over per CTB when the picture was not decoded
+         * in raster order (tiles: DevFrame.sao_pending, OhFrame.sao_pending) */
+        const int pend = f->sao_pending ? G_CONST(uint8_t, f->sao_pending)[cy * ctbw + cx] : (cy >= r_pending ? 1 : 0) | (cy + 1 >= r_pending ? 2 : 0);
+        const SaoEdgeCtx ec = { x, y, x0, y0, w, h, pw, ph, sstride, cx, cy, ctbw, ctbh, flags, bd, stale, pend, vs };
         switch (eo) {                                       /* compile-time neighbour offsets: no indexed registers */
         case 0:  sao_edge8<PX, -1, 0>(src, ec, off, v, r, pp, c); break;
         case 1:  sao_edge8<PX, 0, -1>(src, ec, off, v, r, pp, c); break;

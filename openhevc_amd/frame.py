@@ -76,6 +76,7 @@ class OhFrame(C.Structure):
         ("deblock", C.POINTER(OhDeblockCtb)), ("sao", C.POINTER(OhSaoCtb)), ("is_intra", C.POINTER(C.c_uint8)),
         ("n_sparse", C.c_uint32), ("sparse", C.POINTER(C.c_uint32)), ("tu_sparse", C.POINTER(C.c_uint32)),
         ("scaling", C.c_void_p), ("tu_cross", C.POINTER(C.c_uint32)), ("bs_in", C.c_void_p),
+        ("sao_pending", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -353,6 +354,7 @@ class FrameCopy:
         g.sparse = dup(f.sparse, f.n_sparse * 4, C.c_uint32)
         g.tu_sparse = dup(f.tu_sparse, f.n_tu * 4 if f.sparse else 0, C.c_uint32)
         g.tu_cross = dup(f.tu_cross, f.n_tu * 4, C.c_uint32)
+        g.sao_pending = dup(f.sao_pending, n_ctb, C.c_uint8)
         if f.scaling:
             buf = np.frombuffer(C.string_at(f.scaling, 4 * 6 * 64 + 12), dtype=np.uint8).copy()
             self.keep.append(buf)
@@ -412,6 +414,8 @@ def frame_to_arrays(f):
     out["sao"] = grab(f.sao, n_ctb * C.sizeof(OhSaoCtb))
     if f.tu_cross:
         out["tu_cross"] = np.frombuffer(C.string_at(f.tu_cross, int(f.n_tu) * 4), dtype=np.uint32).copy()
+    if f.sao_pending:
+        out["sao_pending"] = grab(f.sao_pending, n_ctb)
     return out
 
 
@@ -442,6 +446,8 @@ class FrameFromArrays:
             f.n_sparse = int(self.a["sparse"].size)
             f.sparse, f.tu_sparse = ptr("sparse", C.c_uint32), ptr("tu_sparse", C.c_uint32)
             assert self.a["tu_sparse"].size == f.n_tu
+        if "sao_pending" in self.a:                       # optional: the filter-call order of a tiled picture (OhFrame.sao_pending)
+            f.sao_pending = ptr("sao_pending", C.c_uint8)
         if "tu_cross" in self.a:                          # optional: cross-component links (luma TU index | res_scale_val << 24 per TU)
             assert self.a["tu_cross"].size == f.n_tu
             f.tu_cross = ptr("tu_cross", C.c_uint32)

@@ -291,7 +291,7 @@ static void fill(uint8_t *m, const W *w, int x, int y, int n, int v)
 /* ================================================================================================= parameter sets */
 static int rext_profile(const OhStreamParams *p)
 {
-    return p->chroma_format_idc == 3 || p->tskip_rotation || p->tskip_context || p->implicit_rdpcm || p->explicit_rdpcm || p->intra_smoothing_disabled ||
+    return p->chroma_format_idc >= 2 || p->tskip_rotation || p->tskip_context || p->implicit_rdpcm || p->explicit_rdpcm || p->intra_smoothing_disabled ||
            p->persistent_rice || p->log2_max_tskip_size > 2;
 }
 
@@ -329,7 +329,7 @@ static void write_sps(W *w)
     put_bits(&b, 0, 4); put_bits(&b, 0, 3); put_bit(&b, 1);                      /* vps id, max_sub_layers_minus1, temporal_id_nesting */
     write_ptl(&b, p);
     put_ue(&b, 0);                                         /* sps id */
-    put_ue(&b, (uint32_t)p->chroma_format_idc);            /* 1 = 4:2:0, 3 = 4:4:4 */
+    put_ue(&b, (uint32_t)p->chroma_format_idc);            /* 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 */
     if (p->chroma_format_idc == 3) put_bit(&b, 0);         /* separate_colour_plane_flag */
     put_ue(&b, (uint32_t)p->width); put_ue(&b, (uint32_t)p->height);
     {   /* conformance window, offsets in chroma sample units (4:2:0: two luma samples) */
@@ -761,6 +761,7 @@ static void code_residual(W *w, int log2, int c_idx, int scan, int cu_intra, int
 typedef struct Cu { int x, y, log2, intra, part, bypass, merge_2Nx2N; int ipm[4], ipm_c[4], cm_c[4]; } Cu;   /* ipm_c / cm_c: chroma mode and intra_chroma_pred_mode per partition (one unless 4:4:4 NxN) */
 
 static int g_c444;                                    /* ChromaArrayType == 3 in the stream being written */
+static int g_c422;                                    /* ChromaArrayType == 2: two square chroma blocks per transform unit, one above the other */
 static int scan_of(int mode, int log2, int c_idx)
 {
     if (!(log2 == 2 || (log2 == 3 && (c_idx == 0 || g_c444))))
@@ -807,12 +808,14 @@ static void code_tu(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
             else if (cross) log_cross_only(w, log2, ci);
             w->cross_pf = 0; w->res_scale = 0;
         }
-    } else if (chroma_here) {
-        if (cbf_cb) code_residual(w, log2 - 1, 1, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 1) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
-        if (cbf_cr) code_residual(w, log2 - 1, 2, cu->intra ? scan_of(cu->ipm_c[0], log2 - 1, 2) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
-    } else if (chroma_parent) {
-        if (cbf_cb) code_residual(w, 2, 1, cu->intra ? scan_of(cu->ipm_c[0], 2, 1) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
-        if (cbf_cr) code_residual(w, 2, 2, cu->intra ? scan_of(cu->ipm_c[0], 2, 2) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
+    } else if (chroma_here || chroma_parent) {
+        /* 4:2:0 / 4:2:2: chroma blocks of half the luma width (of the 8x8 parent for 4x4 luma blocks); 4:2:2 has two per component,
+         * the second below the first (7.3.8.10: all of Cb, then all of Cr; hevc.c:1302-1391) */
+        const int lc2 = chroma_here ? log2 - 1 : 2;
+        for (int ci = 1; ci <= 2; ci++)
+            for (int i = 0; i < (g_c422 ? 2 : 1); i++)
+                if (((ci == 1 ? cbf_cb : cbf_cr) >> i) & 1)
+                    code_residual(w, lc2, ci, cu->intra ? scan_of(cu->ipm_c[0], lc2, ci) : 0, cu->intra, cu->intra ? cu->ipm_c[0] : -1);
     }
     (void)x; (void)y; (void)depth;
 }
@@ -830,10 +833,19 @@ static void code_tt(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
     } else {
         split = log2 > p->log2_max_tb_size || (intra_split && depth == 0) || inter_split;
     }
-    int cb = 0, cr = 0;
+    int cb = 0, cr = 0;                                    /* bit 0: the (first) chroma block, bit 1: 4:2:2's second block below it */
     if (log2 > 2 || g_c444) {
-        if (depth == 0 || pcb) { cb = pct(&w->g, p->cbf_pct / 2 + 5); enc_bin(c, C_CBF_CHROMA + depth, cb); tr(OH_SE_CBF_CHROMA, cb); }
-        if (depth == 0 || pcr) { cr = pct(&w->g, p->cbf_pct / 2 + 5); enc_bin(c, C_CBF_CHROMA + depth, cr); tr(OH_SE_CBF_CHROMA, cr); }
+        const int two = g_c422 && (!split || log2 == 3);   /* 7.3.8.8: the second flag where the chroma blocks are coded at this level */
+        for (int comp = 0; comp < 2; comp++) {
+            int *f = comp ? &cr : &cb;
+            if (!(depth == 0 || ((comp ? pcr : pcb) & 1)))
+                continue;
+            for (int i = 0; i < (two ? 2 : 1); i++) {
+                const int v = pct(&w->g, p->cbf_pct / 2 + 5);
+                enc_bin(c, C_CBF_CHROMA + depth, v); tr(OH_SE_CBF_CHROMA, v);
+                *f |= v << i;
+            }
+        }
     } else {
         cb = pcb; cr = pcr;                                /* 4x4 luma blocks: the chroma flags of the 8x8 parent apply */
     }
@@ -1036,6 +1048,11 @@ static void code_cu(W *w, int x, int y, int log2)
             static const uint8_t tab[4] = { 0, 26, 10, 1 };
             cu.cm_c[k] = cm;
             cu.ipm_c[k] = cm == 4 ? cu.ipm[k] : (tab[cm] == cu.ipm[k] ? 34 : tab[cm]);
+            if (g_c422) {                                  /* the 4:2:2 mode mapping (table 8-3; hevc.c:2252-2254, 2299-2310) */
+                static const uint8_t tab422[35] = { 0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 15, 17, 18, 19, 20,
+                                                    21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31 };
+                cu.ipm_c[k] = tab422[cu.ipm_c[k]];
+            }
         }
     } else {
         fill(w->pic.ipm, w, x, y, n, 1);
@@ -1322,9 +1339,9 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
         p->log2_max_tb_size < 3 || p->n_refs < 1 || p->n_refs > 4 || p->n_pictures < 1 || p->max_th_depth_intra < 0 || p->max_th_depth_intra > 3 ||
         p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3 || p->dependent_slices)
         return -1;
-    if ((p->chroma_format_idc != 1 && p->chroma_format_idc != 3) || (p->cross_component_pred && p->chroma_format_idc != 3) ||
-        (p->chroma_format_idc == 3 && (p->pcm || p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))
-        return -1;                                         /* 4:4:4: no PCM (its chroma sample count differs), no window (the reference doubles the offsets) */
+    if (p->chroma_format_idc < 1 || p->chroma_format_idc > 3 || (p->cross_component_pred && p->chroma_format_idc != 3) ||
+        (p->chroma_format_idc >= 2 && (p->pcm || p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))
+        return -1;                                         /* 4:2:2 / 4:4:4: no PCM (its chroma sample count differs), no window (the reference doubles the offsets) */
     if ((p->log2_max_tskip_size && (p->log2_max_tskip_size < 2 || p->log2_max_tskip_size > 5)) || (p->persistent_rice && p->wpp))
         return -1;
     if (p->gop < 0 || p->gop > 3 || (p->gop == 3 && p->n_refs < 2))
@@ -1335,6 +1352,7 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     g_trace_on = p->trace != 0; g_trace_n = 0;
     g_lev_on = p->levels != 0 && !p->cu_qp_delta; g_lev_n = 0;
     g_c444 = p->chroma_format_idc == 3;
+    g_c422 = p->chroma_format_idc == 2;
     w.g.s = p->seed * 0x2545F4914F6CDD1Dull + 77;
     w.lc = p->log2_ctb_size; w.ctb = 1 << w.lc;
     w.ctbw = (p->width + w.ctb - 1) >> w.lc; w.ctbh = (p->height + w.ctb - 1) >> w.lc; w.n_ctb = w.ctbw * w.ctbh;

@@ -498,7 +498,8 @@ static int chroma_tc(const OhFrame *f, int qp_y, int c_idx, int tc_offset) /* he
  * call for X + 1: the SAO of CTB (cx, cy) copies the first chroma column of its right neighbour (copy_CTB, :305-307) while the
  * horizontal edges of the CTB rows r >= min(cy + 1, ctb_height - 2) have not touched that column yet (SAO(cx, cy) is triggered by
  * decoding CTB (cx + 2, min(cy + 2, last row)), the deblocking call for CTB (cx + 2, r) by CTB (cx + 3, min(r + 1, last row)):
- * in the last two CTB rows the lag between the two shrinks to one CTB).  With wider chroma CTBs, and for luma, the own first columns of a CTB are filtered in its own call and
+ * in the last two CTB rows the lag between the two shrinks to one CTB; and when cx + 2 is the LAST CTB column, the deblocking call
+ * for it comes from the row-end branch of ff_hevc_hls_filters, a CTB earlier: then r >= min(cy + 1, ctb_height - 1)).  With wider chroma CTBs, and for luma, the own first columns of a CTB are filtered in its own call and
  * nothing is pending.  To reproduce it the deblock pass keeps the chroma planes as they are before its horizontal chroma
  * edges; the SAO pass of the SAME picture (next call on this thread) patches the neighbour column from that. */
 static __thread struct { uint8_t *px[3]; size_t bytes[3]; const void *pic; int w, h, valid; } g_pre_h;
@@ -663,13 +664,21 @@ int oh_or_pass_sao(const OhFrame *f, OhHostPic *pics)
                     const int stale = c && sao_sees_stale_column(p) && p->deblock_enabled && g_pre_h.valid && g_pre_h.pic == cur->data[0] &&
                                       g_pre_h.w == p->width && g_pre_h.h == p->height && cx + 2 < ctbw;
                     uint8_t saved[2 * (16 + 2)];
-                    const int r_pending = cy + 1 < ctbh - 2 ? cy + 1 : (ctbh >= 2 ? ctbh - 2 : 0), ya = y0 > 0 ? y0 - 1 : 0, yb = y0 + h < ph ? y0 + h : ph - 1;
+                    /* first CTB row whose horizontal edges the neighbour column has not seen yet.  When the neighbour's own right
+                     * neighbour is the LAST CTB column, its deblocking call comes from the row-end branch of ff_hevc_hls_filters
+                     * (hevc_filter.c:1058-1059), which in the last two CTB rows runs BEFORE the call that triggers this SAO: there only
+                     * the rows from cy + 1 on are pending */
+                    const int r_lag = cx + 2 == ctbw - 1 ? ctbh - 1 : (ctbh >= 2 ? ctbh - 2 : 0);
+                    const int r_pending = cy + 1 < r_lag ? cy + 1 : r_lag, ya = y0 > 0 ? y0 - 1 : 0, yb = y0 + h < ph ? y0 + h : ph - 1;
+                    /* bit 0: the edges of CTB row cy pending, bit 1: those of row cy + 1 — from the work list when the picture was not
+                     * decoded in raster order (tiles: OhFrame.sao_pending), else the closed form above */
+                    const int pend = f->sao_pending ? f->sao_pending[cy * ctbw + cx] : (cy >= r_pending ? 1 : 0) | (cy + 1 >= r_pending ? 2 : 0);
                     if (stale)
                         for (int y = ya; y <= yb; y++) {
                             uint8_t *px = copy + (ptrdiff_t)y * st + (x0 + w) * bpp;
                             memcpy(saved + (y - ya) * bpp, px, (size_t)bpp);
                             const int ye = (y & 7) == 7 ? y + 1 : y;                    /* the horizontal edge that touches row y: p0 row or q0 row */
-                            if ((ye & 7) == 0 && ye > 0 && ((ye << vs) >> lc) >= r_pending)
+                            if ((ye & 7) == 0 && ye > 0 && ((pend >> (((ye << vs) >> lc) > cy)) & 1))
                                 memcpy(px, g_pre_h.px[c] + (ptrdiff_t)y * st + (x0 + w) * bpp, (size_t)bpp);
                         }
                     oh_or_sao_edge(bd, dst, src, st, st, s->offset_val[c], s->eo_class[c], borders, w, h,

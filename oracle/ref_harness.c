@@ -368,12 +368,15 @@ API int ref_filter_picture(const OhFrame *f, uint8_t *const data[3], const ptrdi
         ctx_free(r);
         return -1;
     }
-    for (int y_ctb = 0; y_ctb < p->height; y_ctb += ctb)
-        for (int x_ctb = 0; x_ctb < p->width; x_ctb += ctb) {
-            ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb);                       /* hevc.c:2690 */
-            if (x_ctb + ctb >= p->width && y_ctb + ctb >= p->height)
-                ff_hevc_hls_filter(s, x_ctb, y_ctb, ctb);                    /* hevc.c:2693-2695 */
-        }
+    /* in DECODING order (tile scan, hevc.c:2666-2669: ctb_addr_rs = ctb_addr_rs_to_ts^-1[ctb_addr_ts]), as the single-threaded CTU
+     * loop does: the order of the calls shows in the output for 16x16 CTBs with subsampled chroma (OhFrame.sao_pending) */
+    const int ctbw = (p->width + ctb - 1) / ctb, n_ctbs = ctbw * ((p->height + ctb - 1) / ctb);
+    for (int ts = 0; ts < n_ctbs; ts++) {
+        const int rs = r->ts_to_rs[ts], x_ctb = (rs % ctbw) * ctb, y_ctb = (rs / ctbw) * ctb;
+        ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb);                           /* hevc.c:2690 */
+        if (x_ctb + ctb >= p->width && y_ctb + ctb >= p->height)
+            ff_hevc_hls_filter(s, x_ctb, y_ctb, ctb);                        /* hevc.c:2693-2695 */
+    }
     ctx_free(r);
     return 0;
 }

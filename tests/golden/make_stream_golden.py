@@ -41,6 +41,11 @@ STREAM_CASES = [
                                                 log2_max_tskip_size=4, tskip_pct=40, bypass_pct=30)),
     # hierarchical B: decode order +4 +2 +1 +3, references from the future, sub-layer non-reference pictures, an IDR picture in the middle
     ("b_hier_tmvp_idr_10b", 264, 200, 19, dict(n_pictures=9, gop=3, bit_depth=10, tmvp=1, n_refs=3, idr_period=6)),
+    # 4:2:2; and tiles with 16x16 CTBs, where the work lists carry the reference's filter-call order (OhFrame.sao_pending)
+    ("b_422_tools_8b", 264, 200, 20, dict(n_pictures=3, gop=2, chroma_format_idc=2, transform_skip=1, transquant_bypass=1, tmvp=1)),
+    ("p_422_ctb16_tiles_slices_10b", 200, 168, 21, dict(n_pictures=3, gop=1, chroma_format_idc=2, bit_depth=10, log2_ctb_size=4, log2_max_tb_size=4, n_slices=2,
+                                                        sao_pct=90, tile_cols=2, tile_rows=2, lf_across_tiles=0)),
+    ("i_420_ctb16_tiles3x2", 296, 168, 22, dict(n_pictures=2, gop=0, log2_ctb_size=4, log2_max_tb_size=4, sao_pct=90, tile_cols=3, tile_rows=2)),
 ]
 
 

@@ -77,6 +77,8 @@ STREAMS = [
     ("rext444_ccp", 416, 240, 16, dict(n_pictures=4, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1)),
     ("hier_b_reordered", 416, 240, 18, dict(n_pictures=11, gop=3, tmvp=1, n_refs=3, idr_period=7)),
     ("main10_window", 416, 240, 19, dict(n_pictures=4, gop=2, bit_depth=10, conf_win_left=6, conf_win_right=10, conf_win_top=4, conf_win_bottom=12)),
+    ("rext422_tiles_ctb16", 264, 200, 20, dict(n_pictures=4, gop=2, chroma_format_idc=2, bit_depth=10, log2_ctb_size=4, log2_max_tb_size=4, tile_cols=2, tile_rows=2,
+                                               n_slices=2, sao_pct=90)),
     ("rext_tools", 416, 240, 17, dict(n_pictures=5, gop=2, bit_depth=10, transform_skip=1, transquant_bypass=1, tskip_rotation=1, tskip_context=1, implicit_rdpcm=1,
                                       explicit_rdpcm=1, persistent_rice=1, intra_smoothing_disabled=1, log2_max_tskip_size=5, tskip_pct=45, bypass_pct=20)),
 ]

@@ -61,6 +61,18 @@ CASES = [
     ("sdh", 416, 240, 17, dict(n_pictures=3, gop=2, sign_data_hiding=1, coeff_density=100, cbf_pct=80)),
     ("sdh_10_tools", 264, 200, 18, dict(n_pictures=3, gop=1, bit_depth=10, sign_data_hiding=1, transform_skip=1, transquant_bypass=1, implicit_rdpcm=1,
                                         explicit_rdpcm=1, tskip_rotation=1, scaling_list=2, cu_qp_delta=1, log2_max_tskip_size=4)),
+    # 4:2:2 (format range extensions): two chroma blocks per transform unit one above the other, two chroma cbf flags, the 4:2:2 chroma mode mapping
+    ("rext422_intra", 264, 200, 31, dict(n_pictures=2, gop=0, chroma_format_idc=2)),
+    ("rext422_b_tools", 264, 200, 31, dict(n_pictures=3, gop=2, chroma_format_idc=2, transform_skip=1, transquant_bypass=1, cu_qp_delta=1, tmvp=1)),
+    # ... with 16x16 CTBs (8 chroma samples wide): the SAO of a CTB in the last two CTB rows whose neighbour's neighbour is the last CTB column
+    ("rext422_p_ctb16_slices_weighted_10", 264, 200, 31, dict(n_pictures=3, gop=1, chroma_format_idc=2, bit_depth=10, log2_ctb_size=4, log2_max_tb_size=4,
+                                                              n_slices=2, weighted_pred=1)),
+    # tiles with 16x16 CTBs and subsampled chroma: the order of the reference's filter calls follows the tile scan (OhFrame.sao_pending)
+    ("tiles_ctb16_420", 296, 168, 521581, dict(n_pictures=3, gop=0, log2_ctb_size=4, log2_max_tb_size=4, n_slices=2, sao_pct=90, tile_cols=2, tile_rows=2, lf_across_tiles=0)),
+    ("tiles_ctb16_422_10", 128, 160, 347975, dict(n_pictures=2, gop=1, chroma_format_idc=2, bit_depth=10, log2_ctb_size=4, log2_max_tb_size=4, n_slices=2, sao_pct=90,
+                                                  tile_cols=2, tile_rows=2, lf_across_tiles=0, deblocking_override=1)),
+    ("tiles3x3_ctb16_420_hier", 152, 88, 806835, dict(n_pictures=5, gop=3, log2_ctb_size=4, log2_max_tb_size=4, n_slices=3, sao_pct=90, tile_cols=3, tile_rows=3,
+                                                       lf_across_tiles=1, deblocking_override=1)),
     # hierarchical B (decode order != output order, two pictures of reordering, sub-layer non-reference pictures, references from the future)
     ("hier_b", 416, 240, 15, dict(n_pictures=9, gop=3)),
     ("hier_b_tmvp_weighted_10_idr", 264, 200, 16, dict(n_pictures=11, gop=3, bit_depth=10, tmvp=1, weighted_pred=1, n_refs=3, idr_period=6, n_slices=2)),
@@ -199,3 +211,42 @@ def test_recording_slots_under_the_reference_wavefront_threads(kw):
         for k in range(4):
             for c in range(3):
                 assert np.array_equal(want[k][c], got[k][c]), (rep, "picture", k, "plane", c)
+
+
+def test_filter_call_order_simulation_equals_the_closed_form_in_raster_order():
+    """16x16 CTBs, subsampled chroma: which horizontal chroma edges the reference's CTB driver had NOT filtered yet in the right
+    neighbour's first column when it ran a CTB's SAO.  The engine and the checker use a closed form for pictures decoded in raster
+    order and, for tiled pictures, the bits oh_sao_pending_driver derives by replaying ff_hevc_hls_filters over the decoding order —
+    with one tile the replay must give the closed form, for every picture size in CTBs"""
+    H = F.host()
+    H.oh_sao_pending_driver.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    for W in range(1, 10):
+        for Hh in range(1, 9):
+            tid, out = (C.c_int32 * (W * Hh))(), (C.c_uint8 * (W * Hh))()
+            H.oh_sao_pending_driver(tid, W, Hh, out)
+            for cy in range(Hh):
+                for cx in range(W):
+                    want = 0
+                    if cx + 2 < W:
+                        r_lag = Hh - 1 if cx + 2 == W - 1 else (Hh - 2 if Hh >= 2 else 0)
+                        rp = min(cy + 1, r_lag)
+                        want = (1 if cy >= rp else 0) | (2 if cy + 1 >= rp and cy + 1 < Hh else 0)
+                    assert out[cy * W + cx] == want, (W, Hh, cx, cy)
+
+
+def test_random_small_ctb_streams():
+    """a seeded sweep over 16x16-CTB streams (every chroma format, slices, tiles up to 3 x 3, all GOP shapes): the configuration in
+    which the reference's filter-call order shows in the output"""
+    import random
+    rng = random.Random(2024)
+    for _ in range(16):
+        w, h = 8 * rng.randint(4, 36), 8 * rng.randint(3, 26)
+        kw = dict(n_pictures=rng.choice([2, 3]), gop=rng.choice([0, 1, 2, 3]), chroma_format_idc=rng.choice([1, 2, 2, 3]), bit_depth=rng.choice([8, 10]),
+                  log2_ctb_size=4, log2_max_tb_size=4, n_slices=rng.choice([1, 2, 3]), sao_pct=90)
+        if rng.random() < 0.6:
+            kw.update(tile_cols=rng.choice([2, 3]), tile_rows=rng.choice([1, 2, 3]), lf_across_tiles=rng.choice([0, 1]))
+        if rng.random() < 0.3:
+            kw.update(lf_across_slices=0)
+        if kw["gop"] == 3:
+            kw.update(n_pictures=5)
+        test_hooked_ctu_loop_reproduces_the_reference_decoder(("sweep", w, h, rng.randint(1, 10 ** 6), kw))

@@ -1171,15 +1171,17 @@ static void write_slice_header(W *w, Bits *b, int nal_type, int first, int poc, 
             put_ue(b, (uint32_t)(5 - sl->max_merge));
         }
         put_se(b, sl->qp - 26);
+        int deblock_off = 0;                               /* slice_deblocking_filter_disabled_flag: the PPS's (0) unless overridden */
         if (p->deblocking_override) {
             const int ov = rnd(&w->g, 2);
             put_bit(b, ov);
             if (ov) {
-                put_bit(b, sl->deblock_disabled);
-                if (!sl->deblock_disabled) { put_se(b, rnd(&w->g, 7) - 3); put_se(b, rnd(&w->g, 7) - 3); }
+                deblock_off = sl->deblock_disabled;
+                put_bit(b, deblock_off);
+                if (!deblock_off) { put_se(b, rnd(&w->g, 7) - 3); put_se(b, rnd(&w->g, 7) - 3); }
             }
         }
-        if (p->lf_across_slices && (sl->sao_luma || sl->sao_chroma || !(p->deblocking_override && sl->deblock_disabled)))
+        if (p->lf_across_slices && (sl->sao_luma || sl->sao_chroma || !deblock_off))
             put_bit(b, sl->lf_across);
     }
     if (w->tcols > 1 || w->trows > 1 || p->wpp) {

@@ -183,3 +183,33 @@ def test_harness_at_baseline_geometries(name, w, h, kw, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("Correct MD5") == 3 * n and "Incorrect MD5" not in r.stdout
     assert r.stdout.strip().splitlines()[-1].startswith(f"frame= {n} fps= ")
+
+
+@need_front_end
+def test_random_streams_through_the_harness(tmp_path):
+    """a seeded sweep over the stream writer's parameter space (tools/sweep_streams.py: sizes, chroma formats, CTB sizes, slices / tiles /
+    wavefronts, every GOP shape, range-extension tools, windows ...): file -> ohevc_dec (hooked reference front end -> engine) must write
+    exactly the pictures the unmodified reference decoder outputs, in its order and window"""
+    import random
+    import refdec
+    import streamgen
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sweep_streams
+    rng = random.Random(77)
+    done = 0
+    for _ in range(40):
+        w, h, seed, kw = sweep_streams.draw(rng)
+        data, _ = streamgen.write_stream(w, h, seed, **kw)
+        pics = refdec.decode(data)
+        path = tmp_path / "s.bin"
+        path.write_bytes(data)
+        out = tmp_path / "o.yuv"
+        for old in tmp_path.glob("o_*.yuv"):
+            old.unlink()
+        r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-c", "-o", str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (w, h, seed, kw, r.stdout[-1500:] + r.stderr[-1500:])
+        ow, oh = pics[0][0].shape[1], pics[0][0].shape[0]
+        raw = (tmp_path / f"o_{ow}x{oh}.yuv").read_bytes()
+        assert raw == b"".join(np.ascontiguousarray(pl).tobytes() for p in pics for pl in p), (w, h, seed, kw)
+        done += 1
+    assert done == 40

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Random sweep of the stream writer's parameter space through the reference decoder (container only: needs oracle/_ref):
+every stream is decoded by the unmodified reference and by the hooked reference + CPU checker; any difference is printed with
+the parameters that reproduce it.  usage: sweep_streams.py [count] [seed]"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import refdec  # noqa: E402
+import streamgen  # noqa: E402
+import test_streams as T  # noqa: E402
+
+
+def draw(rng):
+    lc = rng.choice([4, 5, 6])
+    cf = rng.choice([1, 1, 2, 3])
+    kw = dict(n_pictures=rng.choice([2, 3, 4]), gop=rng.choice([0, 1, 2, 2, 3]), chroma_format_idc=cf, bit_depth=rng.choice([8, 10]),
+              log2_ctb_size=lc, log2_max_tb_size=min(lc, rng.choice([3, 4, 5])), n_refs=rng.choice([1, 2, 3, 4]),
+              qp=rng.randint(12, 44), sao_pct=rng.choice([0, 50, 90]), split_pct=rng.choice([20, 50, 80]), intra_pct=rng.choice([5, 20, 60]),
+              cbf_pct=rng.choice([20, 55, 90]), coeff_density=rng.choice([10, 60, 100]))
+    for flag, prob in (("amp", .5), ("tmvp", .4), ("weighted_pred", .3), ("constrained_intra_pred", .25), ("cu_qp_delta", .3),
+                       ("transform_skip", .4), ("transquant_bypass", .3), ("sign_data_hiding", .4), ("cabac_init_present", .3),
+                       ("deblocking_override", .3), ("strong_intra_smoothing", .5)):
+        kw[flag] = int(rng.random() < prob)
+    kw["sao"] = int(rng.random() < 0.8)
+    kw["scaling_list"] = rng.choice([0, 0, 1, 2])
+    if cf == 1 and rng.random() < 0.3:
+        kw["pcm"] = 1
+    if rng.random() < 0.35:
+        kw["n_slices"] = rng.choice([2, 3, 5])
+        kw["lf_across_slices"] = rng.choice([0, 1])
+    r = rng.random()
+    if r < 0.25:
+        kw.update(tile_cols=rng.choice([1, 2, 3]), tile_rows=rng.choice([1, 2, 3]), lf_across_tiles=rng.choice([0, 1]))
+    elif r < 0.4:
+        kw["wpp"] = 1
+    if rng.random() < 0.3:
+        kw.update(tskip_rotation=rng.choice([0, 1]), tskip_context=rng.choice([0, 1]), implicit_rdpcm=rng.choice([0, 1]), explicit_rdpcm=rng.choice([0, 1]),
+                  intra_smoothing_disabled=rng.choice([0, 1]), log2_max_tskip_size=rng.choice([0, 3, 5]))
+        if not kw.get("wpp"):
+            kw["persistent_rice"] = rng.choice([0, 1])
+    if cf == 3 and rng.random() < 0.5:
+        kw["cross_component_pred"] = 1
+    if kw["gop"] == 3:
+        kw["n_refs"] = max(kw["n_refs"], 2)
+        kw["n_pictures"] = rng.choice([5, 6, 9])
+    if rng.random() < 0.2:
+        kw["idr_period"] = rng.choice([2, 3, 5])
+    if cf == 1 and rng.random() < 0.15:
+        kw.update(conf_win_left=2 * rng.randint(0, 4), conf_win_right=2 * rng.randint(0, 4), conf_win_top=2 * rng.randint(0, 4), conf_win_bottom=2 * rng.randint(0, 4))
+    if rng.random() < 0.15:
+        kw["mvd_range"] = rng.choice([8, 600, 4000])
+    return 8 * rng.randint(2, 40), 8 * rng.randint(2, 30), rng.randint(1, 10 ** 6), kw
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = refused = 0
+    for i in range(count):
+        w, h, seed, kw = draw(rng)
+        try:
+            data, _ = streamgen.write_stream(w, h, seed, **kw)
+        except ValueError:
+            refused += 1
+            continue
+        try:
+            want = refdec.decode(data)
+            got = T.decode_through_hooks(data)
+            assert len(want) == len(got) == kw["n_pictures"], (len(want), len(got))
+            if any(k.startswith("conf_win") for k in kw):                 # the checker's pictures are the coded ones: crop like the output
+                l, r, t, b = (kw.get("conf_win_" + k, 0) for k in ("left", "right", "top", "bottom"))
+                hs, vs = (1, 1) if kw["chroma_format_idc"] == 1 else (0, 0)
+                got = [[pl[(t >> (vs if c else 0)):pl.shape[0] - (b >> (vs if c else 0)), (l >> (hs if c else 0)):pl.shape[1] - (r >> (hs if c else 0))]
+                        for c, pl in enumerate(p)] for p in got]
+            for k in range(len(want)):
+                for c in range(3):
+                    assert np.array_equal(want[k][c], got[k][c]), ("picture", k, "plane", c)
+        except (AssertionError, RuntimeError) as exc:
+            bad += 1
+            print("FAIL", w, h, seed, kw, str(exc)[:120], flush=True)
+    print(f"{count} streams, {refused} refused by the writer, {bad} differ")
+
+
+if __name__ == "__main__":
+    main()

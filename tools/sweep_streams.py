@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random sweep of the stream writer's parameter space through the reference decoder (container only: needs oracle/_ref):
 every stream is decoded by the unmodified reference and by the hooked reference + CPU checker; any difference is printed with
-the parameters that reproduce it.  usage: sweep_streams.py [count] [seed]"""
+the parameters that reproduce it.  usage: sweep_streams.py [count] [seed]   |   sweep_streams.py --harness [count] [seed]  (GPU box: engine vs reference)"""
 import os
 import random
 import sys
@@ -57,7 +57,37 @@ def draw(rng):
     return 8 * rng.randint(2, 40), 8 * rng.randint(2, 30), rng.randint(1, 10 ** 6), kw
 
 
+def harness_sweep(count, seed):
+    """the same sweep with the ENGINE on the other side (GPU box; oracle/_ref travels there): ohevc_dec -o against the reference's output"""
+    import subprocess
+    import tempfile
+    rng = random.Random(seed)
+    harness, hooked = os.path.join(ROOT, "openhevc_amd", "ohevc_dec"), os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hooked.so")
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for i in range(count):
+            w, h, s, kw = draw(rng)
+            data, _ = streamgen.write_stream(w, h, s, **kw)
+            pics = refdec.decode(data)
+            open(os.path.join(tmp, "s.bin"), "wb").write(data)
+            for old in os.listdir(tmp):
+                if old.startswith("o_"):
+                    os.unlink(os.path.join(tmp, old))
+            r = subprocess.run([harness, "-i", os.path.join(tmp, "s.bin"), "-F", hooked, "-c", "-o", os.path.join(tmp, "o.yuv")], capture_output=True, text=True, timeout=600)
+            ow, oh = pics[0][0].shape[1], pics[0][0].shape[0]
+            name = os.path.join(tmp, f"o_{ow}x{oh}.yuv")
+            ok = r.returncode == 0 and os.path.exists(name) and open(name, "rb").read() == b"".join(np.ascontiguousarray(pl).tobytes() for p in pics for pl in p)
+            if not ok:
+                bad += 1
+                print("FAIL", w, h, s, kw, r.returncode, (r.stdout[-300:] + r.stderr[-300:]).replace("\n", " | "), flush=True)
+            if i % 50 == 49:
+                print(f"{i + 1} streams, {bad} differ", flush=True)
+    print(f"{count} streams through the harness, {bad} differ")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--harness":
+        return harness_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = refused = 0

@@ -29,6 +29,9 @@ CASES = [
     # residual is added there (cross_kernel) — the links come from the hooked decoder's shim
     ("ccp444_8", 264, 200, 56, dict(n_pictures=3, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1, transquant_bypass=1)),
     ("sdh8_lists", 264, 200, 58, dict(n_pictures=3, gop=2, sign_data_hiding=1, scaling_list=2, transform_skip=1, cbf_pct=80)),
+    # range-extension tools with scaling lists: skip blocks up to 32x32 stay flat (hevc_cabac.c:1485), the 4x4 intra rotation moves to the GPU with the levels
+    ("rext_tools_lists10", 216, 184, 59, dict(n_pictures=3, gop=2, bit_depth=10, scaling_list=2, transform_skip=1, tskip_rotation=1, tskip_context=1,
+                                              implicit_rdpcm=1, explicit_rdpcm=1, log2_max_tskip_size=5, tskip_pct=50, sign_data_hiding=1, intra_pct=40)),
     ("ccp444_10_lists_intra", 200, 136, 57, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, scaling_list=2, qp=24)),
 ]
 OH_TUF_SPARSE, OH_NO_COEFF, OH_FLAT_MATRIX = 16, 0xFFFFFFFF, 0xFF
@@ -75,11 +78,13 @@ def sparse_work_lists(case):
             p += 2 + n
             if bypass:
                 continue
-            matrix = 3 * (1 - intra) + c_idx if have_lists else OH_FLAT_MATRIX
+            matrix = 3 * (1 - intra) + c_idx if have_lists and not (tskip and log2 > 2) else OH_FLAT_MATRIX     # hevc_cabac.c:1485: skip blocks > 4x4 stay flat
             tu_sparse[i] = len(words)
             words.append(n | qp << 16 | matrix << 24)
             words.extend(int(v) for v in pairs)
             tu["flags"][i] |= OH_TUF_SPARSE
+            if kw.get("tskip_rotation") and tskip and log2 == 2 and intra:
+                tu["flags"][i] |= 8                              # OH_TUF_ROTATE: the host's swap of a 4x4 intra skip block (hevc_cabac.c:1877-1884) moves to the GPU with the levels
             nn = 1 << (2 * log2)
             coeffs[int(t["coeff_off"]):int(t["coeff_off"]) + nn] = 0
             n_sparse_blocks += 1

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random sweep of the stream writer's parameter space through the reference decoder (container only: needs oracle/_ref):
 every stream is decoded by the unmodified reference and by the hooked reference + CPU checker; any difference is printed with
-the parameters that reproduce it.  usage: sweep_streams.py [count] [seed]   |   sweep_streams.py --harness [count] [seed]  (GPU box: engine vs reference)"""
+the parameters that reproduce it.  usage: sweep_streams.py [count] [seed]   |   sweep_streams.py --harness [count] [seed]  (GPU box: engine vs reference)
+   |   sweep_streams.py --sparse | --sparse-engine [count] [seed]   (the sparse hand-over through the checker / the engine)"""
 import os
 import random
 import sys
@@ -85,7 +86,55 @@ def harness_sweep(count, seed):
     print(f"{count} streams through the harness, {bad} differ")
 
 
+def sparse_sweep(count, seed, engine):
+    """the SPARSE hand-over (levels de-quantised by the checker / the engine, tests/test_sparse_pin.py) over random streams"""
+    import ctypes as C
+    import test_sparse_pin as S
+    from openhevc_amd import frame as F
+    from test_streams import host_pic_array, oracle
+    rng = random.Random(seed)
+    eng = None
+    if engine:
+        from openhevc_amd.engine import Engine, remap_frame
+        eng = Engine(0)
+    bad = 0
+    for i in range(count):
+        w, h, s, kw = draw(rng)
+        kw["cu_qp_delta"] = 0                                   # the writer's level log carries the slice QP
+        if kw["gop"] == 3:
+            kw.update(gop=2, n_pictures=3)
+        kw = {k: v for k, v in kw.items() if not k.startswith("conf_win")}
+        try:
+            lists, want = S.sparse_work_lists(("sweep", w, h, s, kw))
+            pics = {}
+            for k, (a, cur, _) in enumerate(lists):
+                ff = F.FrameFromArrays(a)
+                f = ff.frame
+                for q in [cur] + [f.ref_pics[r] for r in range(F.OH_MAX_REFS) if f.ref_pics[r] >= 0]:
+                    if q not in pics:
+                        pics[q] = eng.pic_alloc(f.p) if eng else F.HostPic(f.p)
+                if eng:
+                    eng.frame_submit(remap_frame(f, pics))
+                    got = eng.pic_download(pics[cur], f.p)
+                else:
+                    assert oracle().oh_or_frame(C.byref(f), host_pic_array(pics)) == 0
+                    got = pics[cur]
+                for c in range(3):
+                    assert np.array_equal(got.visible(c), want[k][c]), ("picture", k, "plane", c)
+            if eng:
+                for q in pics.values():
+                    eng.pic_free(q)
+        except AssertionError as exc:
+            bad += 1
+            print("FAIL", w, h, s, kw, str(exc)[:160], flush=True)
+        if i % 50 == 49:
+            print(f"{i + 1} streams, {bad} differ", flush=True)
+    print(f"{count} streams in sparse form through the {'engine' if engine else 'checker'}, {bad} differ")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):
+        return sparse_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1, sys.argv[1] == "--sparse-engine")
     if len(sys.argv) > 1 and sys.argv[1] == "--harness":
         return harness_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100

@@ -53,7 +53,8 @@ typedef int (*fe_locate_fn)(const void *luma, int *x, int *y);     /* DPB slot (
 
 static void usage(const char *prog)
 {
-    printf("%s: -i <file> -F <front end> [-c] [-n] [-o <output file>] [-s <num>]\n", prog);
+    printf("%s: -i <file> -F <front end> [-b] [-c] [-n] [-o <output file>] [-s <num>]\n", prog);
+    printf("     -b : boundary strengths on the GPU (the front end hands over its motion field instead of finished grids)\n");
     printf("     -c : no check md5\n");
     printf("     -F <shared object of the host decoder with the recording table slots linked in>\n");
     printf("     -i <input file>\n");
@@ -76,13 +77,14 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
     const char *input = NULL, *front = NULL, *output = NULL;
-    int check_md5 = 1, num_frames = 0, nb_pthreads = 1, thread_type = 1;
+    int check_md5 = 1, num_frames = 0, nb_pthreads = 1, thread_type = 1, bs_on_gpu = 0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         if (a[0] != '-' || !a[1] || a[2]) { usage(argv[0]); return 2; }
         const int need = strchr("iFospf", a[1]) != NULL;
         if (need && i + 1 >= argc) { usage(argv[0]); return 2; }
         switch (a[1]) {
+        case 'b': bs_on_gpu = 1; break;
         case 'c': check_md5 = 0; break;
         case 'n': break;
         case 'i': input = argv[++i]; break;
@@ -128,6 +130,11 @@ int main(int argc, char **argv)
     if (!fe_init || !fe_start || !fe_decode || !fe_close || !fe_finish || !fe_output || !fe_locate) {
         fprintf(stderr, "%s does not export libOpenHevcInit / StartDecoder / Decode / GetOutput / Close / ref_hooked_finish / ref_hooked_locate\n", front);
         return 1;
+    }
+    if (bs_on_gpu) {
+        void (*fe_bs)(int) = (void (*)(int))dlsym(so, "ref_hooked_bs_from_motion");
+        if (!fe_bs) { fprintf(stderr, "%s cannot hand over its motion field (no ref_hooked_bs_from_motion)\n", front); return 1; }
+        fe_bs(1);                                             /* work lists with OhFrame.bs_in: bs_kernel derives both grids */
     }
     void *h = fe_init(nb_pthreads, thread_type);
     if (!h || fe_start(h) != 1) { fprintf(stderr, "could not open OpenHevc\n"); return 1; }

@@ -44,6 +44,10 @@ static struct {
     OhScalingList scaling;
 } H;
 
+static int g_bs_from_motion;          /* ref_hooked_bs_from_motion(): the work lists carry the boundary-strength INPUTS */
+static uint8_t *g_bs_call;            /* per min-TB cell: log2 size ff_hevc_deblocking_boundary_strengths was called with there, 0 = never */
+static size_t g_bs_call_n;
+
 /* INTEGRATION.md §3 */
 static void intra_from_hevc(struct HEVCContext *s, int x0, int y0, int c_idx, int log2_size, int *mode, int *avail)
 {
@@ -101,6 +105,11 @@ static int frame_rps_and_bind(HEVCContext *s)
     int32_t ids[OH_MAX_REFS];
     for (int i = 0; i < H.n_refs; i++) ids[i] = H.ref_ids[i];
     oh_rec_begin(H.rec, H.cur_id, ids, H.n_refs);
+    if (g_bs_from_motion) {
+        const size_t n_tb = (size_t)sps->min_tb_width * sps->min_tb_height;
+        if (g_bs_call_n != n_tb) { free(g_bs_call); g_bs_call = (uint8_t *)malloc(n_tb); g_bs_call_n = g_bs_call ? n_tb : 0; }
+        if (g_bs_call) memset(g_bs_call, 0, n_tb);
+    }
     oh_tables_set_intra_accessor(intra_from_hevc);
     oh_tables_bind(H.rec, s->frame->data, s->frame->linesize);
     for (int i = 0; i < H.n_refs; i++)
@@ -127,8 +136,17 @@ __attribute__((visibility("default"))) const OhFrame *ref_hooked_finish(int *cur
     }
     *cur_id = H.cur_id; *poc = s->poc;
     const int n_ctb = sps->ctb_width * sps->ctb_height, n_pu = sps->min_pu_width * sps->min_pu_height;
-    memcpy(oh_rec_vertical_bs(H.rec), s->vertical_bs, (size_t)s->bs_width * s->bs_height);
-    memcpy(oh_rec_horizontal_bs(H.rec), s->horizontal_bs, (size_t)s->bs_width * s->bs_height);
+    if (g_bs_from_motion && g_bs_call) {
+        /* the grids stay zero: nothing can fall back on them */
+        _Static_assert(sizeof(MvField) == sizeof(OhMvField), "OhMvField mirrors MvField as compiled");
+        OhBsInputs *bi = oh_rec_bs_maps(H.rec);
+        memcpy((void *)bi->mvf, s->ref->tab_mvf, (size_t)sps->min_pu_width * sps->min_pu_height * sizeof(MvField));
+        memcpy((void *)bi->cbf_luma, s->cbf_luma, (size_t)sps->min_tb_width * sps->min_tb_height);
+        memcpy((void *)bi->call_log2, g_bs_call, g_bs_call_n);
+    } else {
+        memcpy(oh_rec_vertical_bs(H.rec), s->vertical_bs, (size_t)s->bs_width * s->bs_height);
+        memcpy(oh_rec_horizontal_bs(H.rec), s->horizontal_bs, (size_t)s->bs_width * s->bs_height);
+    }
     memcpy(oh_rec_qp_y_tab(H.rec), s->qp_y_tab, (size_t)(sps->min_cb_width * sps->min_cb_height));
     memcpy(oh_rec_is_pcm(H.rec), s->is_pcm, (size_t)n_pu);
     if (s->pps->constrained_intra_pred_flag)
@@ -206,6 +224,20 @@ static int hooked_log2_res_scale_abs(HEVCContext *s, int idx)
     return 0;
 }
 #define ff_hevc_log2_res_scale_abs(s, idx) hooked_log2_res_scale_abs(s, idx)
+
+/* SURVEY §8 f2 on real streams: with ref_hooked_bs_from_motion(1) the work lists carry what ff_hevc_deblocking_boundary_strengths
+ * READS (motion field, cbf_luma, where it was called and for which block size) instead of the grids it writes, and the engine /
+ * the checker derive the boundary strengths.  The call sites (hevc.c:1578, 1607, 2400, 2484) go through this wrapper. */
+static void hooked_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_size)
+{
+    if (g_bs_from_motion && g_bs_call) {
+        const int l = s->sps->log2_min_tb_size;
+        g_bs_call[(size_t)(y0 >> l) * s->sps->min_tb_width + (x0 >> l)] = (uint8_t)log2_size;
+    }
+    ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_size);
+}
+#define ff_hevc_deblocking_boundary_strengths(s, x, y, l) hooked_boundary_strengths(s, x, y, l)
+__attribute__((visibility("default"))) void ref_hooked_bs_from_motion(int on) { g_bs_from_motion = on; }
 
 #define ff_hevc_dsp_init(c, bd)   do { ff_hevc_dsp_init(c, bd);  ff_hevcdsp_init_hip((void *)(c), bd); } while (0)
 #define ff_hevc_pred_init(c, bd)  do { ff_hevc_pred_init(c, bd); ff_hevcpred_init_hip((void *)(c), bd); } while (0)

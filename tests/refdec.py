@@ -230,11 +230,12 @@ def hooked_lib():
     return _hlib
 
 
-def record_work_lists(data, on_picture, threads=1, thread_type=1):
+def record_work_lists(data, on_picture, threads=1, thread_type=1, bs_from_motion=False):
     """Decodes the stream with the reference's own decoder whose DSP tables hold this repository's RECORDING slots: every access
     unit yields the work list of its picture.  on_picture(frame, cur_id, poc) is called while the recorder's arrays are valid
     (until the next access unit); cur_id / frame.ref_pics are indices into the reference's DPB."""
     L = hooked_lib()
+    L.ref_hooked_bs_from_motion(int(bs_from_motion))          # True: OhFrame.bs_in (motion field, cbf_luma, call map) instead of finished BS grids
     h = C.c_void_p(L.libOpenHevcInit(threads, thread_type))  # thread_type 2: the reference's slice / wavefront threads call the recording slots
     assert L.libOpenHevcStartDecoder(h) == 1
     n = 0
@@ -249,4 +250,5 @@ def record_work_lists(data, on_picture, threads=1, thread_type=1):
             on_picture(f.contents, cur.value, poc.value)
             n += 1
     L.libOpenHevcClose(h)
+    L.ref_hooked_bs_from_motion(0)
     return n

@@ -123,6 +123,9 @@ def test_harness_decodes_streams_and_the_gpu_md5_matches_the_sei(case, tmp_path)
         assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1
         r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-p", "4", "-f", "1"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 2                             # frame threads are not what the recording slots support
+    # -b: the front end hands over its motion field, the engine derives the boundary strengths (bs_kernel): same verdict
+    r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-b"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1
     # -c: no check, -s: stop early
     r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-c", "-s", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MD5" not in r.stdout and r.stdout.strip().splitlines()[-1].startswith("frame= 2 ")

@@ -95,7 +95,7 @@ def test_writer_syntax_is_what_the_reference_parses(case):
     assert len(wrote) > 20
 
 
-def decode_through_hooks(data, threads=1, thread_type=1):
+def decode_through_hooks(data, threads=1, thread_type=1, bs_from_motion=False):
     """pictures reconstructed by the CHECKER from the work lists the hooked reference decoder records, in OUTPUT order
     (ascending POC inside an IDR period — the order the plain decoder hands its pictures out in)"""
     pics, got, keys = {}, [], []
@@ -107,7 +107,7 @@ def decode_through_hooks(data, threads=1, thread_type=1):
         assert oracle().oh_or_frame(C.byref(f), host_pic_array(pics)) == 0
         got.append([pics[cur].visible(c).copy() for c in range(3)])
         keys.append((sum(1 for _, q in keys if q == 0) + (poc == 0), poc))       # POC 0 only at IDR pictures in the written streams
-    refdec.record_work_lists(data, on_picture, threads, thread_type)
+    refdec.record_work_lists(data, on_picture, threads, thread_type, bs_from_motion)
     return [got[k] for k in sorted(range(len(got)), key=lambda k: keys[k])]
 
 
@@ -118,6 +118,21 @@ def test_hooked_ctu_loop_reproduces_the_reference_decoder(case):
     want = refdec.decode(data)
     got = decode_through_hooks(data)
     assert len(got) == len(want) == kw["n_pictures"]
+    for k in range(len(want)):
+        for c in range(3):
+            assert np.array_equal(want[k][c], got[k][c]), (case[0], "picture", k, "plane", c)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_boundary_strengths_from_the_decoders_motion_field(case):
+    """SURVEY §8 f2 on real streams: the hooked decoder hands over what ff_hevc_deblocking_boundary_strengths READS — its motion
+    field, cbf_luma and the (position, block size) of every call (hevc.c:1578, 1607, 2400, 2484) — instead of the grids it writes
+    (left zero); the checker derives the boundary strengths and must still reproduce the plain decoder's pictures"""
+    _, w, h, seed, kw = case
+    data, _ = streamgen.write_stream(w, h, seed, **kw)
+    want = refdec.decode(data)
+    got = decode_through_hooks(data, bs_from_motion=True)
+    assert len(got) == len(want)
     for k in range(len(want)):
         for c in range(3):
             assert np.array_equal(want[k][c], got[k][c]), (case[0], "picture", k, "plane", c)

@@ -58,7 +58,7 @@ def draw(rng):
     return 8 * rng.randint(2, 40), 8 * rng.randint(2, 30), rng.randint(1, 10 ** 6), kw
 
 
-def harness_sweep(count, seed):
+def harness_sweep(count, seed, extra=()):
     """the same sweep with the ENGINE on the other side (GPU box; oracle/_ref travels there): ohevc_dec -o against the reference's output"""
     import subprocess
     import tempfile
@@ -74,7 +74,8 @@ def harness_sweep(count, seed):
             for old in os.listdir(tmp):
                 if old.startswith("o_"):
                     os.unlink(os.path.join(tmp, old))
-            r = subprocess.run([harness, "-i", os.path.join(tmp, "s.bin"), "-F", hooked, "-c", "-o", os.path.join(tmp, "o.yuv")], capture_output=True, text=True, timeout=600)
+            r = subprocess.run([harness, "-i", os.path.join(tmp, "s.bin"), "-F", hooked, "-c", "-o", os.path.join(tmp, "o.yuv")] + list(extra),
+                               capture_output=True, text=True, timeout=600)
             ow, oh = pics[0][0].shape[1], pics[0][0].shape[0]
             name = os.path.join(tmp, f"o_{ow}x{oh}.yuv")
             ok = r.returncode == 0 and os.path.exists(name) and open(name, "rb").read() == b"".join(np.ascontiguousarray(pl).tobytes() for p in pics for pl in p)
@@ -135,8 +136,9 @@ def sparse_sweep(count, seed, engine):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):
         return sparse_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1, sys.argv[1] == "--sparse-engine")
-    if len(sys.argv) > 1 and sys.argv[1] == "--harness":
-        return harness_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    if len(sys.argv) > 1 and sys.argv[1] in ("--harness", "--harness-bs"):          # -bs: boundary strengths derived on the GPU (ohevc_dec -b)
+        return harness_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1,
+                             ("-b",) if sys.argv[1] == "--harness-bs" else ())
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = refused = 0

@@ -211,7 +211,7 @@ typedef struct OhMvField {
 typedef struct OhBsInputs {
     const OhMvField *mvf;         /* min_pu_width x min_pu_height: s->ref->tab_mvf                                                  */
     const uint8_t   *cbf_luma;    /* min_tb_width x min_tb_height: s->cbf_luma (hevc.c:1566-1575)                                   */
-    const uint8_t   *call_log2;   /* min_tb_width x min_tb_height: log2 size of the block the function was called for at the cell
+    const uint8_t   *call_log2;   /* min_tb_width x min_tb_height, EVERY cell a call's block covers: log2 size of the block the function was called for
                                      (the transform unit, hevc.c:1578, or the whole coding block, :1607 :2400 :2484); 0 = never
                                      called there (slice_deblocking_filter_disabled_flag): both grids stay 0                        */
     const uint8_t   *ctb_flags;   /* ctb_width x ctb_height: OH_BSF_* of the CTB's slice / position (hevc.c:2636-2637)              */

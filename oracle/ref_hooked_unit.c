@@ -230,9 +230,11 @@ static int hooked_log2_res_scale_abs(HEVCContext *s, int idx)
  * the checker derive the boundary strengths.  The call sites (hevc.c:1578, 1607, 2400, 2484) go through this wrapper. */
 static void hooked_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_size)
 {
-    if (g_bs_from_motion && g_bs_call) {
-        const int l = s->sps->log2_min_tb_size;
-        g_bs_call[(size_t)(y0 >> l) * s->sps->min_tb_width + (x0 >> l)] = (uint8_t)log2_size;
+    if (g_bs_from_motion && g_bs_call) {                   /* every min-TB cell of the block carries its size (OhBsInputs.call_log2) */
+        const int l = s->sps->log2_min_tb_size, n = 1 << (log2_size - l), w = s->sps->min_tb_width, h = s->sps->min_tb_height;
+        for (int j = y0 >> l; j < (y0 >> l) + n && j < h; j++)
+            for (int i = x0 >> l; i < (x0 >> l) + n && i < w; i++)
+                g_bs_call[(size_t)j * w + i] = (uint8_t)log2_size;
     }
     ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_size);
 }

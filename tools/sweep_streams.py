@@ -58,7 +58,7 @@ def draw(rng):
     return 8 * rng.randint(2, 40), 8 * rng.randint(2, 30), rng.randint(1, 10 ** 6), kw
 
 
-def harness_sweep(count, seed, extra=()):
+def harness_sweep(count, seed, extra=(), min_ctb=4):
     """the same sweep with the ENGINE on the other side (GPU box; oracle/_ref travels there): ohevc_dec -o against the reference's output"""
     import subprocess
     import tempfile
@@ -68,6 +68,8 @@ def harness_sweep(count, seed, extra=()):
     with tempfile.TemporaryDirectory() as tmp:
         for i in range(count):
             w, h, s, kw = draw(rng)
+            if kw["log2_ctb_size"] < min_ctb:
+                kw["log2_ctb_size"] = min_ctb
             data, _ = streamgen.write_stream(w, h, s, **kw)
             pics = refdec.decode(data)
             open(os.path.join(tmp, "s.bin"), "wb").write(data)
@@ -136,9 +138,13 @@ def sparse_sweep(count, seed, engine):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):
         return sparse_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1, sys.argv[1] == "--sparse-engine")
-    if len(sys.argv) > 1 and sys.argv[1] in ("--harness", "--harness-bs"):          # -bs: boundary strengths derived on the GPU (ohevc_dec -b)
+    if len(sys.argv) > 1 and sys.argv[1] in ("--harness", "--harness-bs", "--harness-threads"):
+        # -bs: boundary strengths derived on the GPU (ohevc_dec -b); -threads: the front end on 4 slice / wavefront threads (32x32 CTBs and
+        # larger: with 16x16 CTBs the reference's own output depends on its thread count)
+        mode = sys.argv[1]
         return harness_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1,
-                             ("-b",) if sys.argv[1] == "--harness-bs" else ())
+                             ("-b",) if mode == "--harness-bs" else ("-p", "4", "-f", "2") if mode == "--harness-threads" else (),
+                             5 if mode == "--harness-threads" else 4)
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = refused = 0

@@ -71,7 +71,9 @@ def harness_sweep(count, seed, extra=(), min_ctb=4):
             if kw["log2_ctb_size"] < min_ctb:
                 kw["log2_ctb_size"] = min_ctb
             data, _ = streamgen.write_stream(w, h, s, **kw)
-            pics = refdec.decode(data)
+            # the reference's own output depends on its threading in places (tiles: its filters then run at the end of the picture in
+            # raster order, hevc.c:2967-3003): the unmodified decoder runs with the same threads as the front end
+            pics = refdec.decode(data, threads=4, thread_type=2) if "-p" in extra else refdec.decode(data)
             open(os.path.join(tmp, "s.bin"), "wb").write(data)
             for old in os.listdir(tmp):
                 if old.startswith("o_"):
@@ -135,7 +137,36 @@ def sparse_sweep(count, seed, engine):
     print(f"{count} streams in sparse form through the {'engine' if engine else 'checker'}, {bad} differ")
 
 
+def crop(got, kw):
+    """the checker's pictures are the coded ones: crop like the decoder's output"""
+    if not any(k.startswith("conf_win") for k in kw):
+        return got
+    l, r, t, b = (kw.get("conf_win_" + k, 0) for k in ("left", "right", "top", "bottom"))
+    hs, vs = (1, 1) if kw["chroma_format_idc"] == 1 else (0, 0)
+    return [[pl[(t >> (vs if c else 0)):pl.shape[0] - (b >> (vs if c else 0)), (l >> (hs if c else 0)):pl.shape[1] - (r >> (hs if c else 0))]
+             for c, pl in enumerate(p)] for p in got]
+
+
+def threads_sweep(count, seed):
+    """hooked front end on 4 slice / wavefront threads + checker against the unmodified reference on the same threads (32x32 CTBs and larger)"""
+    rng = random.Random(seed)
+    bad = dep = 0
+    for i in range(count):
+        w, h, s, kw = draw(rng)
+        kw["log2_ctb_size"] = max(kw["log2_ctb_size"], 5)
+        data, _ = streamgen.write_stream(w, h, s, **kw)
+        one, ref = refdec.decode(data), refdec.decode(data, threads=4, thread_type=2)
+        dep += not all(np.array_equal(one[k][c], ref[k][c]) for k in range(len(ref)) for c in range(3))
+        got = crop(T.decode_through_hooks(data, 4, 2), kw)
+        if not (len(got) == len(ref) and all(np.array_equal(ref[k][c], got[k][c]) for k in range(len(ref)) for c in range(3))):
+            bad += 1
+            print("FAIL", w, h, s, kw, flush=True)
+    print(f"{count} streams on 4 front-end threads: {bad} differ from the reference on 4 threads; the reference's own 1-thread output differs from its 4-thread output on {dep}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--threads":
+        return threads_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):
         return sparse_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1, sys.argv[1] == "--sparse-engine")
     if len(sys.argv) > 1 and sys.argv[1] in ("--harness", "--harness-bs", "--harness-threads"):
@@ -159,11 +190,7 @@ def main():
             want = refdec.decode(data)
             got = T.decode_through_hooks(data)
             assert len(want) == len(got) == kw["n_pictures"], (len(want), len(got))
-            if any(k.startswith("conf_win") for k in kw):                 # the checker's pictures are the coded ones: crop like the output
-                l, r, t, b = (kw.get("conf_win_" + k, 0) for k in ("left", "right", "top", "bottom"))
-                hs, vs = (1, 1) if kw["chroma_format_idc"] == 1 else (0, 0)
-                got = [[pl[(t >> (vs if c else 0)):pl.shape[0] - (b >> (vs if c else 0)), (l >> (hs if c else 0)):pl.shape[1] - (r >> (hs if c else 0))]
-                        for c, pl in enumerate(p)] for p in got]
+            got = crop(got, kw)
             for k in range(len(want)):
                 for c in range(3):
                     assert np.array_equal(want[k][c], got[k][c]), ("picture", k, "plane", c)

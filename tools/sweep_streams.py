@@ -16,6 +16,9 @@ import streamgen  # noqa: E402
 import test_streams as T  # noqa: E402
 
 
+BIG = False
+
+
 def draw(rng):
     lc = rng.choice([4, 5, 6])
     cf = rng.choice([1, 1, 2, 3])
@@ -55,6 +58,9 @@ def draw(rng):
         kw.update(conf_win_left=2 * rng.randint(0, 4), conf_win_right=2 * rng.randint(0, 4), conf_win_top=2 * rng.randint(0, 4), conf_win_bottom=2 * rng.randint(0, 4))
     if rng.random() < 0.15:
         kw["mvd_range"] = rng.choice([8, 600, 4000])
+    if BIG:                                                     # --big: pictures up to 1920 x 1088 (many workgroups per pass, the CTU-row intra kernel)
+        kw["n_pictures"] = min(kw["n_pictures"], 3) if kw["gop"] != 3 else 5
+        return 8 * rng.randint(40, 240), 8 * rng.randint(30, 136), rng.randint(1, 10 ** 6), kw
     return 8 * rng.randint(2, 40), 8 * rng.randint(2, 30), rng.randint(1, 10 ** 6), kw
 
 
@@ -165,6 +171,10 @@ def threads_sweep(count, seed):
 
 
 def main():
+    global BIG
+    if "--big" in sys.argv:
+        BIG = True
+        sys.argv.remove("--big")
     if len(sys.argv) > 1 and sys.argv[1] == "--threads":
         return threads_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):

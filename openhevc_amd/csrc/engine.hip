@@ -1162,6 +1162,18 @@ static int read_summary(OhEngine *e, OhDevFrame *df, int index)
 /* Execute n mutually independent pictures: every pass is one launch over all of them (chunks of
  * OH_MAX_BATCH).  Nothing orders the pictures of a batch against each other, so none of them may be a
  * reference of another one. */
+/* the CTUs' residual spans staged in LDS, or every block fetching its own from the pool one sub-level ahead (intra.hip: slots_prepare)?
+ * Staging costs ~11 KB of LDS per workgroup in a launch that holds one all-intra CTU, i.e. workgroups per CU (OHEVC_INTRA_RES_LDS=0 / 1
+ * forces one way: experiments) */
+static bool res_in_lds(const OhEngine *e, uint64_t workgroups)
+{
+    static const char *env = getenv("OHEVC_INTRA_RES_LDS");
+    if (env) return atoi(env) != 0;
+    /* a launch the chip holds at once is latency-bound: stage (a 4K I picture alone 6.6 ms against 7.0); a launch of many more
+     * workgroups than fit runs at workgroups-per-CU x latency: keep the LDS small (4-stream bench: intra pass -5 %) */
+    return workgroups <= 5ull * (uint64_t)e->n_cu;
+}
+
 extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
 {
     if (!e || n < 0 || (n && !dfs))
@@ -1312,12 +1324,12 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             }
             if (nr) {
                 OhIntraLaunch IL;
-                IL.staged = staged; IL.level = 0; IL.waves = 8; IL.phases = 2;
+                IL.staged = staged && res_in_lds(e, (uint64_t)nr * oh_ctb_height(p)); IL.level = 0; IL.waves = 8; IL.phases = 2;
                 size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
                 IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
                 IL.off_sub = (uint32_t)off;   off += ((size_t)max_sub + 1) * sizeof(uint32_t);
                 IL.off_small = (uint32_t)off; off = align_up(off + (size_t)max_sub * sizeof(uint32_t), 16);
-                IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)(staged ? max_res : 0) * sizeof(int16_t), 16);
+                IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)(IL.staged ? max_res : 0) * sizeof(int16_t), 16);
                 IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
                 IL.lds_bytes = (uint32_t)off;
                 hipEvent_t a = nullptr, b = nullptr;
@@ -1357,7 +1369,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             if (!ns)
                 continue;                                  /* every picture that has this level runs as rows */
             OhIntraLaunch IL;
-            IL.staged = staged;
+            IL.staged = staged && res_in_lds(e, (uint64_t)max_ctu * ns);
             IL.level = (uint32_t)l;
             /* waves per CTU: as many as blocks run side by side in a sub-level (more only hold LDS and wave slots) */
             const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;
@@ -1374,7 +1386,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
             IL.off_sub = (uint32_t)off;   off += ((size_t)max_sub + 1) * sizeof(uint32_t);
             IL.off_small = (uint32_t)off; off = align_up(off + (size_t)max_sub * sizeof(uint32_t), 16);
-            IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)max_res * sizeof(int16_t), 16);
+            IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)(IL.staged ? max_res : 0) * sizeof(int16_t), 16);
             IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
             IL.lds_bytes = (uint32_t)off;
             hipEvent_t a = nullptr, b = nullptr;

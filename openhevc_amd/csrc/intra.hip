@@ -371,8 +371,9 @@ struct SlotState {                                           /* per lane, carrie
     int bits;                                                /* SS_* | cls << 8 | log2 << 12 | fact << 16 */
 };
 
+template <bool STAGED>
 static __device__ __forceinline__ void slots_prepare(SlotState &st, const DevIntra *__restrict__ items, const uint32_t first, const int count,
-                                                     const int16_t *__restrict__ res_lds_base, const int lane)
+                                                     const int16_t *__restrict__ res_lds_base, const GLOBAL int16_t *__restrict__ res_pool, const int lane)
 {
     /* straight-line code: every choice is a select (the compiler would turn if/else into exec-mask branches, and
      * this runs beside the dependent chain of the sub-level before) */
@@ -395,11 +396,19 @@ static __device__ __forceinline__ void slots_prepare(SlotState &st, const DevInt
     const bool is_h = cls == OH_IC_ANG_H || cls == OH_IC_PURE_H;
     const int o = (4 * sl) >> log2, m0 = (4 * sl) & (n - 1);
     const bool has_res = res_off != OH_NO_COEFF;
-    {   /* the line's residual: unconditional loads (offset 0 of the staged span when the block has none; SS_RES guards the use) */
-        const int16_t *__restrict__ rp = res_lds_base + (has_res ? res_lds : 0u) + (is_h ? (m0 << log2) + o : 4 * sl);
-        const int step = is_h ? n : 1;
+    {   /* the line's residual: unconditional loads (offset 0 of the span / the pool when the block has none; SS_RES guards the use).
+         * Not STAGED: straight from the residual pool in HBM — this runs a sub-level ahead of the chain that consumes the values, so
+         * the round trip is hidden, and the launch needs no LDS for the CTU's residual span (more workgroups per CU) */
+        const int line = is_h ? (m0 << log2) + o : 4 * sl, step = is_h ? n : 1;
+        if (STAGED) {
+            const int16_t *__restrict__ rp = res_lds_base + (has_res ? res_lds : 0u) + line;
 #pragma unroll
-        for (int j = 0; j < 4; j++) st.rv[j] = rp[j * step];
+            for (int j = 0; j < 4; j++) st.rv[j] = rp[j * step];
+        } else {
+            const GLOBAL int16_t *__restrict__ rp = res_pool + (has_res ? res_off : 0u) + line;
+#pragma unroll
+            for (int j = 0; j < 4; j++) st.rv[j] = rp[j * step];
+        }
     }
 
     /* gather (:164-183) + substitution (:251-286) as source addresses.  M[0] holds 1 << (bit_depth - 1) (kernel prologue).
@@ -537,7 +546,8 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
     DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
     uint32_t *__restrict__ sub = (uint32_t *)(smem + L.off_sub);
     uint32_t *__restrict__ small = (uint32_t *)(smem + L.off_small);              /* per sub-level: leading blocks that go four per wave */
-    int16_t *__restrict__ res_l = (int16_t *)(smem + L.off_res);                  /* the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
+    int16_t *__restrict__ res_l = (int16_t *)(smem + L.off_res);                  /* STAGED: the CTU's residual blocks (DevIntraCtu.res_lo/res_cnt) */
+    const GLOBAL int16_t *__restrict__ res_pool = G_CONST(int16_t, f->res);       /* else: every block fetches its own from the pool */
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x, nwaves = nthr >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                    /* wave-uniform: the phase bookkeeping derived from it lives in scalar registers */
     IntraLds &edges = *(IntraLds *)(smem + L.off_wave + wave * OH_INTRA_WAVE_LDS);
@@ -611,7 +621,7 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
     /* Sub-level s belongs to the waves of phase s % K (K = L.phases): while they finish s (the dependent chain), the
      * waves that finished s-1 prepare their first four-block pass of s-1+K (everything that needs no samples) and then
      * sit out the sub-levels in between.  Units of a sub-level: groups of up to four <=8x8 blocks (one 16-lane slot
-     * each), then the bigger blocks one per wave; the slot path needs the residual staged in LDS and has no
+     * each), then the bigger blocks one per wave; the slot path has no
      * constrained-intra variant. */
     const int K = (int)L.phases, ph = wave % K, wi = wave / K, nwk = nwaves / K;
     SlotState st;
@@ -620,11 +630,11 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
     auto prepare = [&](int s) {
         const uint32_t s0 = sub[s], s1 = sub[s + 1];
         b0 = s0;
-        ns = (STAGED && !CIP) ? min(small[s], s1 - s0) : 0u;
+        ns = !CIP ? min(small[s], s1 - s0) : 0u;
         nunits = ((ns + 3) >> 2) + (s1 - s0 - ns);
         ready = (uint32_t)wi < ((ns + 3) >> 2);
         if (ready)
-            slots_prepare(st, items, b0 + 4 * wi, (int)min(4u, ns - 4 * wi), res_l, lane);
+            slots_prepare<STAGED>(st, items, b0 + 4 * wi, (int)min(4u, ns - 4 * wi), res_l, res_pool, lane);
     };
     if (ph < n_sub) prepare(ph);
     for (int s = 0, sp = 0; s < n_sub; s++, sp = sp + 1 == K ? 0 : sp + 1) {      /* sp = s % K */
@@ -634,7 +644,7 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
             for (uint32_t u = wi; u < nunits; u += nwk) {
                 if (u < ngrp) {
                     if (!ready)
-                        slots_prepare(st, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), res_l, lane);
+                        slots_prepare<STAGED>(st, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), res_l, res_pool, lane);
                     ready = false;
                     slots_finish<PX>(st, bd, edges.E, M, lane, acc);
                 } else {

@@ -372,11 +372,12 @@ def main():
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.workload}.json")
         if os.path.exists(tpath):                          # rocprofv3 --pmc passes of this command, recorded under profiles/ (bench.py cannot profile itself)
-            with open(tpath) as fh:
-                for kname, rec in json.load(fh).items():
-                    if kname.startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0]):
-                        traffic, traffic_source = rec["hbm_bytes_per_launch_corrected"], os.path.relpath(tpath, ROOT)
-                        break
+            with open(tpath) as fh:                        # every instantiation of the kernel, weighted by its launches
+                recs = [rec for kname, rec in json.load(fh).items() if kname.startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0])]
+            n_l = sum(rec["launches"] for rec in recs)
+            if n_l:
+                traffic = round(sum(rec["hbm_bytes_per_launch_corrected"] * rec["launches"] for rec in recs) / n_l)
+                traffic_source = os.path.relpath(tpath, ROOT)
         # the committed rocprofv3 --kernel-trace --stats summary of this command, beside the live figure: the kernel's own duration
         # there is shorter than the event-to-event time above, which also holds the dispatch and the wait for the other streams' kernels
         trace_us, trace_source = None, None

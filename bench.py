@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
-    ap.add_argument("--chains", type=int, default=None, help="closed GOPs (steps) in flight per GPU (default: 96; 24 for the 8K workloads, whose pictures are 100-200 MB)")
+    ap.add_argument("--chains", type=int, default=None, help="closed GOPs (steps) in flight per GPU (default: 128 = batches of 32 pictures on each of the 4 streams; 24 for the 8K workloads, whose pictures are 100-200 MB)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
@@ -197,14 +197,14 @@ def main():
 
     params = F.pic_params(**WORKLOADS[args.workload])
     if args.chains is None:
-        args.chains = 96 if params.width * params.height <= 3840 * 2160 else 24
+        args.chains = 128 if params.width * params.height <= 3840 * 2160 else 24
     n_chains = max(1, args.chains)
     if args.scaling == "strong" and world > 1:
         n_chains = max(1, n_chains // world)               # the same pictures per step as one GPU decodes alone, split over the ranks
     # the chains' picture buffers (every rank keeps the reference pictures of all ranks, parallel.GroupStore) must fit the HBM
     # that is free now; a default that does not fit is cut (and said so) rather than left to die in the allocator
     half_bytes = F.half_layout(params)[0]
-    per_chain = (args.waves * 2 * world + max(args.tail, 1) * 2) * half_bytes
+    per_chain = (args.waves * (world + 1) + max(args.tail, 1) * 2) * half_bytes       # parallel.GroupStore: other ranks' pictures keep one half
     free_b, _total_b = torch.cuda.mem_get_info()
     chains_asked = n_chains
     if n_chains * per_chain > 0.85 * free_b:

@@ -223,7 +223,8 @@ def _exchange_grouped(chains, w, dist, exchange, comm):
     torch = gs.torch
     half = be0.final_half(pl0.waves[w].name)
     assert all(be.final_half(pl.waves[w].name) == half for pl, be, _ in chains), "the chains of a group finish a wave in the same half"
-    buf = gs.waves[w][half]                                # [world][n_chains][half_bytes], contiguous
+    assert half == gs.final_half, "the group's buffers were laid out for pictures that finish in the other half (SAO on / off)"
+    buf = gs.final[w]                                      # [world][n_chains][half_bytes], contiguous
     rank, world = pl0.rank, pl0.world
     send_to, recv_from = (list(r for r in range(world) if r != rank),) * 2 if exchange is None else exchange[w]
     on_dev = buf.is_cuda
@@ -375,17 +376,23 @@ def default_synth_knobs():
 
 class GroupStore:
     """The picture buffers of the chains that advance in LOCKSTEP on one stream, laid out for the exchange:
-         wave w : uint8 tensor [2 halves][world][n_chains][half_bytes]
-    so everything one rank contributes to a wave — its reference picture of EVERY chain — is one contiguous block per half: one
-    message per peer and wave (or one all-gather per wave) whatever the number of chains in flight (_exchange_grouped).
-         tail   : uint8 tensor [n_chains][n_tail][2][half_bytes]   (non-reference pictures, never exchanged)"""
+         wave w : final[w]   uint8 tensor [world][n_chains][half_bytes]   the FINISHED half of every rank's reference picture
+                  scratch[w] uint8 tensor [n_chains][half_bytes]          the other half of THIS rank's pictures (a picture is
+                                                                          reconstructed in half 0 and SAO writes half 1)
+    so everything one rank contributes to a wave — its reference picture of EVERY chain — is one contiguous block: one message per
+    peer and wave (or one all-gather per wave) whatever the number of chains in flight (_exchange_grouped); pictures of other ranks
+    are only ever read, they need no second half (at 8 ranks: 0.9 GB of wave buffers per 4K Main 10 chain instead of 1.6).
+         tail   : uint8 tensor [n_chains][n_tail][2][half_bytes]   (non-reference pictures, never exchanged)
+    final_half: which half a finished picture lives in — 1 with SAO (every picture of the streams carries SAO parameters), else 0."""
 
-    def __init__(self, torch, device, params, world, n_chains, n_waves, n_tail):
+    def __init__(self, torch, device, params, world, n_chains, n_waves, n_tail, final_half=None):
         from . import frame as F
         self.torch = torch
         self.half_bytes = F.half_layout(params)[0]
         self.n_chains = n_chains
-        self.waves = [torch.zeros((2, world, n_chains, self.half_bytes), dtype=torch.uint8, device=device) for _ in range(n_waves)]
+        self.final_half = (1 if params.sao_enabled else 0) if final_half is None else final_half
+        self.final = [torch.zeros((world, n_chains, self.half_bytes), dtype=torch.uint8, device=device) for _ in range(n_waves)]
+        self.scratch = [torch.zeros((n_chains, self.half_bytes), dtype=torch.uint8, device=device) for _ in range(n_waves)]
         self.tail = torch.zeros((n_chains, max(n_tail, 1), 2, self.half_bytes), dtype=torch.uint8, device=device)
 
 
@@ -399,11 +406,11 @@ class PictureStore:
         from . import frame as F
         self.half_bytes, self.strides, self.offsets = F.half_layout(params)
         self.params, self.plan = params, plan
-        self.group = None
+        self.group, self.n_waves = None, n_waves
         if group is not None:
-            self.group, k = group
-            self.waves = [t[:, :, k] for t in self.group.waves]
-            self.tail = self.group.tail[k]
+            self.group, self.k = group
+            self.waves = None                              # the group's buffers: GroupStore.final / .scratch
+            self.tail = self.group.tail[self.k]
             return
         self.waves = [torch.zeros((2, plan.world, self.half_bytes), dtype=torch.uint8, device=device) for _ in range(n_waves)]
         self.tail = torch.zeros((max(n_tail, 1), 2, self.half_bytes), dtype=torch.uint8, device=device)
@@ -412,11 +419,17 @@ class PictureStore:
         """(tensor of half 0, tensor of half 1) of a picture"""
         if name[0] == "ref":
             _, w, r = name
+            if self.group is not None:
+                fin = self.group.final[w][r][self.k]
+                if r != self.plan.rank:
+                    return fin, fin                        # another rank's picture: read only, one buffer
+                scr = self.group.scratch[w][self.k]
+                return (scr, fin) if self.group.final_half else (fin, scr)
             return self.waves[w][0][r], self.waves[w][1][r]
         return self.tail[name[1]][0], self.tail[name[1]][1]
 
     def names(self):
-        out = [("ref", w, r) for w in range(len(self.waves)) for r in range(self.plan.world)]
+        out = [("ref", w, r) for w in range(self.n_waves) for r in range(self.plan.world)]
         return out + [p.name for p in self.plan.tail]
 
 

@@ -43,7 +43,7 @@ typedef struct OhStreamParams {
     int32_t n_slices;                   /* slices per picture (>= 1), at random CTB addresses (whole tiles when tiles are on) */
     int32_t tile_cols, tile_rows;       /* > 1: uniformly spaced tiles */
     int32_t wpp;                        /* entropy_coding_sync_enabled_flag */
-    int32_t dependent_slices;           /* some slices become dependent slice segments */
+    int32_t dependent_slices;           /* dependent_slice_segments_enabled_flag: about half of the slices after the first become dependent segments */
     int32_t lf_across_slices, lf_across_tiles;    /* the two loop_filter_across_* flags */
     /* content knobs, per cent */
     int32_t split_pct, intra_pct, skip_pct, merge_pct, bi_pct, cbf_pct, pcm_pct, bypass_pct, tskip_pct, sao_pct;

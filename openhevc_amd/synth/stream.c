@@ -265,6 +265,7 @@ typedef struct W {
     int qp_delta_pending, cu_bypass;
     int cross_pf, res_scale;                           /* cross-component prediction of the chroma block being coded */
     int stat_coeff[4];                                 /* StatCoeff (9.3.3.11): reset with the contexts */
+    uint8_t wpp_ctx[N_CTX]; int have_wpp;              /* the context states after the second CTB of the last row that had two (wavefront synchronisation) */
     /* SAO parameters of the CTBs (for merge candidates we only need to know that they exist) */
 } W;
 
@@ -1204,13 +1205,24 @@ static void write_slice_data(W *w, Bits *data, int ts_first, int ts_end, uint32_
     const OhStreamParams *p = w->p;
     Cabac *c = &w->c;
     const int init_type = w->sl.type == SLICE_I ? 0 : (w->sl.type == SLICE_P ? (w->sl.cabac_init_flag ? 2 : 1) : (w->sl.cabac_init_flag ? 1 : 2));
-    uint8_t wpp_ctx[N_CTX];
-    int have_wpp = 0;
+    uint8_t *wpp_ctx = w->wpp_ctx;
     size_t sub_start = 0;
     *n_entry = 0;
     cabac_start(c, data);
-    cabac_init_contexts(c, init_type, w->sl.qp);
-    memset(w->stat_coeff, 0, sizeof(w->stat_coeff));
+    {
+        /* a dependent slice segment goes on with the states the segment before it ended with — unless it opens a tile (fresh
+         * states) or, with wavefronts, a CTB row: there the reference reloads what it saved after the second CTB of the row above
+         * (ff_hevc_cabac_init, hevc_cabac.c:606-628: load_states whatever the availability of that CTB) */
+        const int rs0 = w->rs_of_ts[ts_first];
+        const int opens_tile = ts_first > 0 && w->tile_of[rs0] != w->tile_of[w->rs_of_ts[ts_first - 1]];
+        if (!w->sl.dependent || opens_tile) {
+            cabac_init_contexts(c, init_type, w->sl.qp);
+            memset(w->stat_coeff, 0, sizeof(w->stat_coeff));
+        } else if (p->wpp && rs0 % w->ctbw == 0) {
+            if (w->ctbw == 1) { cabac_init_contexts(c, init_type, w->sl.qp); memset(w->stat_coeff, 0, sizeof(w->stat_coeff)); }
+            else if (w->have_wpp) memcpy(c->state, wpp_ctx, N_CTX);
+        }
+    }
     for (int ts = ts_first; ts < ts_end; ts++) {
         const int rs = w->rs_of_ts[ts], rx = rs % w->ctbw, ry = rs / w->ctbw;
         const int tile_start = ts > ts_first && w->tile_of[rs] != w->tile_of[w->rs_of_ts[ts - 1]];
@@ -1221,14 +1233,14 @@ static void write_slice_data(W *w, Bits *data, int ts_first, int ts_end, uint32_
             sub_start = data->n / 8;
             cabac_start(c, data);
             if (tile_start) { cabac_init_contexts(c, init_type, w->sl.qp); memset(w->stat_coeff, 0, sizeof(w->stat_coeff)); }
-            else if (have_wpp && ry > 0 && rx + 1 < w->ctbw && avail(w, rx << w->lc, ry << w->lc, (rx + 1) << w->lc, (ry - 1) << w->lc))
+            else if (w->have_wpp && ry > 0 && rx + 1 < w->ctbw && avail(w, rx << w->lc, ry << w->lc, (rx + 1) << w->lc, (ry - 1) << w->lc))
                 memcpy(c->state, wpp_ctx, N_CTX);          /* synchronisation: the states after the second CTB of the row above */
             else cabac_init_contexts(c, init_type, w->sl.qp);
         }
         if (p->cu_qp_delta) w->qp_delta_pending = 1;
         code_sao(w, rx, ry);
         code_cqt(w, rx << w->lc, ry << w->lc, w->lc, 0);
-        if (p->wpp && (rx == 1 || (w->ctbw == 1 && rx == 0))) { memcpy(wpp_ctx, c->state, N_CTX); have_wpp = 1; }
+        if (p->wpp && (rx == 1 || (w->ctbw == 1 && rx == 0))) { memcpy(wpp_ctx, c->state, N_CTX); w->have_wpp = 1; }
         const int last = ts + 1 == ts_end;
         enc_terminate(c, last);                            /* end_of_slice_segment_flag */
         tr(OH_SE_END_OF_SLICE, last);
@@ -1263,7 +1275,7 @@ static void write_picture(W *w, int idx, int poc, int type, Dpb *dpb, int idr, i
             while (ts < w->n_ctb && w->tile_of[w->rs_of_ts[ts]] != t) ts++;
         } else {
             ts = 1 + rnd(&w->g, w->n_ctb - 1);
-            if (p->wpp && !p->dependent_slices) ts -= ts % w->ctbw;     /* with wavefronts, slices that start mid-row must end in their row */
+            if (p->wpp) ts -= ts % w->ctbw;                /* with wavefronts, slice segments that start mid-row must end in their row: none does */
         }
         int dup = ts <= 0 || ts >= w->n_ctb;
         for (int i = 0; i < ns; i++) dup |= starts[i] == ts;
@@ -1273,11 +1285,19 @@ static void write_picture(W *w, int idx, int poc, int type, Dpb *dpb, int idr, i
         for (int j = i; j > 0 && starts[j] < starts[j - 1]; j--) { int t = starts[j]; starts[j] = starts[j - 1]; starts[j - 1] = t; }
     starts[ns] = w->n_ctb;
     const int nal_type = idr ? 19 : nonref ? 0 : 1;        /* IDR_W_RADL / TRAIL_N / TRAIL_R */
+    w->have_wpp = 0;
+    int slice_addr = 0;                                    /* SliceAddrRs: the address of the slice's first (independent) segment */
     for (int s = 0; s < ns; s++) {
         Slice *sl = &w->sl;
+        if (p->dependent_slices && s > 0 && rnd(&w->g, 2)) {
+            /* a dependent slice segment: its header carries the address only, everything else is the slice's (7.3.6.1) */
+            sl->dependent = 1;
+            sl->addr = w->rs_of_ts[starts[s]];
+            goto coded;
+        }
         memset(sl, 0, sizeof(*sl));
         sl->type = type;
-        sl->addr = w->rs_of_ts[starts[s]];
+        sl->addr = slice_addr = w->rs_of_ts[starts[s]];
         sl->qp = p->qp + rnd(&w->g, 7) - 3;
         sl->n_ref[0] = type == SLICE_I ? 0 : 1 + rnd(&w->g, dpb->n);
         sl->n_ref[1] = type == SLICE_B ? 1 + rnd(&w->g, dpb->n) : 0;
@@ -1289,7 +1309,8 @@ static void write_picture(W *w, int idx, int poc, int type, Dpb *dpb, int idr, i
         sl->lf_across = rnd(&w->g, 2);
         sl->sao_luma = p->sao && rnd(&w->g, 4) != 0;
         sl->sao_chroma = p->sao && rnd(&w->g, 4) != 0;
-        for (int ts = starts[s]; ts < starts[s + 1]; ts++) w->slice_of[w->rs_of_ts[ts]] = sl->addr;
+    coded:
+        for (int ts = starts[s]; ts < starts[s + 1]; ts++) w->slice_of[w->rs_of_ts[ts]] = slice_addr;
         Bits data = { 0 }, hdr = { 0 };
         uint32_t entry[4096];
         int n_entry = 0;
@@ -1339,7 +1360,7 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     if (!p || !out || p->width < 8 || p->height < 8 || (p->width & 7) || (p->height & 7) || (p->bit_depth != 8 && p->bit_depth != 10) ||
         p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_tb_size != 2 || p->log2_max_tb_size > 5 || p->log2_max_tb_size > p->log2_ctb_size ||
         p->log2_max_tb_size < 3 || p->n_refs < 1 || p->n_refs > 4 || p->n_pictures < 1 || p->max_th_depth_intra < 0 || p->max_th_depth_intra > 3 ||
-        p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3 || p->dependent_slices)
+        p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3)
         return -1;
     if (p->chroma_format_idc < 1 || p->chroma_format_idc > 3 || (p->cross_component_pred && p->chroma_format_idc != 3) ||
         (p->chroma_format_idc >= 2 && (p->pcm || p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))

@@ -73,6 +73,12 @@ CASES = [
                                                   tile_cols=2, tile_rows=2, lf_across_tiles=0, deblocking_override=1)),
     ("tiles3x3_ctb16_420_hier", 152, 88, 806835, dict(n_pictures=5, gop=3, log2_ctb_size=4, log2_max_tb_size=4, n_slices=3, sao_pct=90, tile_cols=3, tile_rows=3,
                                                        lf_across_tiles=1, deblocking_override=1)),
+    # dependent slice segments (a header that carries the address only; CABAC states carried over from the segment before, reloaded at a
+    # CTB-row start with wavefronts, fresh at a tile start), with slices / wavefronts / tiles
+    ("dependent_slices", 416, 240, 41, dict(n_pictures=3, gop=2, n_slices=5, dependent_slices=1)),
+    ("dependent_slices_wpp", 416, 240, 41, dict(n_pictures=3, gop=2, n_slices=4, dependent_slices=1, wpp=1, log2_ctb_size=5)),
+    ("dependent_slices_tiles_ctb16", 416, 240, 41, dict(n_pictures=3, gop=1, n_slices=4, dependent_slices=1, tile_cols=2, tile_rows=2, log2_ctb_size=4,
+                                                        log2_max_tb_size=4, lf_across_slices=0)),
     # hierarchical B (decode order != output order, two pictures of reordering, sub-layer non-reference pictures, references from the future)
     ("hier_b", 416, 240, 15, dict(n_pictures=9, gop=3)),
     ("hier_b_tmvp_weighted_10_idr", 264, 200, 16, dict(n_pictures=11, gop=3, bit_depth=10, tmvp=1, weighted_pred=1, n_refs=3, idr_period=6, n_slices=2)),

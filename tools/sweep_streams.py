@@ -37,6 +37,7 @@ def draw(rng):
     if rng.random() < 0.35:
         kw["n_slices"] = rng.choice([2, 3, 5])
         kw["lf_across_slices"] = rng.choice([0, 1])
+        kw["dependent_slices"] = int(rng.random() < 0.4)
     r = rng.random()
     if r < 0.25:
         kw.update(tile_cols=rng.choice([1, 2, 3]), tile_rows=rng.choice([1, 2, 3]), lf_across_tiles=rng.choice([0, 1]))

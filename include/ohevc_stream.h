@@ -65,6 +65,8 @@ typedef struct OhStreamParams {
     int32_t persistent_rice;            /* persistent_rice_adaptation_enabled_flag (hevc_cabac.c:1719-1725, 1779-1807); not with wpp: the reference does not
                                            synchronise StatCoeff with the contexts, its threaded and serial decodes would differ */
     int32_t log2_max_tskip_size;        /* 0 or 2..5: log2_max_transform_skip_block_size (pps_range_extension); > 2 needs one of the tools above or 4:4:4 */
+    int32_t log2_min_cb_size;           /* 0 (= 3) or 3..5: smallest coding block (width and height are multiples of it); above 8x8 its inter
+                                           partitions include NxN, its min PU / QP / PCM map granularity follows */
 } OhStreamParams;
 
 /* syntax elements of the slice data as (id, value) pairs in coding order — the writer's side of tests/test_streams.py; the ids are

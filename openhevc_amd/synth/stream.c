@@ -264,6 +264,7 @@ typedef struct W {
     Slice sl;
     int qp_delta_pending, cu_bypass;
     int cross_pf, res_scale;                           /* cross-component prediction of the chroma block being coded */
+    int tt_pu;                                         /* transform tree: index of the depth-1 block being coded = the partition of an intra NxN coding block */
     int stat_coeff[4];                                 /* StatCoeff (9.3.3.11): reset with the contexts */
     uint8_t wpp_ctx[N_CTX]; int have_wpp;              /* the context states after the second CTB of the last row that had two (wavefront synchronisation) */
     /* SAO parameters of the CTBs (for merge candidates we only need to know that they exist) */
@@ -345,8 +346,8 @@ static void write_sps(W *w)
     put_ue(&b, 4);                                         /* log2_max_poc_lsb = 8 */
     put_bit(&b, 1);
     put_ue(&b, (uint32_t)p->n_refs + 1); put_ue(&b, p->gop == 3 ? 2 : 0); put_ue(&b, 0);
-    put_ue(&b, 0);                                         /* log2_min_cb 3 */
-    put_ue(&b, (uint32_t)p->log2_ctb_size - 3);
+    put_ue(&b, (uint32_t)w->min_cb_log2 - 3);              /* log2_min_luma_coding_block_size_minus3 */
+    put_ue(&b, (uint32_t)(p->log2_ctb_size - w->min_cb_log2));
     put_ue(&b, (uint32_t)p->log2_min_tb_size - 2);
     put_ue(&b, (uint32_t)(p->log2_max_tb_size - p->log2_min_tb_size));
     put_ue(&b, (uint32_t)p->max_th_depth_inter); put_ue(&b, (uint32_t)p->max_th_depth_intra);
@@ -385,8 +386,8 @@ static void write_sps(W *w)
     put_bit(&b, p->pcm != 0);
     if (p->pcm) {
         put_bits(&b, (uint32_t)p->bit_depth - 1, 4); put_bits(&b, (uint32_t)p->bit_depth - 1, 4);     /* PCM samples at full depth */
-        put_ue(&b, 0);                                     /* log2_min_pcm 3 */
-        put_ue(&b, (uint32_t)((p->log2_ctb_size < 5 ? p->log2_ctb_size : 5) - 3));
+        put_ue(&b, (uint32_t)w->min_cb_log2 - 3);          /* log2_min_pcm: the smallest coding block */
+        put_ue(&b, (uint32_t)((p->log2_ctb_size < 5 ? p->log2_ctb_size : 5) - w->min_cb_log2));
         put_bit(&b, 1);                                    /* pcm_loop_filter_disabled */
     }
     put_ue(&b, 0);                                         /* no short-term RPS in the SPS: slices carry theirs */
@@ -425,7 +426,7 @@ static void write_pps(W *w)
     put_bit(&b, p->constrained_intra_pred != 0);
     put_bit(&b, p->transform_skip != 0);
     put_bit(&b, p->cu_qp_delta != 0);
-    if (p->cu_qp_delta) put_ue(&b, 1);                     /* diff_cu_qp_delta_depth: quantisation groups of half a CTB */
+    if (p->cu_qp_delta) put_ue(&b, (uint32_t)(p->log2_ctb_size > w->min_cb_log2));   /* diff_cu_qp_delta_depth: quantisation groups of half a CTB (a whole one when that is the smallest coding block) */
     put_se(&b, 1); put_se(&b, -2);                         /* cb / cr qp offsets */
     put_bit(&b, 0);                                        /* slice-level chroma qp offsets */
     put_bit(&b, p->weighted_pred != 0); put_bit(&b, p->weighted_pred != 0);
@@ -788,7 +789,7 @@ static void code_tu(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
             w->qp_delta_pending = 0;
         }
     }
-    const int pu = cu->part == PART_NxN && cu->intra ? blk : 0;
+    const int pu = cu->part == PART_NxN && cu->intra ? w->tt_pu : 0;       /* the mode of the partition the block lies in (hevc.c:1461-1474: set at depth 1) */
     const int pc = g_c444 ? pu : 0;                        /* which chroma mode applies */
     if (cbf_luma)
         code_residual(w, log2, 0, cu->intra ? scan_of(cu->ipm[pu], log2, 0) : 0, cu->intra, cu->intra ? cu->ipm[pu] : -1);
@@ -826,6 +827,7 @@ static void code_tt(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
     Cabac *c = &w->c;
     const OhStreamParams *p = w->p;
     const int intra_split = cu->intra && cu->part == PART_NxN;
+    if (depth <= 1) w->tt_pu = depth ? blk : 0;
     const int inter_split = p->max_th_depth_inter == 0 && !cu->intra && cu->part != PART_2Nx2N && depth == 0;
     int split;
     if (log2 <= p->log2_max_tb_size && log2 > p->log2_min_tb_size && depth < max_depth && !(intra_split && depth == 0)) {
@@ -991,21 +993,25 @@ static void code_cu(W *w, int x, int y, int log2)
     cu.intra = 1;
     if (sl->type != SLICE_I) { cu.intra = pct(&w->g, p->intra_pct); enc_bin(c, C_PRED_MODE, cu.intra); tr(OH_SE_PRED_MODE, cu.intra); }
     cu.part = PART_2Nx2N;
-    if (!cu.intra || log2 == 3) {
+    const int mcb = w->min_cb_log2;
+    if (!cu.intra || log2 == mcb) {
         if (cu.intra) {
             cu.part = log2 > p->log2_min_tb_size && pct(&w->g, 40) ? PART_NxN : PART_2Nx2N;
             enc_bin(c, C_PART_MODE, cu.part == PART_2Nx2N); tr(OH_SE_PART_MODE, cu.part);
         } else {
             const int r = rnd(&w->g, 10);
             if (r < 4) cu.part = PART_2Nx2N;
-            else if (log2 == 3) cu.part = r < 7 ? PART_2NxN : PART_Nx2N;                    /* minimum CB size 8: no NxN, no AMP */
+            else if (log2 == 3) cu.part = r < 7 ? PART_2NxN : PART_Nx2N;                    /* an 8x8 coding block: no NxN, no AMP */
+            else if (log2 == mcb) cu.part = r < 6 ? PART_2NxN : r < 8 ? PART_Nx2N : PART_NxN;  /* the smallest coding block, larger than 8x8: NxN instead of AMP */
             else if (!p->amp) cu.part = r < 7 ? PART_2NxN : PART_Nx2N;
             else cu.part = r == 4 ? PART_2NxN : r == 5 ? PART_Nx2N : r == 6 ? PART_2NxnU : r == 7 ? PART_2NxnD : r == 8 ? PART_nLx2N : PART_nRx2N;
             enc_bin(c, C_PART_MODE, cu.part == PART_2Nx2N);
             if (cu.part != PART_2Nx2N) {
                 const int horiz = cu.part == PART_2NxN || cu.part == PART_2NxnU || cu.part == PART_2NxnD;
                 enc_bin(c, C_PART_MODE + 1, horiz);
-                if (log2 > 3 && p->amp) {
+                if (log2 == mcb) {
+                    if (log2 > 3 && !horiz) enc_bin(c, C_PART_MODE + 2, cu.part == PART_Nx2N);      /* ff_hevc_part_mode_decode, hevc_cabac.c: 001 Nx2N, 000 NxN */
+                } else if (p->amp) {
                     const int sym = cu.part == PART_2NxN || cu.part == PART_Nx2N;
                     enc_bin(c, C_PART_MODE + 3, sym);
                     if (!sym) enc_bypass(c, cu.part == PART_2NxnD || cu.part == PART_nRx2N);
@@ -1017,7 +1023,7 @@ static void code_cu(W *w, int x, int y, int log2)
     if (cu.intra) {
         fill(w->pic.intra, w, x, y, n, 1);
         int pcm = 0;
-        if (cu.part == PART_2Nx2N && p->pcm && log2 >= 3 && log2 <= (p->log2_ctb_size < 5 ? p->log2_ctb_size : 5)) {
+        if (cu.part == PART_2Nx2N && p->pcm && log2 >= mcb && log2 <= (p->log2_ctb_size < 5 ? p->log2_ctb_size : 5)) {
             pcm = pct(&w->g, p->pcm_pct);
             enc_terminate(c, pcm); tr(OH_SE_PCM_FLAG, pcm);
         }
@@ -1026,7 +1032,8 @@ static void code_cu(W *w, int x, int y, int log2)
             fill(w->pic.ipm, w, x, y, n, 1);
             byte_align_zero(c->out);                       /* pcm_alignment_zero_bit */
             for (int i = 0; i < n * n; i++) put_bits(c->out, (uint32_t)rnd(&w->g, 1 << p->bit_depth), p->bit_depth);
-            for (int i = 0; i < n * n / 2; i++) put_bits(c->out, (uint32_t)rnd(&w->g, 1 << p->bit_depth), p->bit_depth);
+            const int n_chroma = 2 * (n >> (p->chroma_format_idc != 3)) * (n >> (p->chroma_format_idc == 1));     /* both chroma blocks (7.3.8.7) */
+            for (int i = 0; i < n_chroma; i++) put_bits(c->out, (uint32_t)rnd(&w->g, 1 << p->bit_depth), p->bit_depth);
             cabac_start(c, c->out);                        /* 9.3.2.5: the arithmetic engine starts over, the contexts stay */
             return;
         }
@@ -1063,6 +1070,7 @@ static void code_cu(W *w, int x, int y, int log2)
         case PART_2Nx2N: code_pu(w, &cu, n, n, 0, &m0); break;
         case PART_2NxN:  code_pu(w, &cu, n, h, 0, &m); code_pu(w, &cu, n, h, 0, &m); break;
         case PART_Nx2N:  code_pu(w, &cu, h, n, 0, &m); code_pu(w, &cu, h, n, 0, &m); break;
+        case PART_NxN:   for (int k = 0; k < 4; k++) code_pu(w, &cu, h, h, 0, &m); break;
         case PART_2NxnU: code_pu(w, &cu, n, q, 0, &m); code_pu(w, &cu, n, n - q, 0, &m); break;
         case PART_2NxnD: code_pu(w, &cu, n, n - q, 0, &m); code_pu(w, &cu, n, q, 0, &m); break;
         case PART_nLx2N: code_pu(w, &cu, q, n, 0, &m); code_pu(w, &cu, n - q, n, 0, &m); break;
@@ -1085,15 +1093,15 @@ static void code_cqt(W *w, int x, int y, int log2, int depth)
     const OhStreamParams *p = w->p;
     const int n = 1 << log2;
     int split;
-    if (x + n <= p->width && y + n <= p->height && log2 > 3) {
+    if (x + n <= p->width && y + n <= p->height && log2 > w->min_cb_log2) {
         const int l = avail(w, x, y, x - 1, y) && *cell(w->pic.depth, w, x - 1, y) > depth;
         const int u = avail(w, x, y, x, y - 1) && *cell(w->pic.depth, w, x, y - 1) > depth;
         split = pct(&w->g, p->split_pct);
         enc_bin(c, C_SPLIT_CU + l + u, split); tr(OH_SE_SPLIT_CU, split);
     } else {
-        split = log2 > 3;
+        split = log2 > w->min_cb_log2;
     }
-    if (p->cu_qp_delta && log2 >= p->log2_ctb_size - 1)
+    if (p->cu_qp_delta && log2 >= p->log2_ctb_size - (p->log2_ctb_size > w->min_cb_log2))
         w->qp_delta_pending = 1;                           /* a new quantisation group */
     if (split) {
         const int h = n >> 1;
@@ -1363,8 +1371,12 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
         p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3)
         return -1;
     if (p->chroma_format_idc < 1 || p->chroma_format_idc > 3 || (p->cross_component_pred && p->chroma_format_idc != 3) ||
-        (p->chroma_format_idc >= 2 && (p->pcm || p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))
-        return -1;                                         /* 4:2:2 / 4:4:4: no PCM (its chroma sample count differs), no window (the reference doubles the offsets) */
+        (p->chroma_format_idc >= 2 && (p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom)))
+        return -1;                                         /* 4:2:2 / 4:4:4: no window (the reference doubles the offsets) */
+    const int mcb_log2 = p->log2_min_cb_size ? p->log2_min_cb_size : 3;
+    if (mcb_log2 < 3 || mcb_log2 > 5 || mcb_log2 > p->log2_ctb_size || (p->width & ((1 << mcb_log2) - 1)) || (p->height & ((1 << mcb_log2) - 1)) ||
+        (p->pcm && mcb_log2 > (p->log2_ctb_size < 5 ? p->log2_ctb_size : 5)))
+        return -1;                                         /* the picture is a whole number of smallest coding blocks */
     if ((p->log2_max_tskip_size && (p->log2_max_tskip_size < 2 || p->log2_max_tskip_size > 5)) || (p->persistent_rice && p->wpp))
         return -1;
     if (p->gop < 0 || p->gop > 3 || (p->gop == 3 && p->n_refs < 2))
@@ -1377,7 +1389,7 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     g_c444 = p->chroma_format_idc == 3;
     g_c422 = p->chroma_format_idc == 2;
     w.g.s = p->seed * 0x2545F4914F6CDD1Dull + 77;
-    w.lc = p->log2_ctb_size; w.ctb = 1 << w.lc;
+    w.lc = p->log2_ctb_size; w.ctb = 1 << w.lc; w.min_cb_log2 = mcb_log2;
     w.ctbw = (p->width + w.ctb - 1) >> w.lc; w.ctbh = (p->height + w.ctb - 1) >> w.lc; w.n_ctb = w.ctbw * w.ctbh;
     w.tcols = p->tile_cols > 1 ? (p->tile_cols < w.ctbw ? p->tile_cols : w.ctbw) : 1;
     w.trows = p->tile_rows > 1 ? (p->tile_rows < w.ctbh ? p->tile_rows : w.ctbh) : 1;

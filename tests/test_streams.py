@@ -79,6 +79,12 @@ CASES = [
     ("dependent_slices_wpp", 416, 240, 41, dict(n_pictures=3, gop=2, n_slices=4, dependent_slices=1, wpp=1, log2_ctb_size=5)),
     ("dependent_slices_tiles_ctb16", 416, 240, 41, dict(n_pictures=3, gop=1, n_slices=4, dependent_slices=1, tile_cols=2, tile_rows=2, log2_ctb_size=4,
                                                         log2_max_tb_size=4, lf_across_slices=0)),
+    # smallest coding block 16x16 / 32x32 (inter NxN partitions, coarser min-PU / QP / PCM maps), PCM with 4:2:2 and 4:4:4 chroma
+    ("min_cb16_b", 416, 256, 43, dict(n_pictures=3, gop=2, log2_min_cb_size=4, tmvp=1, cu_qp_delta=1)),
+    ("min_cb16_ctb16_pcm_slices", 416, 256, 43, dict(n_pictures=3, gop=2, log2_min_cb_size=4, log2_ctb_size=4, log2_max_tb_size=4, cu_qp_delta=1, pcm=1, n_slices=2)),
+    ("min_cb32_ctb64_pcm_bypass_10", 416, 256, 43, dict(n_pictures=2, gop=2, log2_min_cb_size=5, log2_ctb_size=6, pcm=1, transquant_bypass=1, bit_depth=10)),
+    ("pcm_422", 264, 200, 44, dict(n_pictures=3, gop=2, chroma_format_idc=2, pcm=1, pcm_pct=30)),
+    ("pcm_444_ccp_min_cb16", 416, 256, 43, dict(n_pictures=3, gop=2, chroma_format_idc=3, pcm=1, pcm_pct=30, log2_min_cb_size=4, cross_component_pred=1)),
     # hierarchical B (decode order != output order, two pictures of reordering, sub-layer non-reference pictures, references from the future)
     ("hier_b", 416, 240, 15, dict(n_pictures=9, gop=3)),
     ("hier_b_tmvp_weighted_10_idr", 264, 200, 16, dict(n_pictures=11, gop=3, bit_depth=10, tmvp=1, weighted_pred=1, n_refs=3, idr_period=6, n_slices=2)),

@@ -32,8 +32,13 @@ def draw(rng):
         kw[flag] = int(rng.random() < prob)
     kw["sao"] = int(rng.random() < 0.8)
     kw["scaling_list"] = rng.choice([0, 0, 1, 2])
-    if cf == 1 and rng.random() < 0.3:
+    if rng.random() < 0.3:
         kw["pcm"] = 1
+    mcb = min(lc, rng.choice([3, 3, 3, 4, 5]))                 # smallest coding block: the picture is a whole number of them
+    if mcb > 3:
+        kw["log2_min_cb_size"] = mcb
+    if kw.get("pcm") and mcb > min(lc, 5):
+        kw["pcm"] = 0
     if rng.random() < 0.35:
         kw["n_slices"] = rng.choice([2, 3, 5])
         kw["lf_across_slices"] = rng.choice([0, 1])
@@ -59,10 +64,14 @@ def draw(rng):
         kw.update(conf_win_left=2 * rng.randint(0, 4), conf_win_right=2 * rng.randint(0, 4), conf_win_top=2 * rng.randint(0, 4), conf_win_bottom=2 * rng.randint(0, 4))
     if rng.random() < 0.15:
         kw["mvd_range"] = rng.choice([8, 600, 4000])
+    unit = 1 << mcb
+
+    def dim(lo, hi):
+        return max(unit, 8 * rng.randint(lo, hi) // unit * unit)
     if BIG:                                                     # --big: pictures up to 1920 x 1088 (many workgroups per pass, the CTU-row intra kernel)
         kw["n_pictures"] = min(kw["n_pictures"], 3) if kw["gop"] != 3 else 5
-        return 8 * rng.randint(40, 240), 8 * rng.randint(30, 136), rng.randint(1, 10 ** 6), kw
-    return 8 * rng.randint(2, 40), 8 * rng.randint(2, 30), rng.randint(1, 10 ** 6), kw
+        return dim(40, 240), dim(30, 136), rng.randint(1, 10 ** 6), kw
+    return dim(2, 40), dim(2, 30), rng.randint(1, 10 ** 6), kw
 
 
 def harness_sweep(count, seed, extra=(), min_ctb=4):

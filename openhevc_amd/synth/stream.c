@@ -1366,7 +1366,7 @@ void oh_stream_defaults(OhStreamParams *p, int width, int height, uint64_t seed)
 int oh_stream_write(const OhStreamParams *p, OhStream *out)
 {
     if (!p || !out || p->width < 8 || p->height < 8 || (p->width & 7) || (p->height & 7) || (p->bit_depth != 8 && p->bit_depth != 10) ||
-        p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_tb_size != 2 || p->log2_max_tb_size > 5 || p->log2_max_tb_size > p->log2_ctb_size ||
+        p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_tb_size < 2 || p->log2_min_tb_size > 4 || p->log2_min_tb_size > p->log2_max_tb_size || p->log2_max_tb_size > 5 || p->log2_max_tb_size > p->log2_ctb_size ||
         p->log2_max_tb_size < 3 || p->n_refs < 1 || p->n_refs > 4 || p->n_pictures < 1 || p->max_th_depth_intra < 0 || p->max_th_depth_intra > 3 ||
         p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3)
         return -1;
@@ -1375,8 +1375,14 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
         return -1;                                         /* 4:2:2 / 4:4:4: no window (the reference doubles the offsets) */
     const int mcb_log2 = p->log2_min_cb_size ? p->log2_min_cb_size : 3;
     if (mcb_log2 < 3 || mcb_log2 > 5 || mcb_log2 > p->log2_ctb_size || (p->width & ((1 << mcb_log2) - 1)) || (p->height & ((1 << mcb_log2) - 1)) ||
-        (p->pcm && mcb_log2 > (p->log2_ctb_size < 5 ? p->log2_ctb_size : 5)))
-        return -1;                                         /* the picture is a whole number of smallest coding blocks */
+        (p->pcm && mcb_log2 > (p->log2_ctb_size < 5 ? p->log2_ctb_size : 5)) || p->log2_min_tb_size >= mcb_log2)
+        return -1;                                         /* the picture is a whole number of smallest coding blocks; the smallest transform block is smaller than they are */
+    if (p->max_th_depth_intra > p->log2_ctb_size - p->log2_min_tb_size || p->max_th_depth_inter > p->log2_ctb_size - p->log2_min_tb_size)
+        return -1;                                         /* 7.4.3.2.1: the transform hierarchy cannot be deeper than CTB / smallest transform block */
+    if (p->chroma_format_idc == 2 && p->log2_min_tb_size > 2)
+        return -1;                                         /* 4:2:2's second chroma block of a transform unit sits HALF a min-TB down when that is 8x8 or more; the reference
+                                                              derives intra availability in whole min-TBs (hevcpred_template.c:73-109), calls its up-right neighbour
+                                                              available and predicts from samples that are not decoded yet: output that depends on stale memory */
     if ((p->log2_max_tskip_size && (p->log2_max_tskip_size < 2 || p->log2_max_tskip_size > 5)) || (p->persistent_rice && p->wpp))
         return -1;
     if (p->gop < 0 || p->gop > 3 || (p->gop == 3 && p->n_refs < 2))

@@ -83,6 +83,9 @@ CASES = [
     ("min_cb16_b", 416, 256, 43, dict(n_pictures=3, gop=2, log2_min_cb_size=4, tmvp=1, cu_qp_delta=1)),
     ("min_cb16_ctb16_pcm_slices", 416, 256, 43, dict(n_pictures=3, gop=2, log2_min_cb_size=4, log2_ctb_size=4, log2_max_tb_size=4, cu_qp_delta=1, pcm=1, n_slices=2)),
     ("min_cb32_ctb64_pcm_bypass_10", 416, 256, 43, dict(n_pictures=2, gop=2, log2_min_cb_size=5, log2_ctb_size=6, pcm=1, transquant_bypass=1, bit_depth=10)),
+    ("min_tb8_min_cb16", 416, 256, 45, dict(n_pictures=3, gop=2, log2_min_cb_size=4, log2_min_tb_size=3, scaling_list=2, sign_data_hiding=1)),
+    ("min_tb16_min_cb32_444_ccp", 416, 256, 45, dict(n_pictures=2, gop=1, log2_min_cb_size=5, log2_min_tb_size=4, log2_ctb_size=6, log2_max_tb_size=5, chroma_format_idc=3,
+                                                     cross_component_pred=1)),
     ("pcm_422", 264, 200, 44, dict(n_pictures=3, gop=2, chroma_format_idc=2, pcm=1, pcm_pct=30)),
     ("pcm_444_ccp_min_cb16", 416, 256, 43, dict(n_pictures=3, gop=2, chroma_format_idc=3, pcm=1, pcm_pct=30, log2_min_cb_size=4, cross_component_pred=1)),
     # hierarchical B (decode order != output order, two pictures of reordering, sub-layer non-reference pictures, references from the future)

@@ -37,6 +37,10 @@ def draw(rng):
     mcb = min(lc, rng.choice([3, 3, 3, 4, 5]))                 # smallest coding block: the picture is a whole number of them
     if mcb > 3:
         kw["log2_min_cb_size"] = mcb
+        if cf != 2 and rng.random() < 0.5:                      # a smallest transform block of 8x8 / 16x16 (not with 4:2:2: the writer says why)
+            kw["log2_min_tb_size"] = rng.randint(3, mcb - 1)
+            kw["log2_max_tb_size"] = max(kw["log2_max_tb_size"], kw["log2_min_tb_size"])
+            kw["max_th_depth_intra"] = kw["max_th_depth_inter"] = min(2, lc - kw["log2_min_tb_size"])
     if kw.get("pcm") and mcb > min(lc, 5):
         kw["pcm"] = 0
     if rng.random() < 0.35:

@@ -34,7 +34,7 @@ extern "C" {
 /* ---- sequence / picture parameters the hot path needs (subset of SPS/PPS, hevc.h:729-920) ---- */
 typedef struct OhPicParams {
     int32_t width, height;            /* luma samples (sps->width/height)                      */
-    int32_t bit_depth;                /* 8, 10 or 12 (luma == chroma, README.md:16)            */
+    int32_t bit_depth;                /* 8, 9, 10 or 12 (luma == chroma, README.md:16)         */
     int32_t chroma_format_idc;        /* 0 mono, 1 4:2:0, 2 4:2:2, 3 4:4:4                     */
     int32_t log2_ctb_size;            /* 4..6                                                  */
     int32_t log2_min_cb_size;         /* >= 3                                                  */

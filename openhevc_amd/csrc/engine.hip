@@ -304,8 +304,8 @@ static int check_params(OhEngine *e, const OhPicParams *p)
 {
     if (!p || p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384)
         FAIL(e, OH_E_ARG, "bad picture size");
-    if (p->bit_depth != 8 && p->bit_depth != 10 && p->bit_depth != 12)
-        FAIL(e, OH_E_UNSUPPORTED, "bit depth %d not supported (8/10/12)", p->bit_depth);
+    if (p->bit_depth != 8 && p->bit_depth != 9 && p->bit_depth != 10 && p->bit_depth != 12)
+        FAIL(e, OH_E_UNSUPPORTED, "bit depth %d not supported (8/9/10/12: what the reference's wrapper can hand out, openHevcWrapper.c)", p->bit_depth);
     if (p->chroma_format_idc < 0 || p->chroma_format_idc > 3)
         FAIL(e, OH_E_ARG, "chroma_format_idc %d out of range", p->chroma_format_idc);
     if (p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_cb_size < 3 || p->log2_min_cb_size > p->log2_ctb_size ||

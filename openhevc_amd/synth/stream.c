@@ -293,7 +293,7 @@ static void fill(uint8_t *m, const W *w, int x, int y, int n, int v)
 /* ================================================================================================= parameter sets */
 static int rext_profile(const OhStreamParams *p)
 {
-    return p->chroma_format_idc >= 2 || p->tskip_rotation || p->tskip_context || p->implicit_rdpcm || p->explicit_rdpcm || p->intra_smoothing_disabled ||
+    return p->chroma_format_idc >= 2 || p->bit_depth > 10 || p->tskip_rotation || p->tskip_context || p->implicit_rdpcm || p->explicit_rdpcm || p->intra_smoothing_disabled ||
            p->persistent_rice || p->log2_max_tskip_size > 2;
 }
 
@@ -1365,7 +1365,7 @@ void oh_stream_defaults(OhStreamParams *p, int width, int height, uint64_t seed)
 
 int oh_stream_write(const OhStreamParams *p, OhStream *out)
 {
-    if (!p || !out || p->width < 8 || p->height < 8 || (p->width & 7) || (p->height & 7) || (p->bit_depth != 8 && p->bit_depth != 10) ||
+    if (!p || !out || p->width < 8 || p->height < 8 || (p->width & 7) || (p->height & 7) || (p->bit_depth != 8 && p->bit_depth != 9 && p->bit_depth != 10 && p->bit_depth != 12) ||
         p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_tb_size < 2 || p->log2_min_tb_size > 4 || p->log2_min_tb_size > p->log2_max_tb_size || p->log2_max_tb_size > 5 || p->log2_max_tb_size > p->log2_ctb_size ||
         p->log2_max_tb_size < 3 || p->n_refs < 1 || p->n_refs > 4 || p->n_pictures < 1 || p->max_th_depth_intra < 0 || p->max_th_depth_intra > 3 ||
         p->max_th_depth_inter < 0 || p->max_th_depth_inter > 3)

@@ -86,6 +86,10 @@ CASES = [
     ("min_tb8_min_cb16", 416, 256, 45, dict(n_pictures=3, gop=2, log2_min_cb_size=4, log2_min_tb_size=3, scaling_list=2, sign_data_hiding=1)),
     ("min_tb16_min_cb32_444_ccp", 416, 256, 45, dict(n_pictures=2, gop=1, log2_min_cb_size=5, log2_min_tb_size=4, log2_ctb_size=6, log2_max_tb_size=5, chroma_format_idc=3,
                                                      cross_component_pred=1)),
+    # 12 and 9 bit
+    ("main12_tools", 264, 200, 47, dict(n_pictures=3, gop=2, bit_depth=12, pcm=1, transform_skip=1, transquant_bypass=1, weighted_pred=1)),
+    ("rext444_12_ccp_ctb16_intra", 264, 200, 47, dict(n_pictures=2, gop=0, bit_depth=12, chroma_format_idc=3, cross_component_pred=1, log2_ctb_size=4, log2_max_tb_size=4)),
+    ("nine_bit_lists_qpdelta", 264, 200, 47, dict(n_pictures=3, gop=2, bit_depth=9, scaling_list=2, cu_qp_delta=1)),
     ("pcm_422", 264, 200, 44, dict(n_pictures=3, gop=2, chroma_format_idc=2, pcm=1, pcm_pct=30)),
     ("pcm_444_ccp_min_cb16", 416, 256, 43, dict(n_pictures=3, gop=2, chroma_format_idc=3, pcm=1, pcm_pct=30, log2_min_cb_size=4, cross_component_pred=1)),
     # hierarchical B (decode order != output order, two pictures of reordering, sub-layer non-reference pictures, references from the future)

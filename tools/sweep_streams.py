@@ -22,7 +22,7 @@ BIG = False
 def draw(rng):
     lc = rng.choice([4, 5, 6])
     cf = rng.choice([1, 1, 2, 3])
-    kw = dict(n_pictures=rng.choice([2, 3, 4]), gop=rng.choice([0, 1, 2, 2, 3]), chroma_format_idc=cf, bit_depth=rng.choice([8, 10]),
+    kw = dict(n_pictures=rng.choice([2, 3, 4]), gop=rng.choice([0, 1, 2, 2, 3]), chroma_format_idc=cf, bit_depth=rng.choice([8, 8, 10, 10, 12, 9]),
               log2_ctb_size=lc, log2_max_tb_size=min(lc, rng.choice([3, 4, 5])), n_refs=rng.choice([1, 2, 3, 4]),
               qp=rng.randint(12, 44), sao_pct=rng.choice([0, 50, 90]), split_pct=rng.choice([20, 50, 80]), intra_pct=rng.choice([5, 20, 60]),
               cbf_pct=rng.choice([20, 55, 90]), coeff_density=rng.choice([10, 60, 100]))

@@ -65,6 +65,9 @@ typedef struct OhStreamParams {
     int32_t persistent_rice;            /* persistent_rice_adaptation_enabled_flag (hevc_cabac.c:1719-1725, 1779-1807); not with wpp: the reference does not
                                            synchronise StatCoeff with the contexts, its threaded and serial decodes would differ */
     int32_t log2_max_tskip_size;        /* 0 or 2..5: log2_max_transform_skip_block_size (pps_range_extension); > 2 needs one of the tools above or 4:4:4 */
+    int32_t pcm_loop_filter;            /* 1: pcm_loop_filter_disabled_flag = 0 (PCM blocks are deblocked like any other) */
+    int32_t chroma_qp_offsets;          /* 1: pps_cb_qp_offset / pps_cr_qp_offset from the next two fields (-12..12) instead of +1 / -2 */
+    int32_t cb_qp_offset, cr_qp_offset;
     int32_t log2_min_cb_size;           /* 0 (= 3) or 3..5: smallest coding block (width and height are multiples of it); above 8x8 its inter
                                            partitions include NxN, its min PU / QP / PCM map granularity follows */
 } OhStreamParams;

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(64) void residual_kernel(const OhBatch B)
             const GLOBAL uint32_t *__restrict__ rec = G_CONST(uint32_t, f->sparse) + dtu.sparse_off;
             const uint32_t w0 = rec[0], cnt = w0 & 0xffff, qp = (w0 >> 16) & 0xff, mid = w0 >> 24;
             const int shift = bd + LOG2 - 5;
-            const long long radd = 1ll << (shift - 1), scale = (long long)c_level_scale[qp % 6] << (qp / 6);
+            const uint32_t qp6 = qp < 74 ? qp : 0;            /* the reference's rem6[] / div6[] end two entries early (hevc_cabac.c:1428-1440): QP 74 / 75 scale like QP 0 */
+            const long long radd = 1ll << (shift - 1), scale = (long long)c_level_scale[qp6 % 6] << (qp6 / 6);
             const bool flat = mid == OH_FLAT_MATRIX;
             const GLOBAL uint8_t *__restrict__ mtx = flat ? nullptr : G_CONST(uint8_t, f->scaling->sl[LOG2 - 2][flat ? 0 : mid]);
             const int dc_scale = !flat && LOG2 >= 4 ? G_CONST(uint8_t, f->scaling->sl_dc[LOG2 >= 4 ? LOG2 - 4 : 0])[mid] : 16;

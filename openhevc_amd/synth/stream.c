@@ -215,12 +215,13 @@ static void lev_put(uint32_t v)
 }
 size_t oh_stream_levels(const uint32_t **words) { *words = g_lev; return g_lev_n; }
 
-/* chroma QP of a block (8.6.1: qPi -> QpC for ChromaArrayType 1); the writer's PPS carries cb / cr offsets +1 / -2, no slice offsets */
+/* chroma QP of a block (8.6.1: qPi -> QpC for ChromaArrayType 1); the PPS carries the cb / cr offsets (+1 / -2 unless OhStreamParams says otherwise), no slice offsets */
+static int g_cb_off = 1, g_cr_off = -2;               /* pps_cb_qp_offset / pps_cr_qp_offset of the stream being written */
 static int chroma_qp(int qp_y, int c_idx, int bit_depth, int chroma_format_idc)
 {
     static const uint8_t tab[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };     /* qPi 30..43 */
     const int bd_off = 6 * (bit_depth - 8);
-    int qpi = qp_y + (c_idx == 1 ? 1 : -2);
+    int qpi = qp_y + (c_idx == 1 ? g_cb_off : g_cr_off);
     qpi = qpi < -bd_off ? -bd_off : qpi > 57 ? 57 : qpi;
     const int qpc = chroma_format_idc != 1 ? (qpi < 51 ? qpi : 51) : qpi < 30 ? qpi : qpi >= 43 ? qpi - 6 : tab[qpi - 30];
     return qpc + bd_off;
@@ -388,7 +389,7 @@ static void write_sps(W *w)
         put_bits(&b, (uint32_t)p->bit_depth - 1, 4); put_bits(&b, (uint32_t)p->bit_depth - 1, 4);     /* PCM samples at full depth */
         put_ue(&b, (uint32_t)w->min_cb_log2 - 3);          /* log2_min_pcm: the smallest coding block */
         put_ue(&b, (uint32_t)((p->log2_ctb_size < 5 ? p->log2_ctb_size : 5) - w->min_cb_log2));
-        put_bit(&b, 1);                                    /* pcm_loop_filter_disabled */
+        put_bit(&b, p->pcm_loop_filter == 0);              /* pcm_loop_filter_disabled_flag */
     }
     put_ue(&b, 0);                                         /* no short-term RPS in the SPS: slices carry theirs */
     put_bit(&b, 0);                                        /* long-term refs */
@@ -427,7 +428,7 @@ static void write_pps(W *w)
     put_bit(&b, p->transform_skip != 0);
     put_bit(&b, p->cu_qp_delta != 0);
     if (p->cu_qp_delta) put_ue(&b, (uint32_t)(p->log2_ctb_size > w->min_cb_log2));   /* diff_cu_qp_delta_depth: quantisation groups of half a CTB (a whole one when that is the smallest coding block) */
-    put_se(&b, 1); put_se(&b, -2);                         /* cb / cr qp offsets */
+    put_se(&b, g_cb_off); put_se(&b, g_cr_off);            /* pps_cb_qp_offset / pps_cr_qp_offset */
     put_bit(&b, 0);                                        /* slice-level chroma qp offsets */
     put_bit(&b, p->weighted_pred != 0); put_bit(&b, p->weighted_pred != 0);
     put_bit(&b, p->transquant_bypass != 0);
@@ -1393,6 +1394,8 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     g_trace_on = p->trace != 0; g_trace_n = 0;
     g_lev_on = p->levels != 0 && !p->cu_qp_delta; g_lev_n = 0;
     g_c444 = p->chroma_format_idc == 3;
+    g_cb_off = p->chroma_qp_offsets ? p->cb_qp_offset : 1; g_cr_off = p->chroma_qp_offsets ? p->cr_qp_offset : -2;
+    if (g_cb_off < -12 || g_cb_off > 12 || g_cr_off < -12 || g_cr_off > 12) return -1;
     g_c422 = p->chroma_format_idc == 2;
     w.g.s = p->seed * 0x2545F4914F6CDD1Dull + 77;
     w.lc = p->log2_ctb_size; w.ctb = 1 << w.lc; w.min_cb_log2 = mcb_log2;

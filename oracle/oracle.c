@@ -361,7 +361,10 @@ static void tu_dequant(const OhFrame *f, const OhTu *tu, const uint32_t *rec, in
     const int log2 = tu->log2_size, n = 1 << log2, cnt = (int)(rec[0] & 0xffff), qp = (int)((rec[0] >> 16) & 0xff);
     const unsigned matrix = rec[0] >> 24;
     const int shift = f->p.bit_depth + log2 - 5;            /* + 10 - log2_transform_range, the range being 15 (:1416) */
-    const int64_t add = (int64_t)1 << (shift - 1), scale = (int64_t)level_scale[qp % 6] << (qp / 6);
+    /* the reference's rem6[] / div6[] tables (hevc_cabac.c:1428-1440) are declared with 76 entries and initialised with 74: QP 74 and 75
+     * (12 bit: luma QP 50 / 51) read zeros, i.e. scale = level_scale[0] << 0 */
+    const int qp6 = qp < 74 ? qp : 0;
+    const int64_t add = (int64_t)1 << (shift - 1), scale = (int64_t)level_scale[qp6 % 6] << (qp6 / 6);
     const uint8_t *m = matrix != OH_FLAT_MATRIX && f->scaling ? f->scaling->sl[log2 - 2][matrix] : NULL;
     const int dc_scale = m && log2 >= 4 ? f->scaling->sl_dc[log2 - 4][matrix] : (m ? -1 : 16);
     memset(c, 0, sizeof(int16_t) * (size_t)(n * n));

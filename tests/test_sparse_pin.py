@@ -32,6 +32,10 @@ CASES = [
     # range-extension tools with scaling lists: skip blocks up to 32x32 stay flat (hevc_cabac.c:1485), the 4x4 intra rotation moves to the GPU with the levels
     ("rext_tools_lists10", 216, 184, 59, dict(n_pictures=3, gop=2, bit_depth=10, scaling_list=2, transform_skip=1, tskip_rotation=1, tskip_context=1,
                                               implicit_rdpcm=1, explicit_rdpcm=1, log2_max_tskip_size=5, tskip_pct=50, sign_data_hiding=1, intra_pct=40)),
+    # 12 bit at the top of the QP range: QP 74 / 75 (luma QP 50 / 51 + 24) de-quantise like QP 0 in the reference (its rem6[] / div6[] tables end two
+    # entries early, hevc_cabac.c:1428-1440) — the chroma QP offset pushes Cr there
+    ("high_qp_12bit_444", 48, 176, 406270, dict(n_pictures=2, gop=0, chroma_format_idc=3, bit_depth=12, qp=44, scaling_list=1, chroma_qp_offsets=1, cb_qp_offset=-1,
+                                                cr_qp_offset=11, log2_max_tb_size=4, cbf_pct=60, coeff_density=60)),
     ("ccp444_10_lists_intra", 200, 136, 57, dict(n_pictures=2, gop=0, bit_depth=10, chroma_format_idc=3, cross_component_pred=1, scaling_list=2, qp=24)),
 ]
 OH_TUF_SPARSE, OH_NO_COEFF, OH_FLAT_MATRIX = 16, 0xFFFFFFFF, 0xFF

@@ -34,6 +34,10 @@ def draw(rng):
     kw["scaling_list"] = rng.choice([0, 0, 1, 2])
     if rng.random() < 0.3:
         kw["pcm"] = 1
+    if kw.get("pcm"):
+        kw["pcm_loop_filter"] = rng.choice([0, 1])
+    if rng.random() < 0.4:
+        kw.update(chroma_qp_offsets=1, cb_qp_offset=rng.randint(-12, 12), cr_qp_offset=rng.randint(-12, 12))
     mcb = min(lc, rng.choice([3, 3, 3, 4, 5]))                 # smallest coding block: the picture is a whole number of them
     if mcb > 3:
         kw["log2_min_cb_size"] = mcb

@@ -27,7 +27,8 @@ def dequant_numpy(f, p):
         cnt, qp, mid = w0 & 0xffff, (w0 >> 16) & 0xff, w0 >> 24
         l2, n = t.log2_size, 1 << t.log2_size
         shift = p.bit_depth + l2 - 5
-        add, scale = 1 << (shift - 1), LEVEL_SCALE[qp % 6] << (qp // 6)
+        q6 = qp if qp < 74 else 0                          # the reference's rem6[] / div6[] tables end two entries early (hevc_cabac.c:1428-1440)
+        add, scale = 1 << (shift - 1), LEVEL_SCALE[q6 % 6] << (q6 // 6)
         blk = np.zeros(n * n, np.int64)
         for k in range(cnt):
             w = f.sparse[so + 1 + k]

@@ -780,11 +780,18 @@ static void code_tu(W *w, const Cu *cu, int x, int y, int log2, int depth, int b
     const int chroma_here = log2 > 2, chroma_parent = log2 == 2 && blk == 3;
     if (cbf_luma || cbf_cb || cbf_cr) {                    /* for 4x4 luma blocks the chroma flags are those of the 8x8 parent (7.3.8.10) */
         if (w->p->cu_qp_delta && w->qp_delta_pending) {
-            const int d = rnd(&w->g, 3) ? 0 : rnd(&w->g, 7) - 3;
+            /* mostly none or small, now and then anything the range allows (7.4.9.10: -(26 + QpBdOffset / 2) .. 25 + QpBdOffset / 2) */
+            const int lim = 25 + 3 * (w->p->bit_depth - 8);
+            const int d = rnd(&w->g, 3) ? 0 : rnd(&w->g, 6) ? rnd(&w->g, 7) - 3 : rnd(&w->g, 2 * lim + 1) - lim;
             const int a = abs(d);
             enc_bin(c, C_QP_DELTA, a > 0);
             for (int i = 1; i < 5 && i <= a; i++) enc_bin(c, C_QP_DELTA + 1, i < a);
-            if (a >= 5) { /* suffix EG0 of a - 5: never produced by this writer (|d| <= 3) */ }
+            if (a >= 5) {                                  /* suffix: 0-th order Exp-Golomb of a - 5, bypass bins (9.3.3.10) */
+                int v = a - 5, k = 0;
+                while (v >= (1 << k)) { enc_bypass(c, 1); v -= 1 << k; k++; }
+                enc_bypass(c, 0);
+                enc_bypass_bits(c, (uint32_t)v, k);
+            }
             tr(OH_SE_QP_DELTA_ABS, a);
             if (a) { enc_bypass(c, d < 0); tr(OH_SE_QP_DELTA_SIGN, d < 0); }
             w->qp_delta_pending = 0;

@@ -530,15 +530,17 @@ def test_intra_wave_layouts(waves, phases):
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("rows", [0, 1])
-def test_intra_rows_and_levels(rows):
+@pytest.mark.parametrize("rows,res_lds", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_intra_rows_and_levels(rows, res_lds):
     """a picture whose wavefront is (nearly) full — an I picture — runs its intra pass as CTU rows in one launch
     (intra_rows_kernel) while the batch's rows leave the chip room, as one launch per level otherwise; OHEVC_INTRA_ROWS=0
-    forces the levels.  Both ways over the same I / B pictures (child process: the switch is read once)."""
+    forces the levels.  The CTUs' residual spans are staged in LDS in launches the chip holds at once, fetched per block from HBM in
+    the prepare stage in wider ones; OHEVC_INTRA_RES_LDS forces one way.  All four combinations over the same I / B pictures (child
+    process: the switches are read once)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, OHEVC_INTRA_ROWS=str(rows))
+    env = dict(os.environ, OHEVC_INTRA_ROWS=str(rows), OHEVC_INTRA_RES_LDS=str(res_lds))
     env.pop("OHEVC_INTRA_WAVES", None)
     env.pop("OHEVC_INTRA_PHASES", None)
     r = subprocess.run([sys.executable, "-c", _WAVES_SCRIPT.format(tests=here, root=os.path.dirname(here))], env=env,

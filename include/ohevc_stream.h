@@ -68,6 +68,7 @@ typedef struct OhStreamParams {
     int32_t pcm_loop_filter;            /* 1: pcm_loop_filter_disabled_flag = 0 (PCM blocks are deblocked like any other) */
     int32_t chroma_qp_offsets;          /* 1: pps_cb_qp_offset / pps_cr_qp_offset from the next two fields (-12..12) instead of +1 / -2 */
     int32_t cb_qp_offset, cr_qp_offset;
+    int32_t sao_offset_scale_luma, sao_offset_scale_chroma;   /* log2_sao_offset_scale_* of the pps_range_extension: 0 .. bit_depth - 10 (so: 12 bit only) */
     int32_t log2_min_cb_size;           /* 0 (= 3) or 3..5: smallest coding block (width and height are multiples of it); above 8x8 its inter
                                            partitions include NxN, its min PU / QP / PCM map granularity follows */
 } OhStreamParams;

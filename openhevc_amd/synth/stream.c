@@ -454,7 +454,7 @@ static void write_pps(W *w)
         if (p->transform_skip) put_ue(&b, (uint32_t)(max_tskip(p) - 2));   /* log2_max_transform_skip_block_size_minus2 */
         put_bit(&b, p->cross_component_pred != 0);
         put_bit(&b, 0);                                    /* chroma_qp_offset_list_enabled_flag */
-        put_ue(&b, 0); put_ue(&b, 0);                      /* log2_sao_offset_scale_luma / chroma */
+        put_ue(&b, (uint32_t)p->sao_offset_scale_luma); put_ue(&b, (uint32_t)p->sao_offset_scale_chroma);   /* log2_sao_offset_scale_luma / chroma (0 .. bit depth - 10) */
     } else {
         put_bit(&b, 0);                                    /* pps extension */
     }
@@ -1387,6 +1387,11 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
         return -1;                                         /* the picture is a whole number of smallest coding blocks; the smallest transform block is smaller than they are */
     if (p->max_th_depth_intra > p->log2_ctb_size - p->log2_min_tb_size || p->max_th_depth_inter > p->log2_ctb_size - p->log2_min_tb_size)
         return -1;                                         /* 7.4.3.2.1: the transform hierarchy cannot be deeper than CTB / smallest transform block */
+    {
+        const int smax = p->bit_depth > 10 ? p->bit_depth - 10 : 0;
+        if (p->sao_offset_scale_luma < 0 || p->sao_offset_scale_luma > smax || p->sao_offset_scale_chroma < 0 || p->sao_offset_scale_chroma > smax)
+            return -1;                                     /* 7.4.3.3.2 */
+    }
     if (p->chroma_format_idc == 2 && p->log2_min_tb_size > 2)
         return -1;                                         /* 4:2:2's second chroma block of a transform unit sits HALF a min-TB down when that is 8x8 or more; the reference
                                                               derives intra availability in whole min-TBs (hevcpred_template.c:73-109), calls its up-right neighbour

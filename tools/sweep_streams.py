@@ -36,6 +36,8 @@ def draw(rng):
         kw["pcm"] = 1
     if kw.get("pcm"):
         kw["pcm_loop_filter"] = rng.choice([0, 1])
+    if kw["bit_depth"] == 12 and kw["sao"] and rng.random() < 0.6:
+        kw.update(sao_offset_scale_luma=rng.randint(0, 2), sao_offset_scale_chroma=rng.randint(0, 2))
     if rng.random() < 0.4:
         kw.update(chroma_qp_offsets=1, cb_qp_offset=rng.randint(-12, 12), cr_qp_offset=rng.randint(-12, 12))
     mcb = min(lc, rng.choice([3, 3, 3, 4, 5]))                 # smallest coding block: the picture is a whole number of them

@@ -428,6 +428,51 @@ def test_shvc_upsample_pictures(eng):
     eng.pic_free(b)
 
 
+def _random_up_geometries(seed, count):
+    """(base layer size, enhancement layer size, scaled reference layer offsets, phase alignment): ratios 1 .. 2, sizes in units of 8"""
+    import random
+    rng = random.Random(seed)
+    for _ in range(count):
+        wb, hb = 8 * rng.randint(4, 60), 8 * rng.randint(3, 40)
+        r = rng.choice([1.0, 1.5, 2.0, rng.uniform(1.0, 2.0), rng.uniform(1.0, 2.0)])
+        we, he = max(wb, int(wb * r) // 8 * 8), max(hb, int(hb * r) // 8 * 8)
+        win = tuple(2 * rng.randint(0, 6) if rng.random() < 0.5 else 0 for _ in range(4))
+        if we - win[0] - win[1] < wb or he - win[2] - win[3] < hb:
+            win = (0, 0, 0, 0)
+        yield (wb, hb), (we, he), win, rng.choice([0, 0, 1])
+
+
+def test_shvc_upsample_random_geometries(eng):
+    """oh_pic_upsample over random base / enhancement layer geometries (ratios 1 .. 2, scaled reference layer offsets, phase
+    alignment) against the checker — which tests/test_upsample_vs_ref.py holds against the reference's slot on the same sweep"""
+    from oracle_lib import OhHostPicC
+    n = 0
+    for (wb, hb), (we, he), win, pa in _random_up_geometries(4711, 60):
+        u = F.upsample_setup(wb, hb, we, he, win, pa)
+        pb, pe = F.pic_params(wb, hb), F.pic_params(we, he)
+        bl = F.HostPic(pb, rng=np.random.default_rng(n))
+        want = F.HostPic(pe, fill=0)
+
+        def as_c(p, hp):
+            c_ = OhHostPicC()
+            for c, pl in enumerate(hp.planes):
+                w, h = F.plane_dims(p, c)
+                c_.data[c], c_.stride[c], c_.width[c], c_.height[c] = pl.ctypes.data, pl.strides[0], w, h
+            c_.bit_depth = 8
+            return c_
+        b_c, e_c = as_c(pb, bl), as_c(pe, want)
+        assert oracle().oh_or_upsample_frame(C.byref(b_c), C.byref(e_c), C.byref(u)) == 0
+        b_id, e_id = eng.pic_alloc(pb), eng.pic_alloc(pe)
+        eng.pic_upload(b_id, bl)
+        eng.pic_upsample(e_id, b_id, u)
+        eng.sync()
+        assert_same(want, eng.pic_download(e_id, pe), f"up-sampling {wb}x{hb} -> {we}x{he} offsets {win} phase alignment {pa}")
+        eng.pic_free(b_id)
+        eng.pic_free(e_id)
+        n += 1
+    assert n == 60
+
+
 @pytest.mark.parametrize("seed,count,max_w8,max_h8", [(20261004, 40, 34, 26), (20261005, 10, 160, 90)],
                          ids=["40_small", "10_up_to_1280x720"])
 def test_random_configurations(eng, seed, count, max_w8, max_h8):

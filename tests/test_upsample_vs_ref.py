@@ -145,3 +145,21 @@ def test_reference_paths_disagree_with_offsets_or_phase_alignment():
         u, bl, want, _ = run_frame_both(bl_size, (416, 240), win, 92, pa)
         el = run_block_path(u, bl, bl_size, (416, 240), 6)
         assert not np.array_equal(want.visible(0), el.visible(0))
+
+
+def test_frame_slot_random_geometries():
+    """the whole-picture slot over a seeded sweep of geometries (ratios 1 .. 2, offsets, phase alignment): checker == reference.
+    tests/test_gpu_parity.py runs the engine against the checker on the same kind of sweep"""
+    import random
+    rng = random.Random(3)
+    for it in range(120):
+        wb, hb = 8 * rng.randint(4, 60), 8 * rng.randint(3, 40)
+        r = rng.choice([1.0, 1.5, 2.0, rng.uniform(1.0, 2.0), rng.uniform(1.0, 2.0)])
+        we, he = max(wb, int(wb * r) // 8 * 8), max(hb, int(hb * r) // 8 * 8)
+        win = tuple(2 * rng.randint(0, 6) if rng.random() < 0.5 else 0 for _ in range(4))
+        if we - win[0] - win[1] < wb or he - win[2] - win[3] < hb:
+            win = (0, 0, 0, 0)
+        pa = rng.choice([0, 0, 1])
+        _, _, want, got = run_frame_both((wb, hb), (we, he), win, 1000 + it, pa)
+        for c in range(3):
+            assert np.array_equal(want.visible(c), got.visible(c)), ((wb, hb), (we, he), win, pa, c)

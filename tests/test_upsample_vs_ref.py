@@ -160,6 +160,10 @@ def test_frame_slot_random_geometries():
         if we - win[0] - win[1] < wb or he - win[2] - win[3] < hb:
             win = (0, 0, 0, 0)
         pa = rng.choice([0, 0, 1])
-        _, _, want, got = run_frame_both((wb, hb), (we, he), win, 1000 + it, pa)
+        u, bl, want, got = run_frame_both((wb, hb), (we, he), win, 1000 + it, pa)
         for c in range(3):
             assert np.array_equal(want.visible(c), got.visible(c)), ((wb, hb), (we, he), win, pa, c)
+        if win == (0, 0, 0, 0) and pa == 0:                 # there the reference's on-demand CTB path gives the same picture (see above)
+            el = run_block_path(u, bl, (wb, hb), (we, he), rng.choice([4, 5, 6]))
+            for c in range(3):
+                assert np.array_equal(want.visible(c), el.visible(c)), ("block path", (wb, hb), (we, he), c)

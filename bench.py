@@ -207,12 +207,13 @@ def main():
     per_chain = (args.waves * (world + 1) + max(args.tail, 1) * 2) * half_bytes       # parallel.GroupStore: other ranks' pictures keep one half
     free_b, _total_b = torch.cuda.mem_get_info()
     chains_asked = n_chains
-    if n_chains * per_chain > 0.85 * free_b:
-        n_chains = max(1, int(0.85 * free_b // per_chain))
-        if world > 1:                                      # the same number on every rank
-            t = torch.tensor([n_chains], device=torch.device("cuda", local_rank))
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            n_chains = int(t.item())
+    fits = max(1, int(0.85 * free_b // per_chain))
+    if world > 1:                                          # the same number on every rank: every rank takes part, whether it is short of memory or not
+        t = torch.tensor([fits], device=torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        fits = int(t.item())
+    if n_chains > fits:
+        n_chains = fits
         if rank == 0:
             print(f"bench.py: {chains_asked} chains x {per_chain / 1e9:.2f} GB do not fit {free_b / 1e9:.0f} GB of free HBM: {n_chains} chains in flight", file=sys.stderr)
     n_streams = max(1, min(args.streams, n_chains))

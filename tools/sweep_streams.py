@@ -17,6 +17,7 @@ import test_streams as T  # noqa: E402
 
 
 BIG = False
+TINY = False
 
 
 def draw(rng):
@@ -78,6 +79,9 @@ def draw(rng):
 
     def dim(lo, hi):
         return max(unit, 8 * rng.randint(lo, hi) // unit * unit)
+    if TINY:                                                    # --tiny: pictures of 8 .. 64 samples (one or a few CTBs, partial ones)
+        kw = {k: v for k, v in kw.items() if not k.startswith("conf_win")}
+        return unit * rng.randint(1, max(1, 64 // unit)), unit * rng.randint(1, max(1, 64 // unit)), rng.randint(1, 10 ** 6), kw
     if BIG:                                                     # --big: pictures up to 1920 x 1088 (many workgroups per pass, the CTU-row intra kernel)
         kw["n_pictures"] = min(kw["n_pictures"], 3) if kw["gop"] != 3 else 5
         return dim(40, 240), dim(30, 136), rng.randint(1, 10 ** 6), kw
@@ -191,10 +195,13 @@ def threads_sweep(count, seed):
 
 
 def main():
-    global BIG
+    global BIG, TINY
     if "--big" in sys.argv:
         BIG = True
         sys.argv.remove("--big")
+    if "--tiny" in sys.argv:
+        TINY = True
+        sys.argv.remove("--tiny")
     if len(sys.argv) > 1 and sys.argv[1] == "--threads":
         return threads_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):

@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="2160p_main10", choices=sorted(WORKLOADS),
                     help="default: the configuration BASELINE.json's metric is quoted on (4K Main10)")
-    ap.add_argument("--chains", type=int, default=None, help="closed GOPs (steps) in flight per GPU (default: 128 = batches of 32 pictures on each of the 4 streams; 24 for the 8K workloads, whose pictures are 100-200 MB)")
+    ap.add_argument("--chains", type=int, default=None, help="closed GOPs (steps) in flight per GPU (default: 128 = batches of 32 pictures on each of the 4 streams; 64 / 32 for the 8K 4:2:0 / 4:4:4 workloads, whose pictures are 100 / 200 MB)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams per GPU; the chains of one stream run in lockstep batches")
     ap.add_argument("--waves", type=int, default=4, help="reference pictures per rank and step (first is an I picture)")
     ap.add_argument("--tail", type=int, default=12, help="non-reference B pictures per rank and step")
@@ -197,7 +197,8 @@ def main():
 
     params = F.pic_params(**WORKLOADS[args.workload])
     if args.chains is None:
-        args.chains = 128 if params.width * params.height <= 3840 * 2160 else 24
+        # about 100 GB of picture buffers on one GPU: 128 4K Main 10 chains (batches of 32 on each of the 4 streams), 64 / 32 at 8K 4:2:0 / 4:4:4
+        args.chains = 128 if params.width * params.height <= 3840 * 2160 else (64 if params.chroma_format_idc != 3 else 32)
     n_chains = max(1, args.chains)
     if args.scaling == "strong" and world > 1:
         n_chains = max(1, n_chains // world)               # the same pictures per step as one GPU decodes alone, split over the ranks
@@ -205,6 +206,7 @@ def main():
     # that is free now; a default that does not fit is cut (and said so) rather than left to die in the allocator
     half_bytes = F.half_layout(params)[0]
     per_chain = (args.waves * (world + 1) + max(args.tail, 1) * 2) * half_bytes       # parallel.GroupStore: other ranks' pictures keep one half
+    per_chain += 2 * int(2.5 * half_bytes)                 # + the work lists in flight (this batch and the next): lists, prepared lists, residual pool
     free_b, _total_b = torch.cuda.mem_get_info()
     chains_asked = n_chains
     fits = max(1, int(0.85 * free_b // per_chain))

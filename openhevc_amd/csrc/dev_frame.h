@@ -59,7 +59,8 @@ struct OhIntraLaunch {                             /* one wavefront level of a b
     uint32_t level;                                /* index into DevFrame.lvl_start                           */
     uint32_t off_items, off_sub, off_small, off_res, off_wave, lds_bytes;   /* byte offsets into the dynamic LDS block */
     uint32_t waves;                                /* waves per workgroup (CTU)                               */
-    uint32_t staged;                               /* 1: every CTU of the launch has its residual span contiguous: staged in LDS */
+    uint32_t staged;                               /* 1: the CTUs' residual spans are staged in LDS (all contiguous, and the launch is one the chip holds at once);
+                                                      0: every block fetches its residual from the pool in HBM, a sub-level ahead (intra.hip: slots_prepare) */
     uint32_t phases;                               /* sub-level s is finished by the waves with wave % phases == s % phases; >= 2, divides waves */
 };
 

@@ -1169,9 +1169,9 @@ static bool res_in_lds(const OhEngine *e, uint64_t workgroups)
 {
     static const char *env = getenv("OHEVC_INTRA_RES_LDS");
     if (env) return atoi(env) != 0;
-    /* a launch the chip holds at once is latency-bound: stage (a 4K I picture alone 6.6 ms against 7.0); a launch of many more
-     * workgroups than fit runs at workgroups-per-CU x latency: keep the LDS small (4-stream bench: intra pass -5 %) */
-    return workgroups <= 5ull * (uint64_t)e->n_cu;
+    /* a launch of at most a workgroup per CU is latency-bound: stage (a 4K I picture alone 6.6 ms against 7.0); any wider one runs at
+     * workgroups-per-CU x latency: keep the LDS small (all-intra batches 39.8 against 37.6 Gpix/s, the mixed bench +0.6 %) */
+    return workgroups <= (uint64_t)e->n_cu;
 }
 
 extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)

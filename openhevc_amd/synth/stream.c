@@ -1385,6 +1385,9 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     if (mcb_log2 < 3 || mcb_log2 > 5 || mcb_log2 > p->log2_ctb_size || (p->width & ((1 << mcb_log2) - 1)) || (p->height & ((1 << mcb_log2) - 1)) ||
         (p->pcm && mcb_log2 > (p->log2_ctb_size < 5 ? p->log2_ctb_size : 5)) || p->log2_min_tb_size >= mcb_log2)
         return -1;                                         /* the picture is a whole number of smallest coding blocks; the smallest transform block is smaller than they are */
+    if (p->conf_win_left < 0 || p->conf_win_right < 0 || p->conf_win_top < 0 || p->conf_win_bottom < 0 ||
+        p->conf_win_left + p->conf_win_right >= p->width || p->conf_win_top + p->conf_win_bottom >= p->height)
+        return -1;                                         /* the conformance window leaves a picture */
     if (p->max_th_depth_intra > p->log2_ctb_size - p->log2_min_tb_size || p->max_th_depth_inter > p->log2_ctb_size - p->log2_min_tb_size)
         return -1;                                         /* 7.4.3.2.1: the transform hierarchy cannot be deeper than CTB / smallest transform block */
     {

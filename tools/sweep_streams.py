@@ -77,6 +77,12 @@ def draw(rng):
         kw["mvd_range"] = rng.choice([8, 600, 4000])
     unit = 1 << mcb
 
+    def fit_window(w, h):                                       # a window that leaves at least 8 x 8 samples
+        if kw.get("conf_win_left", 0) + kw.get("conf_win_right", 0) > w - 8 or kw.get("conf_win_top", 0) + kw.get("conf_win_bottom", 0) > h - 8:
+            for k in ("conf_win_left", "conf_win_right", "conf_win_top", "conf_win_bottom"):
+                kw.pop(k, None)
+        return w, h
+
     def dim(lo, hi):
         return max(unit, 8 * rng.randint(lo, hi) // unit * unit)
     if TINY:                                                    # --tiny: pictures of 8 .. 64 samples (one or a few CTBs, partial ones)
@@ -84,8 +90,8 @@ def draw(rng):
         return unit * rng.randint(1, max(1, 64 // unit)), unit * rng.randint(1, max(1, 64 // unit)), rng.randint(1, 10 ** 6), kw
     if BIG:                                                     # --big: pictures up to 1920 x 1088 (many workgroups per pass, the CTU-row intra kernel)
         kw["n_pictures"] = min(kw["n_pictures"], 3) if kw["gop"] != 3 else 5
-        return dim(40, 240), dim(30, 136), rng.randint(1, 10 ** 6), kw
-    return dim(2, 40), dim(2, 30), rng.randint(1, 10 ** 6), kw
+        return fit_window(dim(40, 240), dim(30, 136)) + (rng.randint(1, 10 ** 6), kw)
+    return fit_window(dim(2, 40), dim(2, 30)) + (rng.randint(1, 10 ** 6), kw)
 
 
 def harness_sweep(count, seed, extra=(), min_ctb=4):

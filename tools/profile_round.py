@@ -5,6 +5,7 @@ usage: profile_round.py STATS_DIR FETCH_DIR WRITE_DIR OUT_DIR TAG
   FETCH_DIR  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv      (own pass)
   WRITE_DIR  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv      (own pass)
 Writes OUT_DIR/{TAG_kernel_stats.csv, TAG_pmc_fetch_summary.csv, TAG_pmc_write_summary.csv, TAG_pmc_traffic.json}.
+FETCH_DIR / WRITE_DIR "-": only the kernel stats are written.
 HBM bytes per launch = FETCH_SIZE[KiB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE[KiB] x 1024."""
 import collections
 import csv
@@ -53,6 +54,8 @@ def main():
         for r in rows:
             w.writerow([short(r["Name"]), int(r["Calls"]), int(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["Percentage"]),
                         int(r["MinNs"]), int(r["MaxNs"])])
+    if fetch_dir == "-" or write_dir == "-":                    # kernel stats only (no counter passes in this run)
+        return
     fe = pmc_summary(fetch_dir, "FETCH_SIZE", os.path.join(out_dir, f"{tag}_pmc_fetch_summary.csv"))
     wr = pmc_summary(write_dir, "WRITE_SIZE", os.path.join(out_dir, f"{tag}_pmc_write_summary.csv"))
     traffic = {}

@@ -114,8 +114,17 @@ struct DevLevelStat {                 /* one intra wavefront level: what sizes t
 struct DevSummary {
     uint32_t err, err_item;           /* OH_PE_*, index of the offending item */
     uint32_t tu_cnt[4], n_cross, n_levels;
+    uint32_t intra_area64, max_passes;/* samples the intra blocks cover / 64 (all planes); wave passes of the heaviest schedule entry */
     /* DevLevelStat[n_levels] follows */
 };
+/* DevFrame.ctu_aux[k] */
+enum { OH_AUX_PASSES = 0xffff,        /* wave passes of the entry: groups of four <= 8x8 blocks + the bigger blocks */
+       OH_AUX_DEP_SHIFT = 16,         /* bits 16..19: a block of the entry gathers samples of the left / up-left / up / up-right CTU */
+       OH_AUX_WAITS = 1u << 29,       /* ctu_wait[] of the entry holds at least one entry */
+       OH_AUX_AWAITED = 1u << 30,     /* another entry waits for this one: it must publish its samples (release) and set ctu_done */
+       OH_AUX_RES_SCATTERED = 1u << 31 };   /* its residual blocks do not lie together in the pool: not stageable in LDS */
+/* kernel-side failures latched in OhEngine's error word (reported by oh_engine_sync and everything that waits for the stream) */
+enum { OH_KE_OK = 0, OH_KE_ROW_TIMEOUT = 1, OH_KE_DAG_TIMEOUT = 2 };
 struct OhPrepCounts { uint32_t n_pu, n_mc_luma, n_mc_chroma, n_tu, n_intra, n_sub, n_ictu, n_levels; };
 
 struct DevFrame {
@@ -164,7 +173,16 @@ struct DevFrame {
     uint32_t *sub_small_w;            /* = sub_small, writable */
     uint32_t *ctu_seen;               /* [CTBs]: index + 1 of the schedule entry the CTU heads (one at most), 0: no intra block in it */
     uint32_t *row_progress;           /* [CTB rows]: CTUs of the row finished by intra_rows_kernel */
-    uint32_t *ctu_aux;                /* [n_ictu]: wave passes of the entry | its residual is not stageable << 31 */
+    uint32_t *ctu_aux;                /* [n_ictu]: OH_AUX_*: wave passes of the entry, the neighbour CTUs its blocks read, flags */
+    /* the schedule as a dependency graph (intra.hip: intra_dag_kernel / intra_direct_kernel run a whole picture in ONE launch):
+     * entry k starts once the entries ctu_wait[4k .. 4k+3] (left, up-left, up, up-right neighbour CTUs of a LOWER level; ~0: none)
+     * have set their ctu_done word; written by prep_intra_wait, ctu_done cleared before every execution */
+    uint32_t *ctu_wait;               /* [n_ictu][4] */
+    uint32_t *ctu_done;               /* [n_ictu] */
+    uint32_t *ctu_lvl;                /* [n_ictu]: wavefront level of the entry (scratch of the preparation) */
+    uint32_t *ctu_order;              /* [n_ictu]: dispatch order of intra_direct_kernel: entries on dependency chains first (prep_intra_order) */
+    uint32_t *err_word;               /* pinned host memory of the engine: [0] OH_KE_* of the first kernel-side failure, [1] cur_pic, [2] entry / row */
+    int32_t   cur_pic_id;             /* for the error report */
     void     *summary;                /* DevSummary + DevLevelStat[n_levels] */
     void     *summary_host;           /* pinned host copy, written by prep_finish (no D2H copy on the stream) */
     uint32_t *zero_ptr; uint32_t zero_words;      /* scratch the preparation starts from cleared (prep_clear) */

@@ -59,6 +59,7 @@ struct OhDevFrame {
     void      *sum_dev = nullptr; /* the summary in the arena */
     OhPrepCounts cnt{};           /* sizes of the preparation launches */
     uint32_t   prep_err = 0, n_levels = 0;
+    uint32_t   intra_area64 = 0, max_passes = 0;   /* from the summary: samples of the intra blocks / 64; wave passes of the heaviest CTU */
     const struct OhEngine *owner = nullptr;   /* picture ids and arenas belong to one engine */
     struct Level {                        /* one wavefront level: what sizes the launch that runs it */
         uint32_t n_ctu, max_items, max_sub, max_res;
@@ -100,6 +101,11 @@ struct OhEngine {
     uint64_t    host_calls[OH_N_HOST_TIMES] = {};
     uint64_t    up_bytes = 0;                    /* bytes of work lists sent over PCIe since the last reset */
     uint64_t   *dbg = nullptr;           /* diagnostics (OHEVC_STAMPS=1 + a -DOH_STAMPS build) */
+    /* what a kernel can tell the host when it cannot go on (the table slots and the passes have no error channel: hevcdsp.h's slots
+     * return void): four words of pinned host memory, [0] OH_KE_* of the first failure, [1] picture id, [2] schedule entry / CTB
+     * row; read by everything that waits for the stream (kernel_error) */
+    uint32_t   *kerr = nullptr;
+    uint32_t    spin_limit = 1u << 22;   /* polls (with s_sleep between them, ~1 s in all) before a waiting workgroup gives up; OHEVC_SPIN_LIMIT */
 };
 
 #define HIPCHK(e, call)                                                                           \
@@ -122,6 +128,19 @@ struct OhEngine {
     } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* after a wait on the engine's stream: did a kernel latch a failure (intra.hip: dag_latch_error)?  Reported once, then cleared. */
+static int kernel_error(OhEngine *e)
+{
+    if (!e->kerr || !e->kerr[0])
+        return OH_OK;
+    const uint32_t code = e->kerr[0], pic = e->kerr[1], where = e->kerr[2];
+    e->kerr[0] = 0;
+    FAIL(e, OH_E_HIP, code == OH_KE_ROW_TIMEOUT
+             ? "intra pass (CTB rows in one launch): picture %u, CTB row %u gave up waiting for the row above; the picture's samples are not valid"
+             : "intra pass (one launch per picture): picture %u, schedule entry %u gave up waiting for a neighbour CTU; the picture's samples are not valid",
+         pic, where);
+}
 struct HostTimer {                       /* adds the scope's wall time to one slot of OhEngine::host_ms */
     OhEngine *e; int slot; std::chrono::steady_clock::time_point t0;
     HostTimer(OhEngine *e_, int slot_);
@@ -186,6 +205,14 @@ static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_e
     }
     if (hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || e->n_cu <= 0)
         e->n_cu = 256;
+    if (hipHostMalloc((void **)&e->kerr, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        fprintf(stderr, "ohevc_hip: no pinned memory for the kernels' error word\n");
+        delete e;
+        return OH_E_HIP;
+    }
+    memset(e->kerr, 0, 4 * sizeof(uint32_t));
+    if (const char *sl = getenv("OHEVC_SPIN_LIMIT"))          /* tests: make a waiting workgroup give up at once */
+        e->spin_limit = (uint32_t)std::max(1l, atol(sl));
     if (getenv("OHEVC_STAMPS")) {
         const size_t bytes = (16 + 4000 * 16) * sizeof(uint64_t);
         if (hipMalloc((void **)&e->dbg, bytes) == hipSuccess)
@@ -268,7 +295,7 @@ extern "C" int oh_engine_sync(OhEngine *e)
     for (OhDevFrame *df : e->deferred)
         free_dev_frame(e, df);
     e->deferred.clear();
-    return OH_OK;
+    return kernel_error(e);
 }
 
 extern "C" void oh_engine_destroy(OhEngine *e)
@@ -293,6 +320,7 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &a : e->arenas) { if (a.free_ev) (void)hipEventDestroy(a.free_ev); (void)hipFree(a.p); }
     for (auto &ev : e->sync_events) (void)hipEventDestroy(ev);
     for (void *b : e->sum_pool) (void)hipHostFree(b);
+    if (e->kerr) (void)hipHostFree(e->kerr);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->own_stream)
         (void)hipStreamDestroy(e->stream);
@@ -547,6 +575,7 @@ extern "C" int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3]
         HIPCHK(e, hipMemcpy2DAsync(planes[c], (size_t)strides[c], p->final_b ? p->b[c] : p->a[c], (size_t)p->stride[c] * bpp,
                                    (size_t)p->w[c] * bpp, (size_t)p->h[c], hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    { const int ke = kernel_error(e); if (ke) return ke; }     /* a kernel that gave up: these samples are not the picture */
     return OH_OK;
 }
 
@@ -635,6 +664,7 @@ extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *w
         HIPCHK(e, hipMemcpy2DAsync((char *)sg->p + off[c], row[c], src, (size_t)p->stride[c] * bpp, row[c], rows[c], hipMemcpyDeviceToHost, e->stream));
     }
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    { const int ke = kernel_error(e); if (ke) return ke; }     /* a kernel that gave up: these samples are not the picture */
     for (int c = 0; c < np; c++) {
         const char *s = (const char *)sg->p + off[c];
         if ((size_t)strides[c] == row[c])
@@ -680,6 +710,7 @@ extern "C" int oh_pics_md5(OhEngine *e, const int *pic_ids, int n, uint8_t *dige
     ohk_md5(jobs, nj, out, e->stream);                        /* pinned host memory is mapped: the kernel reads the jobs and writes the digests there */
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    { const int ke = kernel_error(e); if (ke) return ke; }     /* a kernel that gave up: these samples are not the picture */
     for (size_t k = 0; k < slot.size(); k++) {
         if (slot[k] >= 0) memcpy(digests + k * 16, out + (size_t)slot[k] * 16, 16);
         else memset(digests + k * 16, 0, 16);
@@ -846,11 +877,11 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
 
     /* arena: [copied: header, raw lists, side arrays, coefficient pool] [device only: prepared lists, scratch, residual pool] */
     struct Seg { const void *src; size_t bytes, off; size_t pack_n; };     /* pack_n != 0: src holds pack_n boundary strengths, one per byte */
-    Seg seg[48];
+    Seg seg[56];
     int ns = 0;
     size_t total = 0;
     auto add = [&](const void *src, size_t bytes) {
-        if (ns >= 48) abort();                                  /* a segment was added without growing seg[] */
+        if (ns >= 56) abort();                                  /* a segment was added without growing seg[] */
         seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].off = total; seg[ns].pack_n = 0;
         total += align_up(bytes ? bytes : 1, 256);
         return ns++;
@@ -914,6 +945,10 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     int s_small = add(nullptr, (size_t)cnt.n_sub * sizeof(uint32_t));
     int s_perm = add(nullptr, (size_t)f->n_intra * sizeof(uint32_t));
     int s_rowp = add(nullptr, cnt.n_intra ? (size_t)oh_ctb_height(&p) * sizeof(uint32_t) : 0);
+    int s_wait = add(nullptr, (size_t)cnt.n_ictu * 4 * sizeof(uint32_t));
+    int s_done = add(nullptr, (size_t)cnt.n_ictu * sizeof(uint32_t));
+    int s_clvl = add(nullptr, (size_t)cnt.n_ictu * sizeof(uint32_t));
+    int s_cord = add(nullptr, (size_t)cnt.n_ictu * sizeof(uint32_t));
     const size_t res_off = total;
     total += align_up((size_t)(f->n_coeff ? f->n_coeff : 1) * sizeof(int16_t), 256);
     const bool stale_cfg = has_db && has_sao && oh_sao_stale_config(&p);       /* see DevFrame.sao_stale */
@@ -998,6 +1033,8 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.pu_off = AT(const uint32_t *, s_puoff); hd.ctu_aux = AT(uint32_t *, s_aux); hd.tu_keep = AT(uint8_t *, s_keep); hd.tu_cursor = AT(uint32_t *, s_cursor);
     hd.intra_perm = AT(uint32_t *, s_perm); hd.ctu_seen = AT(uint32_t *, s_seen); hd.summary = AT(void *, s_sum);
     hd.row_progress = AT(uint32_t *, s_rowp);
+    hd.ctu_wait = AT(uint32_t *, s_wait); hd.ctu_done = AT(uint32_t *, s_done); hd.ctu_lvl = AT(uint32_t *, s_clvl); hd.ctu_order = AT(uint32_t *, s_cord);
+    hd.err_word = e->kerr; hd.cur_pic_id = f->cur_pic;
 #undef AT
     hd.n_pu = f->n_pu; hd.n_mc_luma = cnt.n_mc_luma; hd.n_mc_chroma = cnt.n_mc_chroma; hd.n_tu = f->n_tu; hd.n_intra = f->n_intra;
     hd.n_ictu = cnt.n_ictu; hd.n_sub = cnt.n_sub; hd.n_levels = cnt.n_levels; hd.n_wp = f->n_wp; hd.n_sparse = f->sparse ? f->n_sparse : 0;
@@ -1149,6 +1186,7 @@ static int read_summary(OhEngine *e, OhDevFrame *df, int index)
     for (int k = 0; k < 4; k++)
         if (s->tu_cnt[k] != df->tu_cnt[k])
             FAIL(e, OH_E_ARG, "work list %d: transform block counts changed between hand-over and preparation", index);
+    df->intra_area64 = s->intra_area64; df->max_passes = s->max_passes;
     const DevLevelStat *ls = (const DevLevelStat *)(s + 1);
     df->levels.resize(df->n_levels);
     for (uint32_t l = 0; l < df->n_levels; l++) {
@@ -1292,6 +1330,86 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
         }
         MARK(OH_PASS_RESIDUAL);
         const OhCtuAreas areas = oh_ctu_areas(p->log2_ctb_size, p->chroma_format_idc);
+        /* How the intra pass of each picture runs (intra.hip):
+         *   direct  one launch, a wave per CTU working on the picture in HBM — pictures whose intra blocks cover less than half of
+         *           their samples (B / P pictures);
+         *   dag     one launch, a workgroup per CTU with the CTU staged in LDS, CTUs waiting for their neighbours' flags — the
+         *           others (I pictures);
+         *   levels  one launch per wavefront level (rounds 1-2), or CTU rows in one launch for a few deep pictures: kept for
+         *           comparison and as the form that needs nothing of the dispatcher (OHEVC_INTRA_MODE=levels).
+         * The one-launch forms never deadlock as long as the hardware hands out the workgroups of a grid in id order (per XCD):
+         * an entry only waits for lower ids.  HIP does not promise that order; it is what gfx950 does (guide: "blocks are dealt
+         * round-robin over the 8 XCDs"), every wait is bounded, and a wait that gives up is reported (kernel_error) instead of
+         * producing a silently wrong picture. */
+        static const char *menv = getenv("OHEVC_INTRA_MODE");
+        const int mode_env = !menv ? 0 : !strcmp(menv, "levels") ? 1 : !strcmp(menv, "dag") ? 2 : !strcmp(menv, "direct") ? 3 : 0;
+        bool in_rows[OH_MAX_BATCH] = {};                     /* handled by a one-launch form: not in the level launches below */
+        if (mode_env != 1) {
+            OhBatch bd, bs;                                  /* direct / staged dag */
+            memset(&bd, 0, sizeof(bd)); memset(&bs, 0, sizeof(bs));
+            int nd = 0, nsd = 0;
+            uint32_t max_ictu_d = 0, max_ictu_s = 0, max_ictu_all = 0, max_items = 1, max_sub = 1, max_res = 0;
+            uint64_t sum_items = 0, sum_sub = 0, total_entries = 0;
+            bool staged = true;
+            const uint64_t pic_samples64 = ((uint64_t)p->width * p->height * (p->chroma_format_idc == 0 ? 2 : p->chroma_format_idc == 1 ? 3 : p->chroma_format_idc == 2 ? 4 : 6) / 2) >> 6;
+            for (int i = 0; i < nb; i++) {
+                if (fr[i]->levels.empty())
+                    continue;
+                in_rows[i] = true;
+                max_ictu_all = std::max(max_ictu_all, fr[i]->cnt.n_ictu);
+                const bool sparse = mode_env == 3 || (mode_env == 0 && (uint64_t)fr[i]->intra_area64 * 2 < pic_samples64);
+                if (sparse) {
+                    bd.f[nd++] = fr[i]->d;
+                    max_ictu_d = std::max(max_ictu_d, fr[i]->cnt.n_ictu);
+                    continue;
+                }
+                bs.f[nsd++] = fr[i]->d;
+                max_ictu_s = std::max(max_ictu_s, fr[i]->cnt.n_ictu);
+                total_entries += fr[i]->cnt.n_ictu;
+                for (const OhDevFrame::Level &L : fr[i]->levels) {
+                    max_items = std::max(max_items, L.max_items); max_sub = std::max(max_sub, L.max_sub); max_res = std::max(max_res, L.max_res);
+                    sum_items += L.sum_items; sum_sub += L.sum_sub;
+                    staged = staged && (L.staged || !L.n_ctu);
+                }
+            }
+            hipEvent_t a = nullptr, b = nullptr;
+            if (prof_launch && (nd || nsd)) {                 /* the pass's launches as one bracket: they overlap nothing else on this stream */
+                for (hipEvent_t *pe : { &a, &b }) {
+                    if (!e->lev_pool.empty()) { *pe = e->lev_pool.back(); e->lev_pool.pop_back(); }
+                    else HIPCHK(e, hipEventCreate(pe));
+                }
+            }
+            if (nd || nsd)
+                ohk_intra_dag_reset(&all, nb, max_ictu_all, st);
+            if (a) HIPCHK(e, hipEventRecord(a, st));
+            if (nd)
+                ohk_intra_direct(&bd, nd, p, max_ictu_d, e->spin_limit, st);
+            if (nsd) {
+                OhIntraLaunch IL;
+                /* residual spans in LDS only while the chip holds the whole launch (a picture alone); else the blocks fetch theirs a sub-level ahead */
+                IL.staged = staged && res_in_lds(e, total_entries / 8);
+                IL.level = 0;
+                const double par = sum_sub ? (double)sum_items / (double)sum_sub : 1.0;
+                IL.waves = wenv ? (uint32_t)atoi(wenv) : par > (nb < 8 ? 2.5 : 4.5) ? 8 : par > 1.25 ? 4 : 2;
+                if (IL.waves != 2 && IL.waves != 4 && IL.waves != 8) IL.waves = 8;
+                static const char *penv = getenv("OHEVC_INTRA_PHASES");
+                IL.phases = penv ? (uint32_t)atoi(penv) : 2u;
+                if (IL.phases < 2 || IL.phases > IL.waves || IL.waves % IL.phases) IL.phases = 2;
+                size_t off = align_up((size_t)areas.total * sizeof(uint16_t), 16);
+                IL.off_items = (uint32_t)off; off += (size_t)max_items * sizeof(DevIntra);
+                IL.off_sub = (uint32_t)off;   off += ((size_t)max_sub + 1) * sizeof(uint32_t);
+                IL.off_small = (uint32_t)off; off = align_up(off + (size_t)max_sub * sizeof(uint32_t), 16);
+                IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)(IL.staged ? max_res : 0) * sizeof(int16_t), 16);
+                IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
+                IL.lds_bytes = (uint32_t)off;
+                ohk_intra_dag(&bs, nsd, p, &IL, max_ictu_s, e->spin_limit, st);
+            }
+            if (b) {
+                HIPCHK(e, hipEventRecord(b, st));
+                e->lev_pending.push_back(a);
+                e->lev_pending.push_back(b);
+            }
+        }
         /* pictures whose levels are (nearly) the full CTU wavefront — I pictures — may run as CTU rows in ONE launch (intra.hip:
          * intra_rows_kernel): their cost is then the critical path at the average CTU length, not the sum of the levels' slowest
          * CTUs plus a launch per level (4K I picture alone: 6.6 ms against 9.1 ms).  A row's workgroup holds its slot while it
@@ -1300,8 +1418,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
          * handful of levels (measured: 32 I pictures per batch as rows cost the 4-stream bench 22 %). */
         static const char *renv = getenv("OHEVC_INTRA_ROWS");
         const size_t row_threshold = renv && !atoi(renv) ? (size_t)-1 : (size_t)oh_ctb_width(p);
-        bool in_rows[OH_MAX_BATCH] = {};
-        {
+        if (mode_env == 1) {
             OhBatch rows;
             memset(&rows, 0, sizeof(rows));
             int nr = 0;
@@ -1340,7 +1457,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
                     }
                     HIPCHK(e, hipEventRecord(a, st));
                 }
-                ohk_intra_rows(&rows, nr, p, &IL, st);
+                ohk_intra_rows(&rows, nr, p, &IL, e->spin_limit, st);
                 if (prof_launch) {
                     HIPCHK(e, hipEventRecord(b, st));
                     e->lev_pending.push_back(a);

@@ -50,6 +50,63 @@ static __device__ __forceinline__ void put4(uint16_t *__restrict__ lds, int v0, 
     *(uint2v *)lds = uint2v{ (unsigned)(v0 | (v1 << 16)), (unsigned)(v2 | (v3 << 16)) };
 }
 
+/* four samples as ONE write-through store (global_store_dword / dwordx2 sc1): what a CTU hands to another CTU of the same launch
+ * leaves the XCD's L2 with the store itself, so the hand-off needs no agent-scope release (buffer_wbl2 writes back every dirty
+ * line of the L2: measured, it doubled the launch) — the producer drains its stores and sets its flag, the consumer keeps its
+ * acquire (CDNA4 guide, inter-workgroup visibility: valid forms) */
+template <typename PX>
+static __device__ __forceinline__ void store4_wt(GLOBAL PX *p, int a, int b, int c, int d)
+{
+    if (sizeof(PX) == 1)
+        __hip_atomic_store((GLOBAL uint32_t *)p, (uint32_t)(a | (b << 8) | (c << 16) | (d << 24)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        __hip_atomic_store((GLOBAL uint64_t *)p, (uint64_t)(uint32_t)(a | (b << 16)) | (uint64_t)(uint32_t)(c | (d << 16)) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* Where the CTU's samples live while the pass works on it.
+ *   staged  the CTU's copy in LDS (16-bit entries, layout dev_frame.h: oh_ctu_areas); a block's cm_off / top_off / rs come resolved
+ *           in its descriptor; entry 0 holds 1 << (bit_depth - 1), the substitute when no neighbour exists at all (:251-257);
+ *   direct  the picture itself in HBM (intra_direct_kernel: a wave per CTU, nothing staged): indices are samples from the first
+ *           sample of plane 0 — the three planes of a picture half lie in one allocation (engine.hip: pic_layout) — derived from
+ *           the block's position; index -1 stands for the substitute. */
+template <typename PX, bool DIRECT> struct Samples;
+template <typename PX> struct Samples<PX, false> {
+    uint16_t *__restrict__ M;
+    static constexpr int NONE = 0;
+    __device__ __forceinline__ int ld(int i) const { return M[i]; }
+    __device__ __forceinline__ void st4(int i, int v0, int v1, int v2, int v3) const { put4(M + i, v0, v1, v2, v3); }
+    __device__ __forceinline__ void st1(int i, int v) const { M[i] = (uint16_t)v; }
+};
+template <typename PX> struct Samples<PX, true> {
+    GLOBAL PX *g;
+    int mid;
+    bool wt;                                             /* wave-uniform: another CTU of this launch waits for these samples: store them write-through */
+    static constexpr int NONE = -1;
+    __device__ __forceinline__ int ld(int i) const { const int v = g[max(i, 0)]; return i < 0 ? mid : v; }
+    __device__ __forceinline__ void st4(int i, int v0, int v1, int v2, int v3) const
+    {
+        if (wt) store4_wt<PX>(g + i, v0, v1, v2, v3); else store4<PX>(g + i, v0, v1, v2, v3);
+    }
+    __device__ __forceinline__ void st1(int i, int v) const
+    {
+        if (wt) __hip_atomic_store(g + i, (PX)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else g[i] = (PX)v;
+    }
+};
+/* direct: where a block's samples are (cm = its sample (0,0), top = the row above, rs = row stride), from its position */
+struct PlaneGeo { int off1, off2, st0, st1; };             /* sample offsets of planes 1, 2 from plane 0; strides of luma / chroma */
+template <bool DIRECT>
+static __device__ __forceinline__ void block_geo(const PlaneGeo &G, const uint32_t w0, const uint32_t w1, const uint32_t w3, const uint32_t w4, int &cm_off, int &top_off, int &rs)
+{
+    if (DIRECT) {
+        const int bx = w0 & 0xffff, by = w0 >> 16, ci = w1 & 0xff;
+        rs = ci ? G.st1 : G.st0;
+        cm_off = (ci == 0 ? 0 : ci == 1 ? G.off1 : G.off2) + __mul24(by, rs) + bx;
+        top_off = cm_off - rs;
+    } else {
+        cm_off = w3 & 0xffff; top_off = w3 >> 16; rs = w4 & 0xffff;
+    }
+}
+
 /* constrained_intra_pred (hevcpred_template.c:185-286) for one block, lane-parallel.  Lane i owns left[i] and top[i] (i = 0..63) as
  * gathered with the re-derived candidate flags (unavailable entries hold the reference's memset value); lm1 / tm1 are left[-1] /
  * top[-1].  lm / tm: bit g = the 4-sample group g of the left column / top row lies in an intra CU; corner_intra likewise.
@@ -140,21 +197,22 @@ static __device__ __forceinline__ void cip_lanes(int &Lv, int &Tv, int &corner, 
     corner = lm1;                                                           /* top[-1] = left[-1] */
 }
 
-template <typename PX, bool CIP, bool STAGED>
+template <typename PX, bool CIP, bool STAGED, bool DIRECT>
 static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ f, const int bd,
-                                                   const uint4v *__restrict__ item, IntraLds &s, uint16_t *__restrict__ M,
+                                                   const uint4v q0, const uint4v q1, IntraLds &s, const Samples<PX, DIRECT> S, const PlaneGeo &G,
                                                    const int16_t *__restrict__ res_lds_base, const int lane, unsigned long long *acc)
 {
     unsigned long long ta = 0, tb = 0, tc = 0, td = 0; (void)ta; (void)tb; (void)tc; (void)td; (void)acc;
     STAMP(ta);
     /* the descriptor is the same for every lane: keep it in scalar registers */
-    const uint4v q0 = item[0], q1 = item[1];
     const uint32_t w0 = __builtin_amdgcn_readfirstlane(q0[0]), w1 = __builtin_amdgcn_readfirstlane(q0[1]);
     const uint32_t res_off = __builtin_amdgcn_readfirstlane(q0[2]), w3 = __builtin_amdgcn_readfirstlane(q0[3]);
     const uint32_t w4 = __builtin_amdgcn_readfirstlane(q1[0]), w5 = __builtin_amdgcn_readfirstlane(q1[1]);
     const uint32_t res_lds = __builtin_amdgcn_readfirstlane(q1[2]);
     const int bx = w0 & 0xffff, by = w0 >> 16, log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
-    const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    const int tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    int cm_off, top_off, rs;
+    block_geo<DIRECT>(G, w0, w1, w3, w4, cm_off, top_off, rs);
     const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
     const int n = 1 << log2, cls = (flags >> 4) & 7;
     const uint32_t w7 = __builtin_amdgcn_readfirstlane(q1[3]);           /* cip_left | cip_top << 16 */
@@ -182,7 +240,7 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     const bool t_ok = i < n ? a_u : (i < 2 * n && a_ur), l_ok = i < n ? a_l : (i < 2 * n && a_bl);
     const int ti = i < n ? i : (i < 2 * n ? (i - n < tr_size ? i : n + tr_size - 1) : 0);
     const int li = i < n ? i : (i < 2 * n ? (i - n < bl_size ? i : n + bl_size - 1) : 0);
-    const int tv = M[top_off + ti], lv = M[cm_off - 1 + li * rs], cv = M[top_off - 1];
+    const int tv = S.ld(top_off + ti), lv = S.ld(cm_off - 1 + li * rs), cv = S.ld(top_off - 1);
     /* substitution (:251-286) in closed form: the reference's cascaded fills only ever copy one of
      * these wave-uniform values */
     const int l_0 = __builtin_amdgcn_readlane(lv, 0), l_n1 = __builtin_amdgcn_readlane(lv, n - 1), l_n = __builtin_amdgcn_readlane(lv, n & 63);
@@ -244,7 +302,6 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
     /* prediction (:359-538): lane group g = lane + 64k owns samples 4g..4g+3 of the block (one row).
      * One straight-line loop per mode class; all LDS reads of a group are issued before use. */
     const bool edge = flags & OH_IF_EDGE;
-    uint16_t *__restrict__ cm = M + cm_off;
 #define GROUP_LOOP_BEGIN                                                                  \
     _Pragma("unroll") for (int k = 0; k < 4; k++) {                                       \
         const int g = lane + 64 * k;                                                      \
@@ -253,7 +310,7 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
         int v[4];
 #define GROUP_LOOP_END                                                                    \
         if (has_res) { _Pragma("unroll") for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + rv[k][j], bd); } \
-        put4(cm + y * rs + x0, v[0], v[1], v[2], v[3]);                                                    \
+        S.st4(cm_off + y * rs + x0, v[0], v[1], v[2], v[3]);                                               \
     }
     if (cls == OH_IC_PLANAR) {
         const int tn_ = E[TB + n], ln_ = E[LB + n];
@@ -361,6 +418,18 @@ static __device__ __forceinline__ void intra_block(const DevFrame *__restrict__ 
 static __device__ __forceinline__ int row_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); }
 static __device__ __forceinline__ int row_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false); }
 
+/* a block's 32-byte descriptor from the staged copy (LDS) or from the list in HBM */
+static __device__ __forceinline__ void item_load(const DevIntra *__restrict__ items, const uint32_t i, uint4v &q0, uint4v &q1)
+{
+    const uint4v *__restrict__ it = (const uint4v *)&items[i];
+    q0 = it[0]; q1 = it[1];
+}
+static __device__ __forceinline__ void item_load(const GLOBAL DevIntra *__restrict__ items, const uint32_t i, uint4v &q0, uint4v &q1)
+{
+    const GLOBAL uint4v *__restrict__ it = (const GLOBAL uint4v *)&items[i];
+    q0 = it[0]; q1 = it[1];
+}
+
 enum { SLOT_LB = 1, SLOT_TB = 18 };                          /* left[k] = E[SLOT_LB + k], top[k] = E[SLOT_TB + k] */
 enum { SS_ACT = 1, SS_WORK = 2, SS_H = 4, SS_FILTER = 8, SS_EDGE = 16, SS_RES = 32, SS_SMOOTH_LANE = 64 };
 struct SlotState {                                           /* per lane, carried from slots_prepare to slots_finish */
@@ -371,19 +440,21 @@ struct SlotState {                                           /* per lane, carrie
     int bits;                                                /* SS_* | cls << 8 | log2 << 12 | fact << 16 */
 };
 
-template <bool STAGED>
-static __device__ __forceinline__ void slots_prepare(SlotState &st, const DevIntra *__restrict__ items, const uint32_t first, const int count,
+template <bool STAGED, bool DIRECT, typename ITEMS>
+static __device__ __forceinline__ void slots_prepare(SlotState &st, const ITEMS items, const uint32_t first, const int count, const PlaneGeo &G,
                                                      const int16_t *__restrict__ res_lds_base, const GLOBAL int16_t *__restrict__ res_pool, const int lane)
 {
     /* straight-line code: every choice is a select (the compiler would turn if/else into exec-mask branches, and
      * this runs beside the dependent chain of the sub-level before) */
     const int slot = lane >> 4, sl = lane & 15;
     const bool act = slot < count;
-    const uint4v *__restrict__ item = (const uint4v *)&items[first + (act ? slot : 0)];
-    const uint4v q0 = item[0], q1 = item[1];
+    uint4v q0, q1;
+    item_load(items, first + (act ? slot : 0), q0, q1);
     const uint32_t w1 = q0[1], res_off = q0[2], w3 = q0[3], w4 = q1[0], w5 = q1[1], res_lds = q1[2];
     const int log2 = (w1 >> 8) & 0xff, avail = w1 >> 24;
-    const int cm_off = w3 & 0xffff, top_off = w3 >> 16, rs = w4 & 0xffff, tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    const int tr_size = (w4 >> 16) & 0xff, bl_size = w4 >> 24;
+    int cm_off, top_off, rs;
+    block_geo<DIRECT>(G, q0[0], w1, w3, w4, cm_off, top_off, rs);
     const int angle = (int)(int8_t)(w5 & 0xff), flags = (w5 >> 8) & 0xff, inv_a = (int)(int16_t)(w5 >> 16);
     const int n = 1 << log2, cls = (flags >> 4) & 7, ngroups = (n * n) >> 2;
     const bool a_bl = avail & OH_AV_BOTTOM_LEFT, a_l = avail & OH_AV_LEFT, a_ul = avail & OH_AV_UP_LEFT;
@@ -420,7 +491,7 @@ static __device__ __forceinline__ void slots_prepare(SlotState &st, const DevInt
         const int l_0 = cm_off - 1, l_n1 = l_0 + __mul24(n - 1, rs), l_n = l_n1 + rs;
         const int t_0 = top_off, t_n1 = top_off + n - 1, t_n = top_off + n, c_own = top_off - 1;
         const bool any_l = a_bl || a_l;
-        const int c_l = a_l ? l_0 : l_n, c_t = a_u ? t_0 : (a_ur ? t_n : 0);
+        const int c_l = a_l ? l_0 : l_n, c_t = a_u ? t_0 : (a_ur ? t_n : (DIRECT ? -1 : 0));     /* nothing available at all: the substitute */
         const int corner = a_ul ? c_own : (any_l ? c_l : c_t);
         const int left_a = i < n ? (a_l ? own_l : l_n) : (a_bl ? own_l : l_n1);
         st.src_c = corner;
@@ -451,8 +522,8 @@ static __device__ __forceinline__ void slots_prepare(SlotState &st, const DevInt
               (cls << 8) | (log2 << 12) | (fact << 16);
 }
 
-template <typename PX>
-static __device__ __forceinline__ void slots_finish(const SlotState &st, const int bd, int *__restrict__ edges, uint16_t *__restrict__ M,
+template <typename PX, bool DIRECT>
+static __device__ __forceinline__ void slots_finish(const SlotState &st, const int bd, int *__restrict__ edges, const Samples<PX, DIRECT> S,
                                                     const int lane, unsigned long long *acc)
 {
     unsigned long long sa = 0, sb = 0, sc = 0, sd = 0, se = 0; (void)sa; (void)sb; (void)sc; (void)sd; (void)se; (void)acc;
@@ -460,7 +531,7 @@ static __device__ __forceinline__ void slots_finish(const SlotState &st, const i
     const int slot = lane >> 4, sl = lane & 15, bits = st.bits;
     const int cls = (bits >> 8) & 7, log2 = (bits >> 12) & 7, fact = bits >> 16, n = 1 << log2;
     const bool act = bits & SS_ACT, work = bits & SS_WORK;
-    int left_i = M[st.src_l], top_i = M[st.src_t], corner = M[st.src_c];
+    int left_i = S.ld(st.src_l), top_i = S.ld(st.src_t), corner = S.ld(st.src_c);
 
     if (__builtin_amdgcn_ballot_w64(act && (bits & SS_FILTER)) != 0) {
         /* smoothing (:288-326); never the strong filter here (32x32 only).  All lanes run the shifts, the flag selects. */
@@ -525,12 +596,11 @@ static __device__ __forceinline__ void slots_finish(const SlotState &st, const i
 #pragma unroll
             for (int j = 0; j < 4; j++) v[j] = clip_px(v[j] + st.rv[j], bd);
         }
-        uint16_t *__restrict__ d = M + st.dst;
         if (bits & SS_H) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) d[j * st.dstep] = (uint16_t)v[j];
+            for (int j = 0; j < 4; j++) S.st1(st.dst + j * st.dstep, v[j]);
         } else {
-            put4(d, v[0], v[1], v[2], v[3]);
+            S.st4(st.dst, v[0], v[1], v[2], v[3]);
         }
     }
     WSYNC();                                                 /* the wave's edge arrays are reused by its next pass */
@@ -538,9 +608,58 @@ static __device__ __forceinline__ void slots_finish(const SlotState &st, const i
     ACC(5, sa, sb); ACC(6, sb, sc); ACC(7, sc, sd); ACC(8, sd, se);
 }
 
-/* one CTU by the whole workgroup: schedule entry `entry` of picture f.  Every thread of the workgroup calls it (barriers inside). */
-template <typename PX, bool CIP, bool STAGED>
-static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict__ f, const OhIntraLaunch &L, const uint32_t entry, unsigned char *smem)
+/* ---- the schedule as a dependency graph: one launch per picture batch (intra_dag_kernel, intra_direct_kernel) ----
+ * Entry k of ictu[] may start when the entries ctu_wait[4k..4k+3] (prep_intra_wait: neighbour CTUs of a lower level its blocks gather
+ * from) have set ctu_done.  Hand-off = the placement-independent form of the CDNA4 guide: producer — every storing wave drains its
+ * stores, workgroup barrier, ONE lane: agent-scope release, drain, relaxed agent-scope flag store; consumer — ONE wave polls
+ * (relaxed agent-scope loads, s_sleep between polls), takes ONE agent-scope acquire, drains it, then the workgroup barrier in front
+ * of every load of the samples.  The poll is bounded: a wave that gives up latches OH_KE_DAG_TIMEOUT in the engine's error word
+ * (pinned host memory; oh_engine_sync and every other wait report it) and goes on with what is there, so the grid always drains. */
+static __device__ __forceinline__ void dag_latch_error(const DevFrame *__restrict__ f, const uint32_t code, const uint32_t where)
+{
+    uint32_t *w = f->err_word;
+    if (w && __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        __hip_atomic_store(&w[1], (uint32_t)f->cur_pic_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&w[2], where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&w[0], code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+/* called by ONE wave (all 64 lanes): lanes 0..3 poll one awaited entry each */
+static __device__ __forceinline__ void dag_wait_wave(const DevFrame *__restrict__ f, const uint32_t entry, const int lane, const uint32_t spin_limit, const int exp = 0)
+{
+    const uint32_t w = lane < 4 ? G_CONST(uint32_t, f->ctu_wait)[4 * entry + lane] : ~0u;
+    uint32_t *done = f->ctu_done;
+    bool ok = w == ~0u;
+    uint32_t spin = 0;
+    for (;;) {
+        if (!ok) ok = __hip_atomic_load(&done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull)
+            break;
+        if (++spin >= spin_limit) {
+            if (lane == 0) dag_latch_error(f, OH_KE_DAG_TIMEOUT, entry);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (exp & 8) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            /* the awaited CTUs' samples: not from this CU's L1 / stale L2 lines */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              /* ... and the invalidate has completed before anyone loads */
+}
+/* called by ONE lane after every storing wave has drained its stores (and, with several waves, after their barrier) */
+template <bool WRITE_THROUGH>
+static __device__ __forceinline__ void dag_publish_lane(const DevFrame *__restrict__ f, const uint32_t entry)
+{
+    if (!WRITE_THROUGH)                                           /* plain stores: the XCD's L2 has to be written back */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              /* the compiler may drop the fence's own wait (ROCm 7.2): the flag must not overtake the write-back */
+    __hip_atomic_store(&f->ctu_done[entry], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* one CTU by the whole workgroup: schedule entry `entry` of picture f.  Every thread of the workgroup calls it (barriers inside).
+ * DAG: the entry waits for / publishes to other entries of the same launch (above). */
+template <typename PX, bool CIP, bool STAGED, bool DAG>
+static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict__ f, const OhIntraLaunch &L, const uint32_t entry, unsigned char *smem,
+                                                      const uint32_t spin_limit)
 {
     uint16_t *__restrict__ M = (uint16_t *)smem;                                  /* sample area, oh_ctu_areas() */
     DevIntra *__restrict__ items = (DevIntra *)(smem + L.off_items);
@@ -556,12 +675,12 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
     const OhPicParams &pp = f->pp;
     const int lc = pp.log2_ctb_size, ctbw = (pp.width + (1 << lc) - 1) >> lc;
     const int cx0 = (ctu.ctu % ctbw) << lc, cy0 = (ctu.ctu / ctbw) << lc;      /* luma origin of the CTU */
-    const int n_sub = min((int)ctu.n_sub, OH_MAX_CTU_BLOCKS);
+    const int n_sub = (int)ctu.n_sub;                                             /* <= OH_MAX_CTU_BLOCKS: prep_intra_ctu rejects the list otherwise */
     const int bd = pp.bit_depth;
     const OhCtuAreas ar = oh_ctu_areas(lc, pp.chroma_format_idc);
 
     /* stage: block descriptors, sub-level table, residual blocks */
-    const uint32_t item0 = ctu.item0, n_items = min(ctu.n_items & 0xffffu, (uint32_t)OH_MAX_CTU_BLOCKS);
+    const uint32_t item0 = ctu.item0, n_items = ctu.n_items & 0xffffu;       /* <= OH_MAX_CTU_BLOCKS, checked by prep_intra_ctu */
     /* write-back form, decided while the entry is at hand and kept in a scalar register: blocks (mostly-inter CTU) or rectangle */
     int blockwise;
     {
@@ -582,6 +701,15 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
         const GLOBAL short4v *__restrict__ rsrc = (const GLOBAL short4v *)(f->res + ctu.res_lo);
         if (STAGED)
             for (uint32_t e = tid; e < ctu.res_cnt / 4; e += nthr) ((short4v *)res_l)[e] = rsrc[e];
+    }
+    uint32_t aux = 0;
+    if (DAG) {
+        /* descriptors and residual are on their way; now the neighbours.  Wave 0 polls and acquires, the barrier holds the others */
+        aux = __builtin_amdgcn_readfirstlane(G_CONST(uint32_t, f->ctu_aux)[entry]);
+        if (aux & OH_AUX_WAITS) {
+            if (wave == 0) dag_wait_wave(f, entry, lane, spin_limit);
+            __syncthreads();
+        }
     }
     /* stage the part of the CTU its blocks read (DevIntraCtu.bx0..by1): samples reconstructed by passes
      * 1-2 (inter), the column left of the CTU and the row above it (up to 2*wc samples: the up-right CTU) —
@@ -624,6 +752,8 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
      * each), then the bigger blocks one per wave; the slot path has no
      * constrained-intra variant. */
     const int K = (int)L.phases, ph = wave % K, wi = wave / K, nwk = nwaves / K;
+    const Samples<PX, false> S = { M };
+    const PlaneGeo G0 = { 0, 0, 0, 0 };
     SlotState st;
     bool ready = false;                                      /* st holds the prepared unit `wi` of this wave's next sub-level */
     uint32_t b0 = 0, ns = 0, nunits = 0;                     /* this wave's next sub-level: first block, blocks in slots, units */
@@ -634,7 +764,7 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
         nunits = ((ns + 3) >> 2) + (s1 - s0 - ns);
         ready = (uint32_t)wi < ((ns + 3) >> 2);
         if (ready)
-            slots_prepare<STAGED>(st, items, b0 + 4 * wi, (int)min(4u, ns - 4 * wi), res_l, res_pool, lane);
+            slots_prepare<STAGED, false>(st, (const DevIntra *)items, b0 + 4 * wi, (int)min(4u, ns - 4 * wi), G0, res_l, res_pool, lane);
     };
     if (ph < n_sub) prepare(ph);
     for (int s = 0, sp = 0; s < n_sub; s++, sp = sp + 1 == K ? 0 : sp + 1) {      /* sp = s % K */
@@ -644,11 +774,13 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
             for (uint32_t u = wi; u < nunits; u += nwk) {
                 if (u < ngrp) {
                     if (!ready)
-                        slots_prepare<STAGED>(st, items, b0 + 4 * u, (int)min(4u, ns - 4 * u), res_l, res_pool, lane);
+                        slots_prepare<STAGED, false>(st, (const DevIntra *)items, b0 + 4 * u, (int)min(4u, ns - 4 * u), G0, res_l, res_pool, lane);
                     ready = false;
-                    slots_finish<PX>(st, bd, edges.E, M, lane, acc);
+                    slots_finish<PX, false>(st, bd, edges.E, S, lane, acc);
                 } else {
-                    intra_block<PX, CIP, STAGED>(f, bd, (const uint4v *)&items[b0 + ns + (u - ngrp)], edges, M, res_l, lane, acc);
+                    uint4v q0, q1;
+                    item_load((const DevIntra *)items, b0 + ns + (u - ngrp), q0, q1);
+                    intra_block<PX, CIP, STAGED, false>(f, bd, q0, q1, edges, S, G0, res_l, lane, acc);
                 }
             }
         } else if (sp == (ph + 1 == K ? 0 : ph + 1) && s - 1 + K < n_sub) {
@@ -662,6 +794,7 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
     /* The last sub-level's barrier has been passed.  A CTU that is mostly INTER (B pictures: a few intra blocks scattered over a
      * rectangle that spans the CTU) stores its blocks, a quarter wave per block, instead of the rectangle: measured on the
      * >= 16 k-workgroup launches of B pictures the rectangle's write-back was 19 % of the launch (profiles/r02_intra_staging_experiment.txt) */
+    const bool wt = DAG && (aux & OH_AUX_AWAITED);          /* another CTU of this launch reads these samples: write-through stores, no L2 write-back */
     if (blockwise) {
         const uint64_t gp0 = (uint64_t)f->cur.p[0], gp1 = (uint64_t)f->cur.p[1], gp2 = (uint64_t)f->cur.p[2];
         const int st0 = f->cur.stride[0], st1 = f->cur.stride[1];
@@ -676,8 +809,13 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
                 const int y = (4 * gi) >> log2, x0 = (4 * gi) & (n - 1);
                 const uint2v pk = *(const uint2v *)&M[cm_off + y * rs + x0];
                 GLOBAL PX *__restrict__ d = g + (size_t)y * stride + x0;
-                if (sizeof(PX) == 1) *(GLOBAL uint32_t *)d = __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200);
-                else                 *(GLOBAL uint2v *)d = pk;
+                if (wt) {
+                    if (sizeof(PX) == 1) __hip_atomic_store((GLOBAL uint32_t *)d, __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else                 __hip_atomic_store((GLOBAL uint64_t *)d, (uint64_t)pk[0] | (uint64_t)pk[1] << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (sizeof(PX) == 1) *(GLOBAL uint32_t *)d = __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200);
+                    else                 *(GLOBAL uint2v *)d = pk;
+                }
             }
         }
     } else
@@ -697,9 +835,19 @@ static __device__ __forceinline__ void intra_ctu_body(const DevFrame *__restrict
             for (int row = r0 + (tid >> 4); row < r1; row += nthr >> 4) {
                 const uint2v pk = *(const uint2v *)&Mm[row * rs + cs + 4 * seg + 4];
                 GLOBAL PX *__restrict__ d = g + (size_t)(y0 + row) * stride + x0 + cs + 4 * seg;
-                if (sizeof(PX) == 1) *(GLOBAL uint32_t *)d = __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200);
-                else                 *(GLOBAL uint2v *)d = pk;
+                if (wt) {
+                    if (sizeof(PX) == 1) __hip_atomic_store((GLOBAL uint32_t *)d, __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else                 __hip_atomic_store((GLOBAL uint64_t *)d, (uint64_t)pk[0] | (uint64_t)pk[1] << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (sizeof(PX) == 1) *(GLOBAL uint32_t *)d = __builtin_amdgcn_perm(pk[1], pk[0], 0x06040200);
+                    else                 *(GLOBAL uint2v *)d = pk;
+                }
             }
+    }
+    if (DAG && (aux & OH_AUX_AWAITED)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* this wave's stores of the CTU have left */
+        __syncthreads();
+        if (tid == 0) dag_publish_lane<true>(f, entry);
     }
 #ifdef OH_STAMPS
     if (f->dbg && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0) {
@@ -725,7 +873,109 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
     if (blockIdx.x >= f->lvl_start[L.level + 1] - first_ctu)
         return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    intra_ctu_body<PX, CIP, STAGED>(f, L, first_ctu + blockIdx.x, smem);
+    intra_ctu_body<PX, CIP, STAGED, false>(f, L, first_ctu + blockIdx.x, smem, 0u);
+}
+
+
+/* =========================================================================================
+ * The whole picture's intra pass in ONE launch, staged form: a workgroup per schedule entry (CTU), id = entry x pictures + picture,
+ * so the dispatcher hands the entries out in schedule order (level by level) interleaved over the pictures of the batch; an entry
+ * stages its descriptors, waits for the entries it depends on (ctu_wait[]), and runs the same body as a level launch.  A wait only
+ * ever points at a LOWER workgroup id, which has been dispatched before: no level launches, no launch as long as its slowest CTU,
+ * an I picture costs its dependency chain at the CTUs' own lengths (what intra_rows_kernel gives, without holding a workgroup
+ * slot per CTU row) and a B picture's handful of levels overlap.
+ * ======================================================================================= */
+template <typename PX, bool CIP, bool STAGED>
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void intra_dag_kernel(const OhBatch B, const OhIntraLaunch L, const int n_pics, const uint32_t spin_limit)
+{
+    const uint32_t k = blockIdx.x / (uint32_t)n_pics;
+    const DevFrame *__restrict__ f = B.f[blockIdx.x - k * (uint32_t)n_pics];
+    if (k >= f->n_ictu)
+        return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    intra_ctu_body<PX, CIP, STAGED, true>(f, L, k, smem, spin_limit);
+}
+
+/* =========================================================================================
+ * The same dependency graph for pictures whose CTUs hold FEW intra blocks (B pictures: a third of the CTUs, a third of their
+ * samples): ONE WAVE per schedule entry, nothing staged.  A block gathers its neighbours from the picture in HBM and stores its
+ * samples there; the wave runs the entry's blocks in schedule order (sub-level by sub-level — any topological order would do:
+ * vector memory operations of one wave reach the L1 / L2 in program order, so a block sees what the blocks before it stored),
+ * four <= 8x8 blocks per pass in 16-lane slots, bigger ones alone.  No LDS beyond the wave's edge arrays, no barrier, no
+ * rectangle read or written back: the chip holds as many CTUs as it holds waves, and the launch moves the blocks' samples, their
+ * edges and their descriptors instead of whole staged CTUs (the staged level launches of such pictures spent 42 % of their time on
+ * the rectangles and ran 5 workgroups per CU: profiles/r02_intra_staging_experiment.txt).  Hand-off between entries as above.
+ * ======================================================================================= */
+template <typename PX, bool CIP>
+__global__ __launch_bounds__(64) void intra_direct_kernel(const OhBatch B, const int n_pics, const uint32_t spin_limit, const int exp)
+{
+    /* per wave: the edge arrays, and a window of 64 block descriptors (a wave reads its entry's lists front to back: tables and
+     * descriptors arrive 64 at a time, so a pass waits for ONE round trip to HBM — its samples and residual — not for four) */
+    __shared__ IntraLds edges;
+    __shared__ __attribute__((aligned(16))) DevIntra items_l[64];
+    const uint32_t pos = blockIdx.x / (uint32_t)n_pics;
+    const DevFrame *__restrict__ f = B.f[blockIdx.x - pos * (uint32_t)n_pics];
+    if (pos >= f->n_ictu)
+        return;
+    const uint32_t k = (exp & 4) ? pos : G_CONST(uint32_t, f->ctu_order)[pos];      /* chains first (prep_intra_order) */
+    const int lane = threadIdx.x;
+    const DevIntraCtu ctu = gload(f->ictu + k);
+    const uint32_t aux = __builtin_amdgcn_readfirstlane(G_CONST(uint32_t, f->ctu_aux)[k]);
+    const GLOBAL uint32_t *__restrict__ ss = G_CONST(uint32_t, f->sub_start) + ctu.sub_first;
+    const GLOBAL uint32_t *__restrict__ sm = G_CONST(uint32_t, f->sub_small) + ctu.sub_first;
+    const GLOBAL uint4v *__restrict__ items_g = (const GLOBAL uint4v *)f->intra;
+    const GLOBAL int16_t *__restrict__ res_pool = G_CONST(int16_t, f->res);
+    const int bd = f->pp.bit_depth, n_sub = (int)ctu.n_sub;
+    const uint32_t item0 = ctu.item0, item_end = item0 + (ctu.n_items & 0xffffu);
+    const Samples<PX, true> S = { G_MUT(PX, f->cur.p[0]), 1 << (bd - 1), (aux & OH_AUX_AWAITED) != 0u };
+    const PlaneGeo G = { (int)(((const char *)f->cur.p[1] - (const char *)f->cur.p[0]) / (ptrdiff_t)sizeof(PX)),
+                         (int)(((const char *)f->cur.p[2] - (const char *)f->cur.p[0]) / (ptrdiff_t)sizeof(PX)), f->cur.stride[0], f->cur.stride[1] };
+    /* descriptor window [ib, ib + 64): lane i brings item ib + i (clamped to the entry's last) */
+    uint32_t ib = item0;
+    auto window = [&](uint32_t first) {
+        ib = first;
+        const uint32_t i = min(first + (uint32_t)lane, item_end - 1u);
+        const uint4v q0 = items_g[2 * i], q1 = items_g[2 * i + 1];
+        WSYNC();                                             /* earlier passes are done with the old window */
+        ((uint4v *)items_l)[2 * lane] = q0; ((uint4v *)items_l)[2 * lane + 1] = q1;
+        WSYNC();
+    };
+    window(item0);
+    if ((aux & OH_AUX_WAITS) && !(exp & 1))
+        dag_wait_wave(f, k, lane, spin_limit, exp);
+    SlotState st;
+    for (int cb = 0; cb < n_sub; cb += 63) {                 /* sub-level tables: 64 entries of sub_start (63 sub-levels) per round trip, one per lane */
+        const uint32_t t_ss = ss[min(cb + lane, n_sub)], t_sm = sm[min(cb + lane, n_sub - 1)];
+        const int ce = min(cb + 63, n_sub);
+        for (int s = cb; s < ce; s++) {
+            const uint32_t s0 = __builtin_amdgcn_readlane(t_ss, s - cb), s1 = __builtin_amdgcn_readlane(t_ss, s - cb + 1);
+            const uint32_t ns = CIP ? 0u : min((uint32_t)__builtin_amdgcn_readlane(t_sm, s - cb), s1 - s0);
+            for (uint32_t u = 0; u < ns; u += 4) {
+                const uint32_t first = s0 + u, cnt = min(4u, ns - u);
+                if (first + cnt > ib + 64u) window(first);
+                slots_prepare<false, true>(st, (const DevIntra *)items_l, first - ib, (int)cnt, G, nullptr, res_pool, lane);
+                slots_finish<PX, true>(st, bd, edges.E, S, lane, nullptr);
+            }
+            for (uint32_t b = s0 + ns; b < s1; b++) {
+                if (b >= ib + 64u) window(b);
+                uint4v q0, q1;
+                item_load((const DevIntra *)items_l, b - ib, q0, q1);
+                intra_block<PX, CIP, false, true>(f, bd, q0, q1, edges, S, G, nullptr, lane, nullptr);
+            }
+        }
+    }
+    if ((aux & OH_AUX_AWAITED) && !(exp & 2)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) dag_publish_lane<true>(f, k);
+    }
+}
+
+/* ctu_done[] of every picture of the batch back to zero: a work list may be executed more than once */
+__global__ __launch_bounds__(256) void intra_dag_reset_kernel(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < f->n_ictu) f->ctu_done[k] = 0u;
 }
 
 /* =========================================================================================
@@ -740,11 +990,12 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
  * barrier) and stores x + 1; the waiting workgroup polls it (one lane, relaxed agent-scope loads) and every wave then takes an acquire fence (L1 and the XCD's non-coherent L2 lines dropped) before it stages.  Workgroup
  * ids are row-major over (row, picture), rows ascending: a waiting workgroup only ever waits for a LOWER id, and the dispatcher of
  * each XCD hands workgroups out in id order, so the lowest unfinished workgroup is always resident and never waits on a
- * non-resident one — no deadlock whatever the occupancy.  The poll is bounded all the same (a wave that gives up continues with
- * what is there: wrong samples, caught by every test, instead of a hung GPU).
+ * non-resident one — no deadlock whatever the occupancy (in-order dispatch is what the hardware does, not what HIP promises: see
+ * engine.hip where the path is chosen).  The poll is bounded all the same: a wave that gives up latches OH_KE_ROW_TIMEOUT in the
+ * engine's error word — every wait on the stream then fails with picture and row — and continues, so the grid always drains.
  * ======================================================================================= */
 template <typename PX, bool CIP, bool STAGED>
-__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_rows_kernel(const OhBatch B, const OhIntraLaunch L, const int n_pics)
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_rows_kernel(const OhBatch B, const OhIntraLaunch L, const int n_pics, const uint32_t spin_limit)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int row = blockIdx.x / n_pics, pic = blockIdx.x - row * n_pics;
@@ -761,16 +1012,19 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) void intra_rows_kernel(const 
             if (row > 0) {
                 const uint32_t need = (uint32_t)min(x + 2, ctbw);
                 if (threadIdx.x == 0) {
-                    for (int spin = 0; spin < (1 << 22); spin++) {       /* ~1 s at worst: never reached while the rows above make progress */
-                        if (__hip_atomic_load(&progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need)   /* the acquire is the fence below */
+                    uint32_t spin = 0;                                   /* the default limit is ~1 s: never reached while the rows above make progress */
+                    while (__hip_atomic_load(&progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {   /* the acquire is the fence below */
+                        if (++spin >= spin_limit) {                      /* give up, but not silently: oh_engine_sync reports picture and row */
+                            dag_latch_error(f, OH_KE_ROW_TIMEOUT, (uint32_t)row);
                             break;
+                        }
                         __builtin_amdgcn_s_sleep(8);
                     }
                 }
                 __syncthreads();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   /* samples written by other workgroups: not from this CU's L1 */
             }
-            intra_ctu_body<PX, CIP, STAGED>(f, L, e - 1, smem);
+            intra_ctu_body<PX, CIP, STAGED, false>(f, L, e - 1, smem, 0u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       /* every thread's stores of the CTU */
             __syncthreads();                                         /* ... and the LDS is free for the next CTU */
         }
@@ -809,17 +1063,61 @@ int ohk_init_intra(void)
     for (const void *k : row_kernels)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
             return -1;
+    const void *dag_kernels[8] = {
+        (const void *)intra_dag_kernel<uint8_t, false, false>, (const void *)intra_dag_kernel<uint8_t, false, true>,
+        (const void *)intra_dag_kernel<uint8_t, true, false>, (const void *)intra_dag_kernel<uint8_t, true, true>,
+        (const void *)intra_dag_kernel<uint16_t, false, false>, (const void *)intra_dag_kernel<uint16_t, false, true>,
+        (const void *)intra_dag_kernel<uint16_t, true, false>, (const void *)intra_dag_kernel<uint16_t, true, true> };
+    for (const void *k : dag_kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess)
+            return -1;
     return 0;
 }
 
+/* ctu_done[] cleared for the n pictures of B (max_ictu: the largest schedule among them) */
+extern "C" void ohk_intra_dag_reset(const OhBatch *B, int n, uint32_t max_ictu, hipStream_t st)
+{
+    if (n <= 0 || !max_ictu) return;
+    hipLaunchKernelGGL(intra_dag_reset_kernel, dim3((max_ictu + 255) / 256, n), dim3(256), 0, st, *B);
+}
+
+/* n pictures, each one's whole schedule, staged form: l = the LDS carve-up that fits every CTU of all of them (l->level unused) */
+extern "C" void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ictu, uint32_t spin_limit, hipStream_t st)
+{
+    if (n <= 0 || !max_ictu) return;
+    dim3 g(max_ictu * (uint32_t)n), b(64 * l->waves);
+#define DAG_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_dag_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l, n, spin_limit)
+#define DAG_BY_FLAGS(PX)                                                                       \
+    do {                                                                                       \
+        if (p->constrained_intra_pred) { if (l->staged) DAG_LAUNCH(PX, true, true); else DAG_LAUNCH(PX, true, false); }   \
+        else                           { if (l->staged) DAG_LAUNCH(PX, false, true); else DAG_LAUNCH(PX, false, false); } \
+    } while (0)
+    if (p->bit_depth == 8) DAG_BY_FLAGS(uint8_t); else DAG_BY_FLAGS(uint16_t);
+#undef DAG_BY_FLAGS
+#undef DAG_LAUNCH
+}
+
+/* n pictures, each one's whole schedule, a wave per CTU straight on the picture in HBM */
+extern "C" void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_ictu, uint32_t spin_limit, hipStream_t st)
+{
+    if (n <= 0 || !max_ictu) return;
+    dim3 g(max_ictu * (uint32_t)n), b(64);
+    static const char *xenv = getenv("OHEVC_EXP");           /* experiments only: 1 no waits, 2 no publishing (wrong pictures) */
+    const int exp = xenv ? atoi(xenv) : 0;
+#define DIRECT_LAUNCH(PX, CIP) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_direct_kernel<PX, CIP>), g, b, 0, st, *B, n, spin_limit, exp)
+    if (p->bit_depth == 8) { if (p->constrained_intra_pred) DIRECT_LAUNCH(uint8_t, true); else DIRECT_LAUNCH(uint8_t, false); }
+    else                   { if (p->constrained_intra_pred) DIRECT_LAUNCH(uint16_t, true); else DIRECT_LAUNCH(uint16_t, false); }
+#undef DIRECT_LAUNCH
+}
+
 /* n pictures whose intra pass runs as CTU rows (intra_rows_kernel); l: the LDS carve-up that fits every CTU of all of them */
-extern "C" void ohk_intra_rows(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, hipStream_t st)
+extern "C" void ohk_intra_rows(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t spin_limit, hipStream_t st)
 {
     if (n <= 0) return;
     const int lc = p->log2_ctb_size, ctbh = (p->height + (1 << lc) - 1) >> lc;
     hipLaunchKernelGGL(intra_rows_reset_kernel, dim3(n), dim3(64), 0, st, *B);
     dim3 g(ctbh * n), b(64 * l->waves);
-#define ROWS_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_rows_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l, n)
+#define ROWS_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_rows_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l, n, spin_limit)
 #define ROWS_BY_FLAGS(PX)                                                                      \
     do {                                                                                       \
         if (p->constrained_intra_pred) { if (l->staged) ROWS_LAUNCH(PX, true, true); else ROWS_LAUNCH(PX, true, false); }   \

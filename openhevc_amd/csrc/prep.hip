@@ -430,16 +430,22 @@ __global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
     if (!lane && atomicExch(&f->ctu_seen[c.ctu], k + 1) != 0u) fail(f, OH_PE_INTRA_TABLES, k);   /* a CTU heads ONE entry: its level is one number */
     unsigned long long lo = ~0ull, hi = 0;
     int bx0 = 1 << 14, bx1 = -(1 << 14), by0 = 1 << 14, by1 = -(1 << 14);
-    int any_res = 0, bad = 0;
+    int any_res = 0, bad = 0, dep = 0;                        /* dep: neighbour CTUs a block gathers from, bit 0 left, 1 up-left, 2 up, 3 up-right */
     uint32_t area = 0;                                        /* samples the CTU's blocks cover, all planes */
     for (uint32_t b = b0 + lane; b < b1; b += 64) {
         const uint4v q0 = *(const GLOBAL uint4v *)(di + b);
-        const int x = q0[0] & 0xffff, y = q0[0] >> 16, ci = q0[1] & 0xff, log2 = (q0[1] >> 8) & 0xff, n = 1 << log2;
+        const int x = q0[0] & 0xffff, y = q0[0] >> 16, ci = q0[1] & 0xff, log2 = (q0[1] >> 8) & 0xff, n = 1 << log2, av = q0[1] >> 24;
         const uint32_t res_off = q0[2];
         area += 1u << (2 * log2);
         const int hs = hsh(p, ci), vs = vsh(p, ci);
         if ((uint32_t)((((y << vs) >> lc) * ctbw) + ((x << hs) >> lc)) != c.ctu) bad = 1;       /* the CTU is written back from c.ctu's origin */
         const int lx = x - ((((x << hs) >> lc) << lc) >> hs), ly = y - ((((y << vs) >> lc) << lc) >> vs);
+        /* which neighbour CTUs hold the samples the block gathers (hevcpred_template.c:164-183): a superset by geometry (the
+         * recorder's levels count intra samples only; an entry never waits for a CTU of its own or a higher level) */
+        if (lx == 0 && ((av & (OH_AV_LEFT | OH_AV_BOTTOM_LEFT)) || ((av & OH_AV_UP_LEFT) && ly > 0))) dep |= 1;
+        if (lx == 0 && ly == 0 && (av & OH_AV_UP_LEFT)) dep |= 2;
+        if (ly == 0 && ((av & OH_AV_UP) || ((av & OH_AV_UP_LEFT) && lx > 0) || ((av & OH_AV_UP_RIGHT) && lx + n < ((1 << lc) >> hs)))) dep |= 4;
+        if (ly == 0 && (av & OH_AV_UP_RIGHT) && lx + n >= ((1 << lc) >> hs)) dep |= 8;
         bx0 = min(bx0, (lx - 1) * (1 << hs)); bx1 = max(bx1, (lx + 2 * n) << hs);
         by0 = min(by0, (ly - 1) * (1 << vs)); by1 = max(by1, (ly + 2 * n) << vs);
         if (res_off == OH_NO_COEFF)
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
         lo = min(lo, (unsigned long long)__shfl_xor(lo, d)); hi = max(hi, (unsigned long long)__shfl_xor(hi, d));
         bx0 = min(bx0, __shfl_xor(bx0, d)); bx1 = max(bx1, __shfl_xor(bx1, d));
         by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
-        any_res |= __shfl_xor(any_res, d); bad |= __shfl_xor(bad, d);
+        any_res |= __shfl_xor(any_res, d); bad |= __shfl_xor(bad, d); dep |= __shfl_xor(dep, d);
         slot_passes += __shfl_xor((int)slot_passes, d);
         area += (uint32_t)__shfl_xor((int)area, d);
     }
@@ -484,7 +490,10 @@ __global__ __launch_bounds__(64) void prep_intra_ctu(const OhBatch B)
         __builtin_memcpy(q, &d, 32);
         GLOBAL uint4v *o = (GLOBAL uint4v *)((DevIntraCtu *)f->ictu + k);
         o[0] = q[0]; o[1] = q[1];
-        f->ctu_aux[k] = slot_passes | (any_res && !res_cnt ? 0x80000000u : 0u);
+        f->ctu_aux[k] = min(slot_passes, (uint32_t)OH_AUX_PASSES) | (uint32_t)dep << OH_AUX_DEP_SHIFT | (any_res && !res_cnt ? (uint32_t)OH_AUX_RES_SCATTERED : 0u);
+        DevSummary *sm = summary_of(f);
+        atomicAdd(&sm->intra_area64, (area + 63) >> 6);
+        atomicMax(&sm->max_passes, slot_passes);
     }
 }
 
@@ -501,11 +510,12 @@ __global__ __launch_bounds__(64) void prep_intra_levels(const OhBatch B)
     for (uint32_t k = k0 + threadIdx.x; k < k1; k += 64) {
         const DevIntraCtu d = gload(f->ictu + k);
         const uint32_t aux = f->ctu_aux[k];
-        if (aux & 0x80000000u) staged = 0;
+        f->ctu_lvl[k] = l;
+        if (aux & OH_AUX_RES_SCATTERED) staged = 0;
         max_items = max(max_items, min(d.n_items & 0xffffu, (uint32_t)OH_MAX_CTU_BLOCKS));
         max_sub = max(max_sub, min((uint32_t)d.n_sub, (uint32_t)OH_MAX_CTU_BLOCKS));
         max_res = max(max_res, d.res_cnt);
-        sum_items += aux & 0x7fffffffu;
+        sum_items += aux & OH_AUX_PASSES;
         sum_sub += d.n_sub;
     }
 #pragma unroll
@@ -522,6 +532,72 @@ __global__ __launch_bounds__(64) void prep_intra_levels(const OhBatch B)
         s.n_ctu = k1 - k0; s.max_items = max_items; s.max_sub = max_sub; s.max_res = max_res; s.staged = staged; s.pad = 0;
         s.sum_items = sum_items; s.sum_sub = sum_sub;
         *((DevLevelStat *)(summary_of(f) + 1) + l) = s;
+    }
+}
+
+/* The schedule as a dependency graph, for the one-launch forms of the intra pass (intra.hip): one thread per entry looks up the
+ * entries of the neighbour CTUs its blocks gather from; it waits for those of a LOWER level (the level table is the contract: a
+ * block never reads intra samples of a CTU of its own or a higher level), which sit at lower indices of ictu[] — the one-launch
+ * kernels dispatch in index order, so a wait always points at a workgroup dispatched earlier.  The awaited entry learns that it
+ * has to publish (OH_AUX_AWAITED). */
+__global__ __launch_bounds__(256) void prep_intra_wait(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.y];
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= f->n_ictu || failed(f))
+        return;
+    const OhPicParams &p = f->pp;
+    const int lc = p.log2_ctb_size, ctbw = (p.width + (1 << lc) - 1) >> lc;
+    const uint32_t aux = f->ctu_aux[k], my = f->ctu_lvl[k];
+    const int ctu = (int)gload(f->ictu_raw + k).ctu, x = ctu % ctbw, y = ctu / ctbw;
+    const int dep = (aux >> OH_AUX_DEP_SHIFT) & 15;
+    uint4v w = { ~0u, ~0u, ~0u, ~0u };
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int nx = x + (j == 3 ? 1 : j == 2 ? 0 : -1), ny = y - (j != 0);
+        if (!(dep >> j & 1) || nx < 0 || ny < 0 || nx >= ctbw)
+            continue;
+        const uint32_t e = f->ctu_seen[ny * ctbw + nx];
+        if (!e || f->ctu_lvl[e - 1] >= my)
+            continue;
+        w[j] = e - 1;
+        any = true;
+        atomicOr(&f->ctu_aux[e - 1], (uint32_t)OH_AUX_AWAITED);
+    }
+    *((GLOBAL uint4v *)f->ctu_wait + k) = w;
+    if (any) atomicOr(&f->ctu_aux[k], (uint32_t)OH_AUX_WAITS);
+}
+
+/* Dispatch order of the wave-per-CTU form (intra_direct_kernel): the entries that wait or are awaited first, in schedule order (a
+ * wait still points at a lower position), then the entries nothing depends on.  The chains — a B picture's few levels, each as long
+ * as one CTU's latency — then start with the launch and the independent CTUs, the bulk, fill the chip around them; in plain schedule
+ * order a chain's second link is not even dispatched before every independent CTU of the batch has been.  One workgroup per
+ * picture: a stable partition by a block-wide scan. */
+__global__ __launch_bounds__(256) void prep_intra_order(const OhBatch B)
+{
+    const DevFrame *__restrict__ f = B.f[blockIdx.x];
+    const uint32_t n = f->n_ictu;
+    if (!n || failed(f))
+        return;
+    __shared__ uint32_t cnt[256];
+    const uint32_t t = threadIdx.x, per = (n + 255u) / 256u, b0 = min(t * per, n), b1 = min(b0 + per, n);
+    uint32_t c = 0;
+    for (uint32_t k = b0; k < b1; k++)
+        c += (f->ctu_aux[k] & (OH_AUX_WAITS | OH_AUX_AWAITED)) != 0u;
+    cnt[t] = c;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {                  /* inclusive scan */
+        const uint32_t v = t >= d ? cnt[t - d] : 0u;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    const uint32_t n_chain = cnt[255];
+    uint32_t pc = cnt[t] - c, pi = n_chain + (b0 - pc);       /* chain entries before this segment; independent ones likewise */
+    for (uint32_t k = b0; k < b1; k++) {
+        if (f->ctu_aux[k] & (OH_AUX_WAITS | OH_AUX_AWAITED)) f->ctu_order[pc++] = k;
+        else f->ctu_order[pi++] = k;
     }
 }
 
@@ -568,6 +644,8 @@ extern "C" void ohk_prepare(const OhBatch *B, int nb, const OhPrepCounts *n, uin
         hipLaunchKernelGGL(prep_intra_items, dim3((n->n_intra + 255) / 256, nb), dim3(256), 0, st, *B);
         hipLaunchKernelGGL(prep_intra_ctu, dim3(n->n_ictu, nb), dim3(64), 0, st, *B);
         hipLaunchKernelGGL(prep_intra_levels, dim3(n->n_levels, nb), dim3(64), 0, st, *B);
+        hipLaunchKernelGGL(prep_intra_wait, dim3((n->n_ictu + 255) / 256, nb), dim3(256), 0, st, *B);
+        hipLaunchKernelGGL(prep_intra_order, dim3(nb), dim3(256), 0, st, *B);
     }
     hipLaunchKernelGGL(prep_finish, dim3(nb), dim3(64), 0, st, *B);
 }

@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 The unit of work is a closed GOP (openhevc_amd/parallel.py): 1 I picture, 3 reference B pictures and 12
-non-reference B pictures of the workload's geometry, work lists already resident in HBM (uploaded before
-the timed region; the PCIe-inclusive rate is a separate figure in DESIGN.md).  GOPs are independent, so
+non-reference B pictures of the workload's geometry.  The headline (--mode decode) hands every picture's
+work list over INSIDE the timed region (host work lists -> oh_frames_upload: validation, one copy, H2D,
+list preparation on the GPU -> the passes -> stream-ordered release): its inputs are NOT resident in HBM;
+the same passes over resident lists follow as `kernel_only` in the same JSON line.  GOPs are independent, so
 --chains of them are kept in flight per GPU: the GPU form of the reference's frame threads
 (pthread_frame.c).  One STEP advances every chain by one GOP (chains x 16 pictures per GPU).  The chains
 are split over --streams HIP streams; the chains of one stream advance in LOCKSTEP, i.e. picture k of
@@ -37,8 +39,42 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 # kernel that implements each pass (name as rocprofv3 reports it, without template arguments)
-PASS_KERNEL = dict(inter="mc_kernel", residual="residual_kernel", intra="intra_ctu_kernel", deblock_v="deblock_luma_kernel<0>+deblock_chroma_kernel<0>",
+PASS_KERNEL = dict(inter="mc_kernel", residual="residual_kernel", intra="intra_direct_kernel+intra_dag_kernel", deblock_v="deblock_luma_kernel<0>+deblock_chroma_kernel<0>",
                    deblock_h="deblock_luma_kernel<1>+deblock_chroma_kernel<1>", sao="sao_kernel")
+
+
+def kernels_sha():
+    """identifies the kernels a profile was taken with: sha256 over the engine's device sources"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "openhevc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "openhevc_amd", "csrc", "*.h"))):
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(workload, kind, ext, want_round=None):
+    """(path, note): the newest profiles/rNN_<kind>_<workload>.<ext> (or round `want_round`) — cited only when its
+    rNN_profile_meta_<workload>.json says it was taken with the kernels of this tree; otherwise (None, why)."""
+    import glob
+    import re
+    cands = []
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}_{workload}.{ext}")):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m and (want_round is None or int(m.group(1)) == want_round):
+            cands.append((int(m.group(1)), path))
+    if not cands:
+        return None, "no committed profile of this workload"
+    rnd, path = max(cands)
+    meta = os.path.join(ROOT, "profiles", f"r{rnd:02d}_profile_meta_{workload}.json")
+    if not os.path.exists(meta):
+        return None, f"{os.path.relpath(path, ROOT)} has no profile_meta beside it (taken before the kernels were identified): not cited"
+    with open(meta) as fh:
+        sha = json.load(fh).get("kernels_sha")
+    if sha != kernels_sha():
+        return None, f"{os.path.relpath(path, ROOT)} was taken with other kernels (sha {sha}, this tree {kernels_sha()}): not cited"
+    return path, None
 
 
 def cpu_baseline(params, plan_kwargs, budget_s=12.0):
@@ -90,12 +126,13 @@ def decoder_baseline(params, n_pictures=16):
         return None
     if params.chroma_format_idc != 1:
         return None
-    cores = min(len(os.sched_getaffinity(0)), 16)            # pthread_internal.h:26 MAX_AUTO_THREADS 16: the reference's slice-thread tables end there
+    avail = len(os.sched_getaffinity(0))                     # the host cores this process may use (the GPU box hands a share of the node to one GPU)
+    cores = min(avail, 16)                                   # pthread_internal.h:26 MAX_AUTO_THREADS 16: the reference's slice-thread tables end there
     t0 = time.perf_counter()
     data, aus = streamgen.write_stream(params.width, params.height, 5, n_pictures=n_pictures, gop=2, bit_depth=params.bit_depth, wpp=1)
     t_write = time.perf_counter() - t0
     mpix = n_pictures * params.width * params.height / 1e6
-    out = dict(cpu_model=cpu_model(), host_threads=cores,
+    out = dict(cpu_model=cpu_model(), host_threads=cores, host_cores_available=avail,
                stream=f"{n_pictures} pictures {params.width}x{params.height} {params.bit_depth} bit, IDR + low-delay B (2 references), 64x64 CTBs, wavefront entry points, "
                       f"SAO + deblocking on, {len(data) / 1e6:.1f} MB (written in {t_write:.1f} s)")
 
@@ -122,6 +159,29 @@ def decoder_baseline(params, n_pictures=16):
         os.dup2(saved, 2)
         os.close(saved)
         os.close(devnull)
+    # every host core: the reference scales one decoder to 16 slice threads at most, so the node's cores are used the way its frame-level
+    # users would — k independent decoder instances (child processes; this process holds the GPU), each on its own 16 threads
+    k = avail // 16
+    if k >= 2 and (os.path.exists(refdec.SSE_LIB) or os.path.exists(refdec.LIB)):
+        import subprocess
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".265", delete=False) as fh:
+            fh.write(data)
+            spath = fh.name
+        try:
+            for key, sse in (("c_allcores", 0), ("sse_allcores", 1)):
+                if sse and not os.path.exists(refdec.SSE_LIB):
+                    continue
+                t = time.perf_counter()
+                kids = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "refdec.py"), spath, "16", str(sse)],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(k)]
+                ok = all(kid.wait() == 0 for kid in kids)
+                dt = time.perf_counter() - t
+                if ok:
+                    out[key] = dict(Mpixels_per_s=round(k * mpix / dt, 1), fps=round(k * n_pictures / dt, 2), threads=16 * k, instances=k,
+                                    note="wall time of k concurrent decoder processes incl. their start-up")
+        finally:
+            os.unlink(spath)
     return out
 
 
@@ -160,6 +220,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events between passes in the timed region")
     ap.add_argument("--no-check", action="store_true", help="skip the picture check after the timed region")
+    ap.add_argument("--profile-round", type=int, default=None, help="cite profiles/rNN_* of this round (default: the newest round that was taken with this tree's kernels)")
     args = ap.parse_args()
 
     # One HIP stream per chain only overlaps if the runtime maps them to distinct hardware queues
@@ -312,7 +373,7 @@ def main():
             eng.host_times(reset=True)
             eng.upload_bytes(reset=True)
             eng.n_batches = 0
-            eng.profile(0 if args.no_profile else 2)      # events between passes and around every intra launch
+            eng.profile(0 if args.no_profile else prof_level[0])      # 1: events between the passes of a batch (7 per batch); 2: also around every launch of the intra pass
         for _, be_k, _, _ in chains:
             be_k.upload_s, be_k.uploads, be_k.execute_s, be_k.release_s = 0.0, 0, 0.0, 0.0
         for cm in comms:
@@ -341,21 +402,38 @@ def main():
         return dt, dt_enqueue
 
     exchange_stats = []
+    prof_level = [1]            # the timed regions carry the per-pass events only; per-launch events get a short region of their own
+
+    def launch_durations():
+        """one extra step outside the timed regions with an event pair around every launch of the intra pass: (ms, launches)"""
+        if args.no_profile:
+            return 0.0, 0
+        prof_level[0] = 2
+        timed(0, 1)
+        prof_level[0] = 1
+        ms = n = 0
+        for eng in engines:
+            eng.pass_times()                               # collects the pending events (the per-launch pairs with them)
+            a, c = eng.intra_launch_times(reset=True)
+            ms += a
+            n += c
+            eng.pass_times(reset=True)
+        intra_steps[0] = 1
+        return ms, n
+
+    intra_steps = [1]
 
     luma_px = params.width * params.height
     b = 2 if params.bit_depth > 8 else 1
 
     def collect(dt, n_steps):
         """per-pass figures of the region just timed: HIP events on the engines' streams (this run, nothing read from profiles/)"""
-        pass_ms, n_exec, intra_ms, intra_n, per_stream = None, 0, 0.0, 0, []
+        pass_ms, n_exec, per_stream = None, 0, []
         for eng in engines:                                # sum over the streams
             ms_k, n_k = eng.pass_times()
             per_stream.append({k: round(v / n_steps, 3) for k, v in ms_k.items()})
             pass_ms = ms_k if pass_ms is None else {k: pass_ms[k] + ms_k[k] for k in ms_k}
             n_exec += n_k
-            im, inn = eng.intra_launch_times()
-            intra_ms += im
-            intra_n += inn
         if not n_exec:
             return None
         abytes = {k: 0.0 for k in pass_ms}                 # algorithmic bytes of this rank's step, per pass (SURVEY.md 8d; parallel.py)
@@ -364,45 +442,64 @@ def main():
                 for k, v in P.algorithmic_bytes(be_k.stats[pic.name], b).items():
                     abytes[k] += v
         steps_timed = n_exec / float(pics_per_step)
+        n_batches = max(sum(e.n_batches for e in engines), 1)
+        # the per-launch events of the intra pass come from a short region of their own (one more step, not timed)
+        intra_ms, intra_n = launch_durations() if world == 1 else (0.0, 0)     # (a region of its own runs collectives: one GPU only)
         # dominant pass = the largest share of the streams' time in THIS region.  With several streams sharing the chip a pass's
-        # stream-elapsed time also counts the time its launches waited for the other streams' kernels; the per-launch events of the
-        # intra pass (one launch per wavefront level) and launch counts of the other passes give the launch durations.
+        # stream-elapsed time also counts the time its launches waited for the other streams' kernels: `avg_launch_us` is that
+        # event-to-event time per launch; the kernel's OWN duration comes from the committed rocprofv3 kernel trace of this command
+        # (cited only when it was taken with this tree's kernels) and is what `frac` uses when it is there.
         dom = max(pass_ms, key=lambda k: pass_ms[k])
+        per_batch = dict(inter=2, residual=4, deblock_v=2, deblock_h=2, sao=1, intra=1)[dom]
         if dom == "intra" and intra_n:
-            n_launch_total, avg_launch_us = intra_n, intra_ms * 1e3 / intra_n
-            launch_source = "HIP events around every launch of the pass, timed region, all streams"
+            n_launch_total = intra_n / max(intra_steps[0], 1e-9) * steps_timed
+            avg_launch_us = intra_ms * 1e3 / intra_n
+            launch_source = "HIP events around every launch of the pass, one extra step after the timed region, all streams"
         else:
-            per_batch = dict(inter=2, residual=4, deblock_v=2, deblock_h=2, sao=1, intra=1)[dom]
-            n_launch_total = max(sum(e.n_batches for e in engines) * per_batch, 1)
+            n_launch_total = n_batches * per_batch
             avg_launch_us = pass_ms[dom] * 1e3 / n_launch_total
             launch_source = "pass time between HIP events / launches of the pass, timed region, all streams"
-        achieved = (abytes[dom] * steps_timed / n_launch_total) / (avg_launch_us * 1e-6) / 1e9
+        bytes_per_launch = abytes[dom] * steps_timed / n_launch_total
+        achieved_ev = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9
+        knames = [k.split("<")[0] for k in PASS_KERNEL[dom].split("+")]      # every instantiation of the pass's kernels
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.workload}.json")
-        if os.path.exists(tpath):                          # rocprofv3 --pmc passes of this command, recorded under profiles/ (bench.py cannot profile itself)
+        tpath, why_t = committed_profile(args.workload, "pmc_traffic", "json", args.profile_round)
+        if tpath:                                          # rocprofv3 --pmc passes of this command, recorded under profiles/ (bench.py cannot profile itself)
             with open(tpath) as fh:                        # every instantiation of the kernel, weighted by its launches
-                recs = [rec for kname, rec in json.load(fh).items() if kname.startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0])]
+                recs = [rec for kn, rec in json.load(fh).items() if any(kn.startswith(x) for x in knames)]
             n_l = sum(rec["launches"] for rec in recs)
             if n_l:
                 traffic = round(sum(rec["hbm_bytes_per_launch_corrected"] * rec["launches"] for rec in recs) / n_l)
                 traffic_source = os.path.relpath(tpath, ROOT)
-        # the committed rocprofv3 --kernel-trace --stats summary of this command, beside the live figure: the kernel's own duration
-        # there is shorter than the event-to-event time above, which also holds the dispatch and the wait for the other streams' kernels
+        else:
+            traffic_source = why_t
         trace_us, trace_source = None, None
-        spath = os.path.join(ROOT, "profiles", f"r02_kernel_stats_{args.workload}.csv")
-        if os.path.exists(spath):
+        spath, why_s = committed_profile(args.workload, "kernel_stats", "csv", args.profile_round)
+        if spath:
             import csv
             with open(spath) as fh:
-                rows = [r for r in csv.DictReader(fh) if r["Name"].startswith(PASS_KERNEL[dom].split("<")[0].split("+")[0])]
+                rows = [r for r in csv.DictReader(fh) if any(r["Name"].startswith(x) for x in knames)]
             calls = sum(int(r["Calls"]) for r in rows)
             if calls:
                 trace_us, trace_source = round(sum(float(r["TotalDurationNs"]) for r in rows) / calls / 1e3, 3), os.path.relpath(spath, ROOT)
+        else:
+            trace_source = why_s
+        achieved_tr = bytes_per_launch / (trace_us * 1e-6) / 1e9 if trace_us else None
+        achieved = achieved_tr if achieved_tr is not None else achieved_ev
         return dict(bound="hbm", kernel=PASS_KERNEL[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_source,
+                    frac=round(achieved / HBM_PEAK_GBS, 6),
+                    frac_from=("the kernel's own average duration in the committed rocprofv3 --kernel-trace --stats summary of this command"
+                               if achieved_tr is not None else "event-to-event time per launch of this run (no committed kernel trace of these kernels)"),
+                    achieved_by_events=round(achieved_ev, 3), frac_by_events=round(achieved_ev / HBM_PEAK_GBS, 6),
+                    achieved_by_trace=None if achieved_tr is None else round(achieved_tr, 3),
+                    frac_by_trace=None if achieved_tr is None else round(achieved_tr / HBM_PEAK_GBS, 6),
+                    traffic=traffic, traffic_source=traffic_source,
                     kernel_trace_avg_launch_us=trace_us, kernel_trace_source=trace_source,
                     dominant_pass=dom, dominant_by="largest sum of stream-elapsed pass time between HIP events, this run",
                     launches_per_step=round(n_launch_total / steps_timed, 3), avg_launch_us=round(avg_launch_us, 3), avg_launch_source=launch_source,
-                    algorithmic_bytes_per_launch=round(abytes[dom] * steps_timed / n_launch_total, 1),
+                    algorithmic_bytes_per_launch=round(bytes_per_launch, 1),
+                    intra_pass_launches=dict(per_step=round(intra_n / max(intra_steps[0], 1e-9), 1), avg_us=round(intra_ms * 1e3 / intra_n, 3) if intra_n else None,
+                                             what="one launch per picture batch and form (wave per CTU on the picture / workgroup per CTU staged in LDS), dependency flags between CTUs"),
                     pass_ms_per_step={k: round(v / steps_timed, 4) for k, v in pass_ms.items()},
                     pass_ms_per_step_per_stream=per_stream,
                     pass_algorithmic_GBps={k: round(abytes[k] / max(pass_ms[k] / steps_timed, 1e-9) / 1e6, 2) for k in pass_ms},
@@ -444,10 +541,26 @@ def main():
             decode_exchange = list(exchange_stats)
         kernel_only = dict(dt=kdt, dt_enqueue=kdt_enq, roofline=collect(kdt, k_steps) if rank == 0 else None)
 
-    # the pictures of the timed regions are real pictures: one chain's GOP against the checker (bit-exact) before anything is printed
+    # the pictures of the timed regions are real pictures: one chain per (stream, host GOP) — together every distinct work list of the
+    # run — against the checker (bit-exact) before anything is printed
     check = None
     if rank == 0 and not args.no_check:
-        check = check_pictures(params, chains[0], world)
+        seen, picked = set(), []
+        for k, ch in enumerate(chains):
+            key = (k % n_streams, k % n_host)
+            if key not in seen:
+                seen.add(key)
+                picked.append(k)
+        check = dict(ok=True, pictures=0, chains=picked, mismatching=[], checker=None,
+                     what=f"{len(picked)} chains = one per (stream, host GOP): every distinct work list of the run once")
+        for k in picked:
+            c = check_pictures(params, chains[k], world)
+            check["checker"] = c.get("checker")
+            check["pictures"] += c.get("pictures", 0)
+            check["mismatching"] += [f"chain {k}: {m}" for m in c.get("mismatching", [])]
+            if not c["ok"]:
+                check["ok"] = False
+                check["error"] = c.get("error")
         if not check["ok"]:
             print(f"bench.py: PICTURE MISMATCH against the checker: {check}", file=sys.stderr)
             sys.exit(4)

@@ -143,8 +143,10 @@ int oh_sei_picture_hash(const uint8_t *nal, size_t size, OhPictureHash *out)
     oh_nal_unescape(nal, size, rbsp, &n, NULL, 0, NULL);
     size_t p = 2;                                             /* behind the NAL header */
     int found = 0, bad = 0;
-    /* sei_message()s until only rbsp_trailing_bits are left (hevc_sei.c:183-200 more_rbsp_data) */
-    while (p < n && !(p == n - 1 && rbsp[p] == 0x80) && rbsp[p] != 0x80) {
+    /* sei_message()s until only rbsp_trailing_bits are left (hevc_sei.c:183-200 more_rbsp_data): the LAST byte being 0x80.  A 0x80
+     * anywhere else is a payloadType (128, structure_of_pictures_info), not the end: a hash message may follow it in the same NAL */
+    while (n > 0 && rbsp[n - 1] == 0) n--;                    /* cabac_zero_words / trailing zero bytes behind the trailing bits */
+    while (p < n && !(p == n - 1 && rbsp[p] == 0x80)) {
         unsigned type = 0, len = 0;
         while (p < n && rbsp[p] == 0xFF) { type += 255; p++; }
         if (p >= n) { bad = 1; break; }

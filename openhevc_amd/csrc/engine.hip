@@ -339,6 +339,9 @@ static int check_params(OhEngine *e, const OhPicParams *p)
     if (p->log2_ctb_size < 4 || p->log2_ctb_size > 6 || p->log2_min_cb_size < 3 || p->log2_min_cb_size > p->log2_ctb_size ||
         p->log2_min_tb_size < 2 || p->log2_min_tb_size > 5 || p->log2_min_pu_size != p->log2_min_cb_size - 1)
         FAIL(e, OH_E_ARG, "bad block size parameters");
+    if ((uint64_t)oh_ctb_width(p) * (uint64_t)oh_ctb_height(p) > 65535u)
+        FAIL(e, OH_E_UNSUPPORTED, "%d x %d picture with %d x %d CTBs has more than 65535 CTBs: the intra schedule (OhIntraCtu.ctu) counts them in 16 bits; use larger CTBs",
+             p->width, p->height, 1 << p->log2_ctb_size, 1 << p->log2_ctb_size);
     if (p->width % (1 << p->log2_min_cb_size) || p->height % (1 << p->log2_min_cb_size))
         FAIL(e, OH_E_ARG, "picture size must be a multiple of the minimum CB size");
     return OH_OK;
@@ -1590,8 +1593,10 @@ extern "C" int oh_frame_submit(OhEngine *e, const OhFrame *f)
     if (rc)
         return rc;
     rc = oh_frame_execute(e, df);
-    e->deferred.push_back(df);
-    return rc;
+    /* stream-ordered release: the arena returns to the pool behind the passes that read it.  (Rounds 1-2 parked the list until
+     * oh_engine_sync: a decoder that submits a long stream and syncs once at the end kept one arena per picture in HBM.) */
+    const int rr = oh_frame_release(e, df);
+    return rc ? rc : rr;
 }
 
 /* the two boundary-strength grids of an uploaded work list as the deblock pass reads them (handed over or derived from bs_in) */

@@ -14,6 +14,7 @@
  * workgroup barriers inside the CU instead of kernel launches.
  */
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../../include/ohevc_recorder.h"
@@ -79,6 +80,13 @@ void oh_rec_destroy(OhRecorder *r);
 
 OhRecorder *oh_rec_create(const OhPicParams *p)
 {
+    /* the intra schedule counts CTBs in 16 bits (OhIntraCtu.ctu): 8K with 16x16 CTBs (129 600) does not fit; the engine refuses such
+     * pictures with OH_E_UNSUPPORTED, the recorder does not start on them */
+    if (!p || (long long)oh_ctb_width(p) * oh_ctb_height(p) > 65535) {
+        if (p) fprintf(stderr, "ohevc recorder: %dx%d with %dx%d CTBs has more than 65535 CTBs (unsupported: use larger CTBs)\n",
+                       p->width, p->height, 1 << p->log2_ctb_size, 1 << p->log2_ctb_size);
+        return NULL;
+    }
     OhRecorder *r = (OhRecorder *)calloc(1, sizeof(*r));
     if (r) pthread_mutex_init(&r->mu, NULL);
     if (!r)

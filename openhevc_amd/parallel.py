@@ -166,7 +166,8 @@ class Turnstile:
             ticket = self.calls[lane] * self.lanes + lane
             deadline = time.monotonic() + self.timeout
             while self.next != ticket and self.failed is None:
-                if not self.cv.wait(timeout=1.0) and time.monotonic() > deadline:
+                self.cv.wait(timeout=1.0)
+                if self.next != ticket and self.failed is None and time.monotonic() > deadline:      # on every pass: a lane that is notified once a second would otherwise never time out
                     self.failed = TimeoutError(f"exchange ticket {ticket}: ticket {self.next} was never issued")
                     self.cv.notify_all()
             if self.failed is not None:

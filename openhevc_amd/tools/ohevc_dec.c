@@ -146,7 +146,7 @@ int main(int argc, char **argv)
     OhPicParams engine_p[MAX_DPB];
     for (int i = 0; i < MAX_DPB; i++) engine_id[i] = -1;
     FILE *fo = NULL;
-    int nb_frame = 0, nb_decoded = 0, width = 0, height = 0, bad_planes = 0, hashed = 0, rc = 0;
+    int nb_frame = 0, nb_decoded = 0, width = 0, height = 0, bad_planes = 0, hashed = 0, unverified = 0, rc = 0;
     uint8_t *planes[3] = { NULL, NULL, NULL };
     const double t0 = now_s();
 
@@ -204,6 +204,9 @@ int main(int argc, char **argv)
                         printf("Correct MD5 (poc: %d, plane: %d)\n", poc, c);
                 }
                 hashed++;
+            } else if (check_md5 && want.present) {
+                printf("picture hash of type %d (CRC / checksum) present but not verified (poc: %d)\n", want.hash_type, poc);
+                unverified++;
             }
             nb_decoded++;
         }
@@ -266,7 +269,7 @@ int main(int argc, char **argv)
     free(au);
     free(data);
     if (check_md5)
-        printf("md5: %d pictures checked, %d planes differ\n", hashed, bad_planes);
+        printf("md5: %d pictures checked, %d planes differ%s\n", hashed, bad_planes, unverified ? " (some pictures carry CRC / checksum hashes: not verified)" : "");
     printf("frame= %d fps= %.0f time= %.2f video_size= %dx%d\n", nb_frame, t > 0 ? nb_frame / t : 0.0, t, width, height);
     return rc ? rc : bad_planes ? 3 : 0;
 }

@@ -252,3 +252,12 @@ def record_work_lists(data, on_picture, threads=1, thread_type=1, bs_from_motion
     L.libOpenHevcClose(h)
     L.ref_hooked_bs_from_motion(0)
     return n
+
+
+if __name__ == "__main__":
+    # child process of bench.py's all-cores CPU baseline: decode STREAM with THREADS slice threads, nothing kept.  usage: refdec.py STREAM THREADS SSE(0|1)
+    import sys
+    with open(sys.argv[1], "rb") as fh:
+        _data = fh.read()
+    _n = len(decode(_data, threads=int(sys.argv[2]), thread_type=2, L=sse_lib() if int(sys.argv[3]) else lib(), keep=False))
+    sys.exit(0 if _n > 0 else 1)

@@ -65,8 +65,18 @@ def test_picture_md5_follows_the_finished_half():
 HOOKED = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hooked.so")
 REFDEC = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_ref.so")
 HARNESS = os.path.join(ROOT, "openhevc_amd", "ohevc_dec")
-need_front_end = pytest.mark.skipif(not (os.path.exists(HOOKED) and os.path.exists(REFDEC) and os.path.exists(HARNESS)),
-                                    reason="oracle/_ref front end / harness binary did not travel")
+
+
+@pytest.fixture
+def front_end():
+    """the hooked reference decoder (front end of the harness), the plain one (checker) and the harness binary.  These tests are
+    -m gpu: on a GPU box the three files must have travelled with the snapshot (oracle/_ref/ is git-ignored, not gpurun-ignored) — a
+    run without them would be 16 tests short and look just as green, so their absence FAILS here instead of skipping."""
+    missing = [f for f in (HOOKED, REFDEC, HARNESS) if not os.path.exists(f)]
+    assert not missing, f"did not travel to the GPU box (build them in the container: python -c 'import __graft_entry__ as g; g.build()'): {missing}"
+
+
+need_front_end = pytest.mark.usefixtures("front_end")
 
 STREAMS = [
     ("main8_lowdelay", 416, 240, 11, dict(n_pictures=8, gop=2)),

@@ -28,6 +28,7 @@ struct Pic {
     int32_t     stride[3] = {}, w[3] = {}, h[3] = {};
     bool        final_b = false;         /* which buffer holds the finished picture */
     uint32_t    gen = 0;                 /* bumped whenever the id is (re)installed: uploaded work lists remember it */
+    uint64_t    done_seq = 0;            /* the batch that last reconstructed the picture (OhEngine::batch_ev ring); 0: written by something else, or never */
 };
 
 struct EventSet { hipEvent_t ev[OH_N_PASSES + 1]; int n_frames = 1; };
@@ -104,6 +105,13 @@ struct OhEngine {
     /* what a kernel can tell the host when it cannot go on (the table slots and the passes have no error channel: hevcdsp.h's slots
      * return void): four words of pinned host memory, [0] OH_KE_* of the first failure, [1] picture id, [2] schedule entry / CTB
      * row; read by everything that waits for the stream (kernel_error) */
+    /* a ring of events, one behind every executed batch: a download of a finished picture waits for ITS batch (on the download
+     * stream), not for everything enqueued since — a decoder fetches the picture it outputs while the passes of the pictures it
+     * submitted later keep running */
+    enum { BATCH_RING = 64 };
+    hipEvent_t  batch_ev[BATCH_RING] = {};
+    uint64_t    batch_seq = 0;
+    hipStream_t dl_stream = nullptr;
     uint32_t   *kerr = nullptr;
     uint32_t    spin_limit = 1u << 22;   /* polls (with s_sleep between them, ~1 s in all) before a waiting workgroup gives up; OHEVC_SPIN_LIMIT */
 };
@@ -321,6 +329,8 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &ev : e->sync_events) (void)hipEventDestroy(ev);
     for (void *b : e->sum_pool) (void)hipHostFree(b);
     if (e->kerr) (void)hipHostFree(e->kerr);
+    for (auto &ev : e->batch_ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->dl_stream) { (void)hipStreamSynchronize(e->dl_stream); (void)hipStreamDestroy(e->dl_stream); }
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->own_stream)
         (void)hipStreamDestroy(e->stream);
@@ -456,6 +466,7 @@ extern "C" int oh_pic_set_final_half(OhEngine *e, int pic_id, int half)
     if (!p || (half != 0 && half != 1))
         FAIL(e, OH_E_ARG, "oh_pic_set_final_half: bad picture or half");
     p->final_b = half == 1;
+    p->done_seq = 0;                      /* filled from outside (an exchange): a download stays behind the whole engine stream */
     return OH_OK;
 }
 
@@ -472,6 +483,7 @@ static int upsample_tiles(OhEngine *e, int dst_pic, int src_pic, const OhUpsampl
     Pic *el = get_pic(e, dst_pic), *bl = get_pic(e, src_pic);
     if (!el || !bl || el == bl)
         FAIL(e, OH_E_ARG, "%s: bad picture ids", who);
+    el->done_seq = 0;
     if (el->p.bit_depth != 8 || bl->p.bit_depth != 8 || el->p.chroma_format_idc != 1 || bl->p.chroma_format_idc != 1)
         FAIL(e, OH_E_UNSUPPORTED, "%s: the reference's up-sampler is written for 8-bit 4:2:0 (byte edge buffers, shift 12)", who);
     const int w_el = el->p.width, h_el = el->p.height, w_bl = bl->p.width, h_bl = bl->p.height;
@@ -562,6 +574,7 @@ extern "C" int oh_pic_upload(OhEngine *e, int pic_id, const uint8_t *const plane
                                    (size_t)p->h[c], hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     p->final_b = false;
+    p->done_seq = 0;
     return OH_OK;
 }
 
@@ -661,12 +674,20 @@ extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *w
     OhEngine::Stage *sg = stage_acquire(e, total);
     if (!sg)
         FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", total);
+    /* a picture a batch of this engine finished, and whose event is still in the ring: the copies run on the download stream behind
+     * THAT batch; anything else (uploaded, up-sampled, received from another GPU, long ago): behind everything on the engine stream */
+    hipStream_t dl = e->stream;
+    if (p->done_seq && e->batch_seq - p->done_seq < OhEngine::BATCH_RING - 1) {
+        if (!e->dl_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->dl_stream, hipStreamNonBlocking));
+        HIPCHK(e, hipStreamWaitEvent(e->dl_stream, e->batch_ev[p->done_seq % OhEngine::BATCH_RING], 0));
+        dl = e->dl_stream;
+    }
     for (int c = 0; c < np; c++) {
         const int hs = oh_hshift(&p->p, c), vs = oh_vshift(&p->p, c);
         const uint8_t *src = (const uint8_t *)(p->final_b ? p->b[c] : p->a[c]) + ((size_t)(win->top >> vs) * p->stride[c] + (size_t)(win->left >> hs)) * bpp;
-        HIPCHK(e, hipMemcpy2DAsync((char *)sg->p + off[c], row[c], src, (size_t)p->stride[c] * bpp, row[c], rows[c], hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpy2DAsync((char *)sg->p + off[c], row[c], src, (size_t)p->stride[c] * bpp, row[c], rows[c], hipMemcpyDeviceToHost, dl));
     }
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipStreamSynchronize(dl));
     { const int ke = kernel_error(e); if (ke) return ke; }     /* a kernel that gave up: these samples are not the picture */
     for (int c = 0; c < np; c++) {
         const char *s = (const char *)sg->p + off[c];
@@ -1549,6 +1570,15 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
         HIPCHK(e, hipGetLastError());
         if (prof)
             e->ev_pending.push_back(es);
+        {   /* the batch's pictures are finished behind this point of the stream */
+            const uint64_t seq = ++e->batch_seq;
+            hipEvent_t &bev = e->batch_ev[seq % OhEngine::BATCH_RING];
+            if (!bev) HIPCHK(e, hipEventCreateWithFlags(&bev, hipEventDisableTiming));
+            HIPCHK(e, hipEventRecord(bev, st));
+            for (int i = 0; i < nb; i++)
+                if (Pic *c = get_pic(e, fr[i]->cur_pic))
+                    c->done_seq = seq;
+        }
     }
     return OH_OK;
 }

@@ -1,68 +1,75 @@
 /*
- * ohevc_dec — SDL-free counterpart of the reference's `hevc` test harness (main_hm/main.c:134-311, options main_hm/getopt.c:47-62)
- * for the MI355X engine:
+ * ohevc_dec — SDL-free, libavformat-free counterpart of the reference's `hevc` test harness (main_hm/main.c:115-311, options
+ * main_hm/getopt.c:47-62): a client of the PUBLIC API only.
  *
- *     ohevc_dec -i stream.bin -F <front-end.so> [-c] [-n] [-o out.yuv] [-s frames] [-p threads -f 2]
+ *     ohevc_dec -i stream.bin -F <library> [-c] [-n] [-g] [-o out.yuv] [-s frames] [-p threads] [-f thread type] [-b]
  *
- * reads a raw Annex-B file, splits it into access units (oh_annexb_split: what the reference's harness gets from libavformat's raw
- * HEVC demuxer through hevc_parser.c), hands every access unit to the FRONT END — the host decoder that does what stays on the host
- * (parameter sets, slice headers, CABAC, motion-vector and mode derivation: SURVEY.md §8 "out of scope") and records the picture's
- * work list through the table slots of libohevc_hip.so (include/ohevc_tables.h) — runs the work list on the GPU
- * (oh_frame_submit), and checks the result against the stream's decoded-picture-hash SEI with MD5s computed on the GPU
- * (oh_pics_md5): the reference's `decode_checksum_sei` check (hevc.c:4146-4162), its verdict lines included.  It ends with the
- * reference's summary line (main.c:304-306):
+ * <library> is any shared object that exports the 18 libOpenHevc* functions of gpac/modules/openhevc_dec/openHevcWrapper.h:79-98:
+ * the drop-in library with the MI355X engine inside (oracle/_ref/libopenhevc_hip.so) or the reference's own (libopenhevc_ref.so,
+ * libopenhevc_ref_sse.so) — the same loop, the same clock, so `frame= N fps= F` of the two are comparable line by line.
+ * The harness reads a raw Annex-B file, splits it into access units (oh_annexb_split: what the reference's harness gets from
+ * libavformat's raw HEVC demuxer through hevc_parser.c:40-87) and runs main.c's loop: libOpenHevcInit, SetCheckMD5, StartDecoder,
+ * then libOpenHevcDecode per access unit; for every released picture GetPictureInfo, and — with -o — GetOutputCpy into packed planes
+ * written to <out>_WxH.yuv exactly as main.c:246-274 does; -g fetches every released picture with libOpenHevcGetOutput (the
+ * display path of main.c:268-272 without a display) — with the drop-in library that is the device-to-host copy of the picture;
+ * without -o / -g a picture is decoded and never looked at, as with the reference's `hevc -n`.  After the last access unit it
+ * flushes with empty packets (main.c:225) and prints the reference's summary line (main.c:304-306):
  *
  *     frame= N fps= F time= T video_size= WxH
  *
- * The front end is named on the command line and loaded with dlopen(); it exports the libOpenHevc* API of the reference's wrapper
- * (gpac/modules/openhevc_dec/openHevcWrapper.h:79-98: libOpenHevcInit / StartDecoder / Decode / Close) plus
- *     const OhFrame *ref_hooked_finish(int *cur_id, int *poc, int *untranslated);
- * which returns the work list of the access unit just decoded (picture ids = the front end's DPB slots).  -c: do not check MD5
- * (as the reference's flag), -n: accepted and ignored (there is no display), -o: write the decoded pictures (whole coded planes,
- * decode order), -s: stop after so many pictures, -p / -f: threads of the front end as in the reference's harness — -f 2 (slice /
- * wavefront threads) is what the recording slots support with more than one thread.
+ * The MD5 check (-c switches it off, as in the reference) is the DECODER's (hevc.c:4146-4169): its "Correct MD5 (poc, plane)" /
+ * "Incorrect MD5" verdicts arrive on the library's log (stderr); the harness passes that log through to stdout, counts the verdicts
+ * and exits with 3 when a plane differed.  -b: boundary strengths derived on the GPU (drop-in library: OHEVC_BS_FROM_MOTION).
  */
 #include <dlfcn.h>
+#include <pthread.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "../../include/ohevc_annexb.h"
-#include "../../include/ohevc_frame.h"
-#include "../../include/ohevc_hip.h"
 
-typedef void *(*fe_init_fn)(int nb_pthreads, int thread_type);
-typedef int (*fe_start_fn)(void *h);
-typedef int (*fe_decode_fn)(void *h, const unsigned char *buf, int len, int64_t pts);
-typedef void (*fe_close_fn)(void *h);
-typedef const OhFrame *(*fe_finish_fn)(int *cur_id, int *poc, int *untranslated);
-/* the output side of the front end's public API (openHevcWrapper.h:38-66, :86): the frame libOpenHevcDecode just released for
- * output — in OUTPUT order, inside its conformance window — as plane pointers into the front end's picture buffers; the harness
- * only uses them to learn WHICH picture that is (fe_locate) and takes the samples from the engine's copy */
-typedef struct FeRational { int num, den; } FeRational;
-typedef struct FeFrameInfo {
+/* openHevcWrapper.h:38-77, re-declared: the harness is compiled without the reference tree */
+typedef void *OpenHevc_Handle;
+typedef struct OpenHevc_Rational { int num, den; } OpenHevc_Rational;
+typedef struct OpenHevc_FrameInfo {
     int nYPitch, nUPitch, nVPitch, nBitDepth, nWidth, nHeight, chromat_format;
-    FeRational sample_aspect_ratio, frameRate;
+    OpenHevc_Rational sample_aspect_ratio, frameRate;
     int display_picture_number, flag;
     int64_t nTimeStamp;
-} FeFrameInfo;
-typedef struct FeFrame { void **pvY, **pvU, **pvV; FeFrameInfo frameInfo; } FeFrame;
-typedef int (*fe_output_fn)(void *h, int got_picture, FeFrame *frame);
-typedef int (*fe_locate_fn)(const void *luma, int *x, int *y);     /* DPB slot (= picture id of the work lists) and the window's origin */
+} OpenHevc_FrameInfo;
+typedef struct OpenHevc_Frame { void **pvY, **pvU, **pvV; OpenHevc_FrameInfo frameInfo; } OpenHevc_Frame;
+typedef struct OpenHevc_Frame_cpy { void *pvY, *pvU, *pvV; OpenHevc_FrameInfo frameInfo; } OpenHevc_Frame_cpy;
+enum { YUV420 = 0, YUV422, YUV444 };
+
+static struct {
+    OpenHevc_Handle (*Init)(int nb_pthreads, int thread_type);
+    int  (*StartDecoder)(OpenHevc_Handle);
+    int  (*Decode)(OpenHevc_Handle, const unsigned char *buff, int nal_len, int64_t pts);
+    void (*GetPictureInfo)(OpenHevc_Handle, OpenHevc_FrameInfo *);
+    int  (*GetOutput)(OpenHevc_Handle, int got_picture, OpenHevc_Frame *);
+    int  (*GetOutputCpy)(OpenHevc_Handle, int got_picture, OpenHevc_Frame_cpy *);
+    void (*SetCheckMD5)(OpenHevc_Handle, int val);
+    void (*SetDebugMode)(OpenHevc_Handle, int val);
+    void (*Close)(OpenHevc_Handle);
+} api;
 
 static void usage(const char *prog)
 {
-    printf("%s: -i <file> -F <front end> [-b] [-c] [-n] [-o <output file>] [-s <num>]\n", prog);
-    printf("     -b : boundary strengths on the GPU (the front end hands over its motion field instead of finished grids)\n");
+    printf("%s: -i <file> -F <library> [-b] [-c] [-f <type>] [-g] [-n] [-o <output file>] [-p <threads>] [-s <num>]\n", prog);
+    printf("     -b : boundary strengths on the GPU (drop-in library)\n");
     printf("     -c : no check md5\n");
-    printf("     -F <shared object of the host decoder with the recording table slots linked in>\n");
+    printf("     -f <thread type> (1: frame, 2: slice, 4: frameslice)\n");
+    printf("     -F <shared object exporting the libOpenHevc* API (openHevcWrapper.h)>\n");
+    printf("     -g : get every released picture (libOpenHevcGetOutput)\n");
     printf("     -i <input file>\n");
     printf("     -n : no display (there is none)\n");
     printf("     -o <output file>\n");
+    printf("     -p <number of threads> \n");
     printf("     -s <num> Stop after num frames \n");
-    printf("     -p <number of threads of the front end> \n");
-    printf("     -f <thread type> (2: slice; with -p 1 anything)\n");
 }
 
 static double now_s(void)
@@ -72,12 +79,46 @@ static double now_s(void)
     return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
-#define MAX_DPB 64
+/* the library's log (file descriptor 2) -> stdout, the MD5 verdicts counted on the way */
+static struct { int rd, saved_err, correct, incorrect; pthread_t th; } logp;
+static void *log_reader(void *arg)
+{
+    (void)arg;
+    FILE *in = fdopen(logp.rd, "r");
+    char line[4096];
+    while (in && fgets(line, sizeof(line), in)) {
+        if (strstr(line, "Incorrect MD5")) logp.incorrect++;
+        else if (strstr(line, "Correct MD5")) logp.correct++;
+        fputs(line, stdout);
+    }
+    if (in) fclose(in);
+    return NULL;
+}
+static void log_capture_begin(void)
+{
+    int fds[2];
+    fflush(stderr);
+    if (pipe(fds) != 0) return;
+    logp.saved_err = dup(2);
+    dup2(fds[1], 2);
+    close(fds[1]);
+    logp.rd = fds[0];
+    pthread_create(&logp.th, NULL, log_reader, NULL);
+}
+static void log_capture_end(void)
+{
+    if (!logp.saved_err) return;
+    fflush(stderr);
+    dup2(logp.saved_err, 2);                                  /* closes the pipe's write end: the reader sees end of file */
+    close(logp.saved_err);
+    pthread_join(logp.th, NULL);
+    fflush(stdout);
+}
 
 int main(int argc, char **argv)
 {
-    const char *input = NULL, *front = NULL, *output = NULL;
-    int check_md5 = 1, num_frames = 0, nb_pthreads = 1, thread_type = 1, bs_on_gpu = 0;
+    const char *input = NULL, *library = NULL, *output = NULL;
+    int check_md5 = 1, num_frames = 0, nb_pthreads = 1, thread_type = 1, bs_on_gpu = 0, get_output = 0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         if (a[0] != '-' || !a[1] || a[2]) { usage(argv[0]); return 2; }
@@ -86,9 +127,10 @@ int main(int argc, char **argv)
         switch (a[1]) {
         case 'b': bs_on_gpu = 1; break;
         case 'c': check_md5 = 0; break;
+        case 'g': get_output = 1; break;
         case 'n': break;
         case 'i': input = argv[++i]; break;
-        case 'F': front = argv[++i]; break;
+        case 'F': library = argv[++i]; break;
         case 'o': output = argv[++i]; break;
         case 's': num_frames = atoi(argv[++i]); break;
         case 'p': nb_pthreads = atoi(argv[++i]); break;
@@ -97,11 +139,8 @@ int main(int argc, char **argv)
         }
     }
     if (!input) { printf("No input file specified.\nSpecify it with: -i <filename>\n"); return 1; }
-    if (!front) { printf("No front end specified.\nSpecify it with: -F <shared object>\n"); return 1; }
-    if (nb_pthreads < 1 || (nb_pthreads > 1 && thread_type != 2)) {
-        printf("the recording table slots support several front-end threads as slice / wavefront threads only (-f 2)\n");
-        return 2;
-    }
+    if (!library) { printf("No decoder library specified.\nSpecify it with: -F <shared object>\n"); return 1; }
+    if (bs_on_gpu) setenv("OHEVC_BS_FROM_MOTION", "1", 1);
 
     FILE *fi = fopen(input, "rb");
     if (!fi) { printf("%s", input); return 1; }
@@ -111,165 +150,91 @@ int main(int argc, char **argv)
     uint8_t *data = (uint8_t *)calloc((size_t)(fsize > 0 ? fsize : 0) + 64, 1);          /* zero padding behind the last packet (FF_INPUT_BUFFER_PADDING_SIZE) */
     if (!data || fread(data, 1, (size_t)fsize, fi) != (size_t)fsize) { fprintf(stderr, "could not read %s\n", input); return 1; }
     fclose(fi);
-
     long n_au = oh_annexb_split(data, (size_t)fsize, NULL, 0);
     size_t cap = (size_t)(-n_au) + 1;
     size_t *au = (size_t *)malloc(cap * sizeof(*au));
     n_au = oh_annexb_split(data, (size_t)fsize, au, cap);
     if (n_au < 0) { fprintf(stderr, "access-unit split failed\n"); return 1; }
 
-    void *so = dlopen(front, RTLD_NOW | RTLD_LOCAL);
-    if (!so) { fprintf(stderr, "could not open the front end: %s\n", dlerror()); return 1; }
-    fe_init_fn fe_init = (fe_init_fn)dlsym(so, "libOpenHevcInit");
-    fe_start_fn fe_start = (fe_start_fn)dlsym(so, "libOpenHevcStartDecoder");
-    fe_decode_fn fe_decode = (fe_decode_fn)dlsym(so, "libOpenHevcDecode");
-    fe_close_fn fe_close = (fe_close_fn)dlsym(so, "libOpenHevcClose");
-    fe_finish_fn fe_finish = (fe_finish_fn)dlsym(so, "ref_hooked_finish");
-    fe_output_fn fe_output = (fe_output_fn)dlsym(so, "libOpenHevcGetOutput");
-    fe_locate_fn fe_locate = (fe_locate_fn)dlsym(so, "ref_hooked_locate");
-    if (!fe_init || !fe_start || !fe_decode || !fe_close || !fe_finish || !fe_output || !fe_locate) {
-        fprintf(stderr, "%s does not export libOpenHevcInit / StartDecoder / Decode / GetOutput / Close / ref_hooked_finish / ref_hooked_locate\n", front);
+    void *so = dlopen(library, RTLD_NOW | RTLD_LOCAL);
+    if (!so) { fprintf(stderr, "could not open the decoder library: %s\n", dlerror()); return 1; }
+#define SYM(field, name) (*(void **)&api.field = dlsym(so, name))
+    SYM(Init, "libOpenHevcInit"); SYM(StartDecoder, "libOpenHevcStartDecoder"); SYM(Decode, "libOpenHevcDecode");
+    SYM(GetPictureInfo, "libOpenHevcGetPictureInfo"); SYM(GetOutput, "libOpenHevcGetOutput"); SYM(GetOutputCpy, "libOpenHevcGetOutputCpy");
+    SYM(SetCheckMD5, "libOpenHevcSetCheckMD5"); SYM(SetDebugMode, "libOpenHevcSetDebugMode"); SYM(Close, "libOpenHevcClose");
+#undef SYM
+    if (!api.Init || !api.StartDecoder || !api.Decode || !api.GetPictureInfo || !api.GetOutput || !api.GetOutputCpy || !api.SetCheckMD5 || !api.Close) {
+        fprintf(stderr, "%s does not export the libOpenHevc* API (openHevcWrapper.h)\n", library);
         return 1;
     }
-    if (bs_on_gpu) {
-        void (*fe_bs)(int) = (void (*)(int))dlsym(so, "ref_hooked_bs_from_motion");
-        if (!fe_bs) { fprintf(stderr, "%s cannot hand over its motion field (no ref_hooked_bs_from_motion)\n", front); return 1; }
-        fe_bs(1);                                             /* work lists with OhFrame.bs_in: bs_kernel derives both grids */
-    }
-    void *h = fe_init(nb_pthreads, thread_type);
-    if (!h || fe_start(h) != 1) { fprintf(stderr, "could not open OpenHevc\n"); return 1; }
 
-    OhEngine *e = NULL;
-    if (oh_engine_create(&e, 0) != OH_OK) { fprintf(stderr, "could not create the engine (no HIP device?)\n"); return 1; }
+    log_capture_begin();
+    int rc = 0;
+    OpenHevc_Handle h = api.Init(nb_pthreads, thread_type);
+    if (!h) { fprintf(stderr, "could not open OpenHevc\n"); log_capture_end(); return 1; }
+    api.SetCheckMD5(h, check_md5);
+    if (api.SetDebugMode) api.SetDebugMode(h, 0);
+    if (api.StartDecoder(h) != 1) { fprintf(stderr, "could not start the decoder (threads %d, thread type %d)\n", nb_pthreads, thread_type); log_capture_end(); return 2; }
 
-    int engine_id[MAX_DPB];
-    OhPicParams engine_p[MAX_DPB];
-    for (int i = 0; i < MAX_DPB; i++) engine_id[i] = -1;
     FILE *fo = NULL;
-    int nb_frame = 0, nb_decoded = 0, width = 0, height = 0, bad_planes = 0, hashed = 0, unverified = 0, rc = 0;
-    uint8_t *planes[3] = { NULL, NULL, NULL };
+    OpenHevc_Frame frame;
+    OpenHevc_Frame_cpy cpy;
+    memset(&frame, 0, sizeof(frame));
+    memset(&cpy, 0, sizeof(cpy));
+    int nb_frame = 0, width = -1, height = -1, stop = 0;
     const double t0 = now_s();
-
-    for (long k = 0; !rc; k++) {                             /* k >= n_au: flushing, one released picture per call */
-        const uint8_t *buf = k < n_au ? data + au[k] : NULL;
-        const size_t len = k < n_au ? au[k + 1] - au[k] : 0;
-        OhPictureHash want;
-        memset(&want, 0, sizeof(want));
-        if (check_md5 && k < n_au) {
-            OhNal units[256];
-            long nu = oh_annexb_nal_units(buf, len, units, 256);
-            for (long u = 0; u < nu && u < 256; u++)
-                if (units[u].type == 39 || units[u].type == 40) {
-                    OhPictureHash ph;
-                    if (oh_sei_picture_hash(buf + units[u].offset, units[u].size, &ph) == 1)
-                        want = ph;
-                }
-        }
-        const int got_picture = k < n_au ? fe_decode(h, buf, (int)len, k) : fe_decode(h, NULL, 0, k);      /* past the last access unit: flush (main.c:225) */
-        if (got_picture < 0) { fprintf(stderr, "front end failed on access unit %ld\n", k); rc = 1; break; }
-        int cur = -1, poc = 0, untranslated = 0;
-        const OhFrame *f = k < n_au ? fe_finish(&cur, &poc, &untranslated) : NULL;
-        if (f) {
-            if (untranslated) { fprintf(stderr, "%d table-slot calls of picture %d could not be turned into work-list items\n", untranslated, nb_decoded); rc = 1; break; }
-            /* engine pictures for the DPB slots this work list names */
-            OhFrame g = *f;
-            int ids[1 + OH_MAX_REFS], n_ids = 0;
-            ids[n_ids++] = cur;
-            for (int r = 0; r < OH_MAX_REFS; r++)
-                if (f->ref_pics[r] >= 0) ids[n_ids++] = f->ref_pics[r];
-            for (int q = 0; q < n_ids && !rc; q++) {
-                const int d = ids[q];
-                if (d < 0 || d >= MAX_DPB) { fprintf(stderr, "DPB slot %d out of range\n", d); rc = 1; break; }
-                const int same = engine_id[d] >= 0 && engine_p[d].width == f->p.width && engine_p[d].height == f->p.height &&
-                                 engine_p[d].bit_depth == f->p.bit_depth && engine_p[d].chroma_format_idc == f->p.chroma_format_idc;
-                if (!same) {
-                    if (engine_id[d] >= 0) oh_pic_free(e, engine_id[d]);
-                    if (oh_pic_alloc(e, &f->p, &engine_id[d]) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
-                    engine_p[d] = f->p;
+    for (long k = 0; !stop; k++) {                           /* k >= n_au: flushing with empty packets (main.c:225) */
+        const int flushing = k >= n_au;
+        const int got_picture = api.Decode(h, flushing ? NULL : data + au[k], flushing ? 0 : (int)(au[k + 1] - au[k]), k);
+        if (got_picture < 0) { fprintf(stderr, "decoder failed on access unit %ld\n", k); rc = 1; break; }
+        if (got_picture > 0) {
+            api.GetPictureInfo(h, &frame.frameInfo);
+            if (width != frame.frameInfo.nWidth || height != frame.frameInfo.nHeight) {
+                width = frame.frameInfo.nWidth; height = frame.frameInfo.nHeight;
+                if (fo) fclose(fo);
+                fo = NULL;
+                if (output) {
+                    char name[1024], stem[900];
+                    snprintf(stem, sizeof(stem), "%s", output);
+                    const size_t sl = strlen(stem);
+                    if (sl > 4 && stem[sl - 4] == '.') stem[sl - 4] = 0;                  /* getopt.c:174-175 */
+                    snprintf(name, sizeof(name), "%s_%dx%d.yuv", stem, width, height);   /* main.c:231 */
+                    fo = fopen(name, "wb");
+                    if (!fo) { fprintf(stderr, "could not open %s\n", name); rc = 1; break; }
                 }
             }
-            if (rc) break;
-            g.cur_pic = engine_id[cur];
-            for (int r = 0; r < OH_MAX_REFS; r++)
-                g.ref_pics[r] = f->ref_pics[r] >= 0 ? engine_id[f->ref_pics[r]] : -1;
-            if (oh_frame_submit(e, &g) != OH_OK) { fprintf(stderr, "picture %d: %s\n", nb_decoded, oh_engine_last_error(e)); rc = 1; break; }
-            if (check_md5 && want.present && want.hash_type == 0) {
-                uint8_t got[48];
-                if (oh_pics_md5(e, &g.cur_pic, 1, got) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
-                for (int c = 0; c < (f->p.chroma_format_idc ? 3 : 1); c++) {
-                    if (memcmp(got + 16 * c, want.md5[c], 16)) {
-                        printf("Incorrect MD5 (poc: %d, plane: %d)\n", poc, c);
-                        bad_planes++;
-                    } else
-                        printf("Correct MD5 (poc: %d, plane: %d)\n", poc, c);
-                }
-                hashed++;
-            } else if (check_md5 && want.present) {
-                printf("picture hash of type %d (CRC / checksum) present but not verified (poc: %d)\n", want.hash_type, poc);
-                unverified++;
+            if (get_output)
+                api.GetOutput(h, 1, &frame);                                              /* main.c:268-272 without the display */
+            if (fo) {
+                /* packed planes: rows of width << pixel_shift bytes (libOpenHevcGetPictureInfoCpy's pitches); the reference's harness sizes
+                 * its buffers from GetPictureInfo's (main.c:246-251), which are never smaller */
+                const int ps = frame.frameInfo.nBitDepth > 8, cf = frame.frameInfo.chromat_format;
+                const int hs = cf != YUV444, vs = cf == YUV420;
+                const size_t yb = ((size_t)width << ps) * (size_t)height, cb = ((size_t)(width >> hs) << ps) * (size_t)(height >> vs);
+                cpy.pvY = realloc(cpy.pvY, yb ? yb : 1); cpy.pvU = realloc(cpy.pvU, cb ? cb : 1); cpy.pvV = realloc(cpy.pvV, cb ? cb : 1);
+                api.GetOutputCpy(h, 1, &cpy);
+                fwrite(cpy.pvY, 1, yb, fo);
+                fwrite(cpy.pvU, 1, cb, fo);
+                fwrite(cpy.pvV, 1, cb, fo);
             }
-            nb_decoded++;
+            nb_frame++;
+            if (nb_frame == num_frames)
+                stop = 1;
+        } else if (flushing) {
+            stop = 1;
         }
-        if (got_picture == 0) {
-            if (k >= n_au)
-                break;                                        /* flushed */
-            continue;                                         /* nothing released for output yet (reordering), or no picture in the access unit */
-        }
-        /* the picture the front end released for output (bumping and cropping are its host logic: hevc_refs.c:182-290) */
-        FeFrame fr;
-        memset(&fr, 0, sizeof(fr));
-        fe_output(h, 1, &fr);
-        int ox = 0, oy = 0;
-        const int slot = fe_locate((const void *)fr.pvY, &ox, &oy);
-        if (slot < 0 || slot >= MAX_DPB || engine_id[slot] < 0) { fprintf(stderr, "output picture %d is not a picture of the engine (slot %d)\n", nb_frame, slot); rc = 1; break; }
-        const OhPicParams *op = &engine_p[slot];
-        if (width != fr.frameInfo.nWidth || height != fr.frameInfo.nHeight) {
-            width = fr.frameInfo.nWidth; height = fr.frameInfo.nHeight;
-            if (fo) fclose(fo);
-            fo = NULL;
-            if (output) {
-                char name[1024];
-                char stem[900];
-                snprintf(stem, sizeof(stem), "%s", output);
-                const size_t sl = strlen(stem);
-                if (sl > 4 && stem[sl - 4] == '.') stem[sl - 4] = 0;                  /* getopt.c:174-175 */
-                snprintf(name, sizeof(name), "%s_%dx%d.yuv", stem, width, height);   /* main.c:231 */
-                fo = fopen(name, "wb");
-                if (!fo) { fprintf(stderr, "could not open %s\n", name); rc = 1; break; }
-            }
-        }
-        if (fo) {
-            const size_t bpp = op->bit_depth > 8 ? 2 : 1;
-            const int cf = op->chroma_format_idc;
-            const int hs = cf == 1 || cf == 2, vs = cf == 1;
-            ptrdiff_t strides[3];
-            size_t bytes[3];
-            for (int c = 0; c < 3; c++) {
-                const size_t w = c ? (size_t)(width >> hs) : (size_t)width, hh = c ? (size_t)(height >> vs) : (size_t)height;
-                strides[c] = (ptrdiff_t)(w * bpp);
-                bytes[c] = cf || !c ? w * bpp * hh : 0;
-                planes[c] = (uint8_t *)realloc(planes[c], bytes[c] ? bytes[c] : 1);
-            }
-            const OhWindow win = { ox, op->width - ox - width, oy, op->height - oy - height };
-            if (win.right < 0 || win.bottom < 0) { fprintf(stderr, "output window %dx%d+%d+%d leaves the %dx%d picture\n", width, height, ox, oy, op->width, op->height); rc = 1; break; }
-            if (oh_pic_download_window(e, engine_id[slot], &win, planes, strides) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; break; }
-            for (int c = 0; c < 3; c++)
-                fwrite(planes[c], 1, bytes[c], fo);
-        }
-        nb_frame++;
-        if (nb_frame == num_frames)
-            break;
     }
-    if (oh_engine_sync(e) != OH_OK) { fprintf(stderr, "%s\n", oh_engine_last_error(e)); rc = 1; }
-    const double t = now_s() - t0;
+    const double t = now_s() - t0;                           /* the decode loop, as main.c's SDL_GetTime() around it; Close (which waits for the GPU) below */
     if (fo) fclose(fo);
-    for (int c = 0; c < 3; c++) free(planes[c]);
-    fe_close(h);
-    oh_engine_destroy(e);
+    free(cpy.pvY); free(cpy.pvU); free(cpy.pvV);
+    api.Close(h);
+    const double t_closed = now_s() - t0;
+    log_capture_end();
     free(au);
     free(data);
     if (check_md5)
-        printf("md5: %d pictures checked, %d planes differ%s\n", hashed, bad_planes, unverified ? " (some pictures carry CRC / checksum hashes: not verified)" : "");
+        printf("md5: %d pictures checked, %d planes differ\n", (logp.correct + logp.incorrect + 2) / 3, logp.incorrect);
+    printf("time until the decoder was closed (everything enqueued has run)= %.3f\n", t_closed);
     printf("frame= %d fps= %.0f time= %.2f video_size= %dx%d\n", nb_frame, t > 0 ? nb_frame / t : 0.0, t, width, height);
-    return rc ? rc : bad_planes ? 3 : 0;
+    return rc ? rc : logp.incorrect ? 3 : 0;
 }

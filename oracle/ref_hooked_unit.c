@@ -13,6 +13,13 @@
  * calls — is the reference's own code running as it always does.  The library (oracle/_ref/libopenhevc_hooked.so) decodes a
  * stream into WORK LISTS; tests/test_streams.py runs them through the checker (and -m gpu tests through the engine) and compares
  * the pictures with what the unmodified reference decoder (libopenhevc_ref.so) outputs for the same stream.
+ *
+ * Compiled a second time with -DOH_WITH_ENGINE and linked against openhevc_amd/libohevc_hip.so this unit is the decoder half of
+ * the DROP-IN LIBRARY (oracle/_ref/libopenhevc_hip.so, the wrapper half is ref_wrapper_hip_unit.c): the AVCodec's decode callback
+ * is followed by finish + oh_frame_submit (every picture's work list goes to the MI355X engine as soon as its access unit is
+ * parsed), the decoder's own SEI picture-hash check takes its digests from the GPU (oh_pics_md5), and the wrapper's
+ * libOpenHevcGetOutput / GetOutputCpy get the picture's samples out of HBM first — the 18 libOpenHevc* entry points with the
+ * engine inside, which a caller of openHevcWrapper.h uses exactly like the reference's library.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -42,6 +49,7 @@ static struct {
     int untranslated;
     int scaling_on;
     OhScalingList scaling;
+    int last_engine_pic;              /* engine build: the engine picture the last submitted work list reconstructs */
 } H;
 
 static int g_bs_from_motion;          /* ref_hooked_bs_from_motion(): the work lists carry the boundary-strength INPUTS */
@@ -241,6 +249,160 @@ static void hooked_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_s
 #define ff_hevc_deblocking_boundary_strengths(s, x, y, l) hooked_boundary_strengths(s, x, y, l)
 __attribute__((visibility("default"))) void ref_hooked_bs_from_motion(int on) { g_bs_from_motion = on; }
 
+#ifdef OH_WITH_ENGINE
+/* ============================ the engine behind the decoder (drop-in library) ============================ */
+#include <pthread.h>
+#include "../include/ohevc_hip.h"
+
+/* Engine pictures are keyed by the HOST buffer of the decoder's frame (plane 0 origin): libavcodec's frame pool hands the same
+ * buffers out again and again, a buffer holds one picture at a time, and the frame libOpenHevcGetOutput exposes keeps its buffer
+ * referenced until the next libOpenHevcDecode — so "the engine picture of this host buffer" is the picture the caller is asking
+ * for even after the DPB slot has moved on (hevc_refs.c:45-65 ff_hevc_unref_frame). */
+static struct {
+    OhEngine *e;
+    int failed;
+    struct { const uint8_t *base; size_t span; int id; OhPicParams p; } pic[256];
+    int n;
+    pthread_mutex_t lock;
+} E = { .lock = PTHREAD_MUTEX_INITIALIZER };
+static __thread HEVCContext *tls_s;           /* the context whose access unit this thread is decoding (hooked_decode_frame) */
+static __thread int tls_md5_plane;            /* calc_md5 calls seen for the picture (0..2) */
+static __thread uint8_t tls_md5[48];
+
+static OhEngine *the_engine(void)
+{
+    if (!E.e && !E.failed) {
+        const char *dev = getenv("OHEVC_DEVICE");
+        if (oh_engine_create(&E.e, dev ? atoi(dev) : 0) != OH_OK) {
+            fprintf(stderr, "libopenhevc_hip: no MI355X engine (there is no CPU fallback)\n");
+            E.e = NULL; E.failed = 1;
+        }
+    }
+    return E.e;
+}
+static int same_geometry(const OhPicParams *a, const OhPicParams *b)
+{
+    return a->width == b->width && a->height == b->height && a->bit_depth == b->bit_depth && a->chroma_format_idc == b->chroma_format_idc;
+}
+/* the engine picture of a decoder frame (created on first sight, re-created when the buffer comes back with another geometry) */
+static int engine_pic_of(const AVFrame *fr, const OhPicParams *p)
+{
+    OhEngine *e = the_engine();
+    if (!e || !fr || !fr->data[0]) return -1;
+    int slot = -1;
+    for (int i = 0; i < E.n; i++)
+        if (E.pic[i].base == fr->data[0]) { slot = i; break; }
+    if (slot >= 0 && same_geometry(&E.pic[slot].p, p))
+        return E.pic[slot].id;
+    if (slot < 0) {
+        if (E.n == (int)(sizeof(E.pic) / sizeof(E.pic[0]))) { fprintf(stderr, "libopenhevc_hip: more than %d host frame buffers in use\n", E.n); return -1; }
+        slot = E.n++;
+    } else {
+        oh_pic_free(e, E.pic[slot].id);
+    }
+    int id = -1;
+    if (oh_pic_alloc(e, p, &id) != OH_OK) { fprintf(stderr, "libopenhevc_hip: %s\n", oh_engine_last_error(e)); E.n -= (slot == E.n - 1); return -1; }
+    E.pic[slot].base = fr->data[0]; E.pic[slot].span = (size_t)fr->linesize[0] * (size_t)p->height; E.pic[slot].id = id; E.pic[slot].p = *p;
+    return id;
+}
+
+/* end of an access unit on the thread that decoded it: the picture's work list -> engine (asynchronous).  Idempotent. */
+static int finish_and_submit(HEVCContext *s)
+{
+    int cur = -1, poc = 0, bad = 0;
+    if (!H.open || H.s != s)
+        return 0;
+    const OhFrame *f = ref_hooked_finish(&cur, &poc, &bad);
+    if (!f)
+        return 0;
+    if (bad) { fprintf(stderr, "libopenhevc_hip: %d table-slot calls of the picture (poc %d) could not be turned into work-list items\n", bad, poc); return -1; }
+    pthread_mutex_lock(&E.lock);
+    OhEngine *e = the_engine();
+    int rc = e ? 0 : -1;
+    OhFrame g = *f;
+    if (!rc) {
+        g.cur_pic = engine_pic_of(s->DPB[cur].frame, &f->p);
+        if (g.cur_pic < 0) rc = -1;
+        for (int r = 0; r < OH_MAX_REFS && !rc; r++) {
+            g.ref_pics[r] = -1;
+            if (f->ref_pics[r] >= 0) {
+                g.ref_pics[r] = engine_pic_of(s->DPB[f->ref_pics[r]].frame, &f->p);
+                if (g.ref_pics[r] < 0) rc = -1;
+            }
+        }
+    }
+    if (!rc && H.scaling_on && g.sparse) g.scaling = &H.scaling;
+    if (!rc && oh_frame_submit(e, &g) != OH_OK) { fprintf(stderr, "libopenhevc_hip: picture poc %d: %s\n", poc, oh_engine_last_error(e)); rc = -1; }
+    H.last_engine_pic = rc ? -1 : g.cur_pic;
+    pthread_mutex_unlock(&E.lock);
+    return rc;
+}
+
+/* decode_checksum_sei (hevc.c:4146-4169): the decoder hashes s->ref->frame's planes — host memory nothing was decoded into.  Its
+ * three calc_md5() calls (hevc.c:4623-4638) keep their place; the av_md5_sum inside them is replaced: it hands out the digest the
+ * GPU computed over the engine's picture (md5.hip: oh_pics_md5, 48 bytes over PCIe instead of the picture), so the decoder's own
+ * "Correct MD5 (poc, plane)" / "Incorrect MD5" lines judge what the engine decoded. */
+static void hooked_md5_final(uint8_t *dst)
+{
+    if (tls_md5_plane == 0) {
+        memset(tls_md5, 0, sizeof(tls_md5));
+        if (tls_s && finish_and_submit(tls_s) == 0 && H.last_engine_pic >= 0) {
+            pthread_mutex_lock(&E.lock);
+            if (oh_pics_md5(E.e, &H.last_engine_pic, 1, tls_md5) != OH_OK)
+                fprintf(stderr, "libopenhevc_hip: %s\n", oh_engine_last_error(E.e));
+            pthread_mutex_unlock(&E.lock);
+        }
+    }
+    memcpy(dst, tls_md5 + 16 * tls_md5_plane, 16);
+    tls_md5_plane = (tls_md5_plane + 1) % 3;
+}
+
+/* the samples of the frame libOpenHevcDecode released for output, into the host planes the wrapper exposes: `out` is the wrapper's
+ * AVFrame (data[] = the DPB frame's planes moved to the conformance window's origin, hevc_refs.c:248-254; width / height = the
+ * cropped size) */
+__attribute__((visibility("default"))) int oh_hooked_fetch_output(AVFrame *out)
+{
+    int rc = -1;
+    pthread_mutex_lock(&E.lock);
+    for (int i = 0; i < E.n && E.e; i++) {
+        const ptrdiff_t off = out->data[0] - E.pic[i].base;
+        if (off < 0 || (size_t)off >= E.pic[i].span || out->linesize[0] <= 0)
+            continue;
+        const OhPicParams *p = &E.pic[i].p;
+        const int ps = p->bit_depth > 8;
+        const int y = (int)(off / out->linesize[0]), x = (int)(off % out->linesize[0]) >> ps;
+        const OhWindow win = { x, p->width - x - out->width, y, p->height - y - out->height };
+        ptrdiff_t strides[3] = { out->linesize[0], out->linesize[1], out->linesize[2] };
+        uint8_t *planes[3] = { out->data[0], out->data[1], out->data[2] };
+        if (win.right < 0 || win.bottom < 0)
+            fprintf(stderr, "libopenhevc_hip: output window %dx%d+%d+%d leaves the %dx%d picture\n", out->width, out->height, x, y, p->width, p->height);
+        else if (oh_pic_download_window(E.e, E.pic[i].id, &win, planes, strides) != OH_OK)
+            fprintf(stderr, "libopenhevc_hip: %s\n", oh_engine_last_error(E.e));
+        else
+            rc = 0;
+        break;
+    }
+    pthread_mutex_unlock(&E.lock);
+    return rc;
+}
+__attribute__((visibility("default"))) void oh_hooked_engine_close(void)
+{
+    pthread_mutex_lock(&E.lock);
+    if (E.e) { oh_engine_sync(E.e); oh_engine_destroy(E.e); }
+    E.e = NULL; E.n = 0; E.failed = 0;
+    pthread_mutex_unlock(&E.lock);
+}
+__attribute__((visibility("default"))) int oh_hooked_engine_sync(void)
+{
+    pthread_mutex_lock(&E.lock);
+    const int rc = E.e ? oh_engine_sync(E.e) : 0;
+    if (rc) fprintf(stderr, "libopenhevc_hip: %s\n", oh_engine_last_error(E.e));
+    pthread_mutex_unlock(&E.lock);
+    return rc;
+}
+#define av_md5_sum(dst, src, len)     hooked_md5_final(dst)
+#endif /* OH_WITH_ENGINE */
+
 #define ff_hevc_dsp_init(c, bd)   do { ff_hevc_dsp_init(c, bd);  ff_hevcdsp_init_hip((void *)(c), bd); } while (0)
 #define ff_hevc_pred_init(c, bd)  do { ff_hevc_pred_init(c, bd); ff_hevcpred_init_hip((void *)(c), bd); } while (0)
 #define ff_videodsp_init(c, bd)   do { ff_videodsp_init(c, bd);  ff_videodsp_init_hip((void *)(c), bd); } while (0)
@@ -249,3 +411,24 @@ __attribute__((visibility("default"))) void ref_hooked_bs_from_motion(int on) { 
 #define ff_hevc_hls_filter(s, x, y, c)  ((void)0)
 
 #include "libavcodec/hevc.c"
+
+
+#ifdef OH_WITH_ENGINE
+/* The AVCodec's decode callback (hevc.c:4555-4571 `.decode = hevc_decode_frame`), followed by the hand-over of the picture the
+ * access unit held: on whichever thread libavcodec runs the callback.  Installed when the library is loaded. */
+static int hooked_decode_frame(AVCodecContext *avctx, void *data, int *got_output, AVPacket *avpkt)
+{
+    tls_s = avctx->priv_data;
+    tls_md5_plane = 0;
+    const int ret = hevc_decode_frame(avctx, data, got_output, avpkt);
+    if (finish_and_submit(avctx->priv_data) < 0)
+        return AVERROR_EXTERNAL;
+    return ret;
+}
+__attribute__((constructor)) static void install_engine_hooks(void)
+{
+    ff_hevc_decoder.decode = hooked_decode_frame;
+    const char *b = getenv("OHEVC_BS_FROM_MOTION");          /* boundary strengths derived on the GPU from the decoder's motion field (bs_kernel) */
+    if (b && atoi(b)) g_bs_from_motion = 1;
+}
+#endif

@@ -230,6 +230,31 @@ def hooked_lib():
     return _hlib
 
 
+# ---- the drop-in library: the reference's decoder + libOpenHevc* wrapper with the MI355X engine inside (oracle/Makefile refhip) ----
+HIP_LIB = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hip.so")
+_piplib = None
+WRAPPER_API = ("libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDecode", "libOpenHevcGetPictureInfo", "libOpenHevcGetPictureInfoCpy",
+               "libOpenHevcCopyExtraData", "libOpenHevcGetOutput", "libOpenHevcGetOutputCpy", "libOpenHevcSetCheckMD5", "libOpenHevcSetDebugMode",
+               "libOpenHevcSetTemporalLayer_id", "libOpenHevcSetNoCropping", "libOpenHevcSetActiveDecoders", "libOpenHevcSetViewLayers",
+               "libOpenHevcClose", "libOpenHevcFlush", "libOpenHevcFlushSVC", "libOpenHevcVersion")       # openHevcWrapper.h:79-98
+
+
+def hip_lib():
+    global _piplib
+    if _piplib is None:
+        if os.path.isdir(REF_TREE):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openhevc_amd"), "libohevc_hip.so"])
+            subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "refhip"])
+        L = C.CDLL(HIP_LIB)
+        plain = lib()
+        for name in ("libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDecode", "libOpenHevcGetPictureInfoCpy", "libOpenHevcGetOutputCpy",
+                     "libOpenHevcSetCheckMD5", "libOpenHevcSetDebugMode", "libOpenHevcClose"):
+            getattr(L, name).argtypes = getattr(plain, name).argtypes
+            getattr(L, name).restype = getattr(plain, name).restype
+        _piplib = L
+    return _piplib
+
+
 def record_work_lists(data, on_picture, threads=1, thread_type=1, bs_from_motion=False):
     """Decodes the stream with the reference's own decoder whose DSP tables hold this repository's RECORDING slots: every access
     unit yields the work list of its picture.  on_picture(frame, cur_id, poc) is called while the recorder's arrays are valid

@@ -62,7 +62,7 @@ def test_picture_md5_follows_the_finished_half():
     rec.close()
 
 
-HOOKED = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hooked.so")
+HOOKED = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hip.so")          # the drop-in library: the reference's decoder + wrapper, engine inside
 REFDEC = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_ref.so")
 HARNESS = os.path.join(ROOT, "openhevc_amd", "ohevc_dec")
 

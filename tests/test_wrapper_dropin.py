@@ -1,0 +1,83 @@
+"""The drop-in library oracle/_ref/libopenhevc_hip.so: the reference's own decoder and libOpenHevc* wrapper (compiled from its sources
+where they lie) with this repository's recording table slots in its CTU loop and the MI355X engine behind them.  A caller that knows
+only openHevcWrapper.h — Init, StartDecoder, SetCheckMD5, Decode per access unit, GetPictureInfoCpy + GetOutputCpy per released
+picture, flush, Close: the loop of main_hm/main.c:149-306 — must get from it what the reference's library gives, plane for plane.
+The checker is the unmodified reference decoder (oracle/_ref/libopenhevc_ref.so)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import refdec
+import streamgen
+
+need_lib = pytest.mark.skipif(not (os.path.exists(refdec.HIP_LIB) or os.path.isdir(refdec.REF_TREE)), reason="the drop-in library is built where the reference tree is")
+
+
+@need_lib
+def test_exports_exactly_the_wrapper_api():
+    """openHevcWrapper.h:79-98 declares 18 functions (bin/ffmpeg_w64/libLibOpenHevcWrapper.def lists the same 18): the drop-in library
+    defines every one of them, and the handle opens, starts and closes without a GPU (the engine is created with the first picture)"""
+    L = refdec.hip_lib()
+    out = subprocess.run(["nm", "-D", "--defined-only", refdec.HIP_LIB], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert set(refdec.WRAPPER_API) <= defined, sorted(set(refdec.WRAPPER_API) - defined)
+    assert {n for n in defined if n.startswith("libOpenHevc")} == set(refdec.WRAPPER_API)
+    import ctypes as C
+    h = C.c_void_p(L.libOpenHevcInit(1, 1))
+    assert h and L.libOpenHevcStartDecoder(h) == 1
+    L.libOpenHevcVersion.restype = C.c_char_p
+    L.libOpenHevcVersion.argtypes = [C.c_void_p]
+    assert L.libOpenHevcVersion(h).startswith(b"OpenHEVC")
+    L.libOpenHevcClose(h)
+
+
+STREAMS = [
+    ("main8_lowdelay", 416, 240, 31, dict(n_pictures=8, gop=2), 1, 1),
+    ("main10_tools", 416, 240, 32, dict(n_pictures=6, gop=2, bit_depth=10, amp=1, pcm=1, transform_skip=1, transquant_bypass=1, weighted_pred=1, scaling_list=1), 1, 1),
+    ("hier_b_reordered", 416, 240, 33, dict(n_pictures=11, gop=3, tmvp=1, n_refs=3, idr_period=7), 1, 1),
+    ("main10_window", 416, 240, 34, dict(n_pictures=5, gop=2, bit_depth=10, conf_win_left=6, conf_win_right=10, conf_win_top=4, conf_win_bottom=12), 1, 1),
+    ("rext444_ccp", 416, 240, 35, dict(n_pictures=4, gop=2, chroma_format_idc=3, cross_component_pred=1, transform_skip=1), 1, 1),
+    ("slices_tiles", 416, 240, 36, dict(n_pictures=5, gop=1, n_slices=3, tile_cols=2, tile_rows=2, lf_across_tiles=0), 1, 1),
+    ("wavefront_slice_threads", 832, 480, 37, dict(n_pictures=6, gop=2, wpp=1), 4, 2),
+    ("hd_main10_wavefront", 1920, 1080, 38, dict(n_pictures=4, gop=2, bit_depth=10, wpp=1), 8, 2),
+]
+
+
+@pytest.mark.gpu
+@need_lib
+@pytest.mark.parametrize("name,w,h,seed,kw,threads,ttype", STREAMS, ids=[s[0] for s in STREAMS])
+def test_wrapper_loop_matches_the_reference_library(name, w, h, seed, kw, threads, ttype):
+    """the harness loop through the drop-in library vs through the reference's: same number of output pictures, in the same (output)
+    order, every plane of every picture equal (cropped size, bit depth and chroma format as libOpenHevcGetPictureInfoCpy reports them)"""
+    data, _ = streamgen.write_stream(w, h, seed, **kw)
+    want = refdec.decode(data)
+    got = refdec.decode(data, threads=threads, thread_type=ttype, L=refdec.hip_lib())
+    assert len(got) == len(want) and len(want) > 0, (len(got), len(want))
+    for k, (a, b) in enumerate(zip(want, got)):
+        for c in range(3):
+            assert a[c].shape == b[c].shape and a[c].dtype == b[c].dtype, (name, k, c, a[c].shape, b[c].shape)
+            assert np.array_equal(a[c], b[c]), f"{name}: output picture {k} plane {c} differs from the reference library's"
+
+
+@pytest.mark.gpu
+@need_lib
+def test_the_decoders_own_md5_check_judges_the_engines_pictures():
+    """libOpenHevcSetCheckMD5(1): the decoder's "Correct MD5 (poc, plane)" lines (hevc.c:4146-4169) come from digests computed on the
+    GPU over the engine's pictures against the stream's picture-hash SEI; a corrupted SEI digest is reported as Incorrect"""
+    data, aus = streamgen.write_stream(416, 240, 41, n_pictures=6, gop=2, bit_depth=10)
+    pics = refdec.decode(data)                                # low delay: output order = decode order
+    digests = [refdec.md5_of(p) for p in pics]
+    with_sei, _ = streamgen.add_md5(data, aus, digests)
+    refdec.hip_lib().libOpenHevcSetDebugMode.argtypes = refdec.lib().libOpenHevcSetDebugMode.argtypes
+    with refdec.captured_stderr() as cap:
+        got = refdec.decode(with_sei, check_md5=True, L=refdec.hip_lib(), keep=False)
+    assert len(got) == len(pics)
+    assert cap.text.count("Correct MD5") == 3 * len(pics) and "Incorrect MD5" not in cap.text, cap.text[-2000:]
+    wrong = [list(d) for d in digests]
+    wrong[2][1] = bytes(16)
+    bad, _ = streamgen.add_md5(data, aus, wrong)
+    with refdec.captured_stderr() as cap:
+        refdec.decode(bad, check_md5=True, L=refdec.hip_lib(), keep=False)
+    assert cap.text.count("Incorrect MD5") == 1 and cap.text.count("Correct MD5") == 3 * len(pics) - 1, cap.text[-2000:]

@@ -99,7 +99,7 @@ def harness_sweep(count, seed, extra=(), min_ctb=4):
     import subprocess
     import tempfile
     rng = random.Random(seed)
-    harness, hooked = os.path.join(ROOT, "openhevc_amd", "ohevc_dec"), os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hooked.so")
+    harness, hooked = os.path.join(ROOT, "openhevc_amd", "ohevc_dec"), os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hip.so")
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         for i in range(count):

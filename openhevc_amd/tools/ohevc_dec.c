@@ -5,7 +5,7 @@
  *     ohevc_dec -i stream.bin -F <library> [-c] [-n] [-g] [-o out.yuv] [-s frames] [-p threads] [-f thread type] [-b]
  *
  * <library> is any shared object that exports the 18 libOpenHevc* functions of gpac/modules/openhevc_dec/openHevcWrapper.h:79-98:
- * the drop-in library with the MI355X engine inside (oracle/_ref/libopenhevc_hip.so) or the reference's own (libopenhevc_ref.so,
+ * the drop-in library with the MI355X engine inside (libopenhevc_hip.so: INTEGRATION.md) or the reference's own (libopenhevc_ref.so,
  * libopenhevc_ref_sse.so) — the same loop, the same clock, so `frame= N fps= F` of the two are comparable line by line.
  * The harness reads a raw Annex-B file, splits it into access units (oh_annexb_split: what the reference's harness gets from
  * libavformat's raw HEVC demuxer through hevc_parser.c:40-87) and runs main.c's loop: libOpenHevcInit, SetCheckMD5, StartDecoder,

@@ -19,17 +19,37 @@
 #include <string.h>
 #include "../../include/ohevc_recorder.h"
 
+/* The appending entry points may be called from the reference's slice / wavefront threads (pthread_slice.c: one CTU row or slice
+ * each), sixteen of them at once.  Every recording thread appends to lists of its OWN (a shard, picked on the thread's first call
+ * for the picture): no lock on the hot path — with one shared list and a mutex the front end ran SLOWER on 16 threads than on one
+ * (96 against 42 ms per 4K picture on the GPU box's EPYC, profiles/r03_front_end.txt).  The indices the entry points hand back
+ * (oh_rec_tu*, oh_rec_intra_idx, oh_rec_n_intra) count inside the calling thread's shard; the blocks of a coding unit all come
+ * from the thread that decodes its CTU row, so the links between them (intra block -> its residual, chroma block -> the luma
+ * residual it is predicted from, PU -> its weights) never cross shards.  oh_rec_finish() concatenates the shards and rebases the
+ * links; a picture recorded by one thread is handed on as it lies. */
+#define OH_MAX_SHARDS 64
+typedef struct Shard {
+    OhPu      *pu;      uint32_t n_pu, cap_pu;
+    OhWeights *wp;      uint32_t n_wp, cap_wp;
+    OhTu      *tu;      uint32_t n_tu, cap_tu;
+    int16_t   *coeffs;  uint64_t n_coeff, cap_coeff;
+    OhIntra   *intra;   uint32_t n_intra, cap_intra;     /* in recording order */
+    uint32_t  *it_ctu;                          /* CTU raster index of intra[i] */
+    uint16_t  *it_sub;                          /* sub-level (1-based) of intra[i] */
+    uint32_t  *sparse, *tu_sparse, *tu_cross; uint64_t cap_sparse, cap_tu_sparse, cap_tu_cross; uint32_t n_sparse;
+    int any_sparse, any_matrix, any_cross, oom;
+} Shard;
+
 struct OhRecorder {
-    pthread_mutex_t mu;                         /* the appending entry points may be called from the reference's slice / wavefront threads */
+    pthread_mutex_t mu;                         /* hands out shards; nothing else */
     OhFrame  f;
-    /* growable item lists */
+    Shard     sh[OH_MAX_SHARDS]; int n_sh;      /* shards in use for the picture in flight */
+    unsigned  epoch;                            /* changes with every oh_rec_begin(): a thread's cached shard is for one picture */
+    /* the concatenated lists (pictures recorded by several threads) */
     OhPu      *pu;      uint32_t cap_pu;
     OhWeights *wp;      uint32_t cap_wp;
     OhTu      *tu;      uint32_t cap_tu;
     int16_t   *coeffs;  uint64_t cap_coeff;
-    OhIntra   *intra;   uint32_t cap_intra;     /* in recording order */
-    uint32_t  *it_ctu;                          /* CTU raster index of intra[i] */
-    uint16_t  *it_sub;                          /* sub-level (1-based) of intra[i] */
     OhIntra   *sorted;  uint32_t cap_sorted;
     /* schedule */
     int        n_ctb, ctbw, ctbh;
@@ -42,7 +62,7 @@ struct OhRecorder {
     uint32_t  *level_start;
     /* side arrays */
     uint8_t *vbs, *hbs, *is_pcm, *is_intra;
-    uint32_t *sparse, *tu_sparse, *tu_cross; uint64_t cap_sparse, cap_tu_sparse, cap_tu_cross; int any_sparse, any_matrix, any_cross;
+    uint32_t *sparse, *tu_sparse, *tu_cross; uint64_t cap_sparse, cap_tu_sparse, cap_tu_cross;
     const OhBsInputs *bs_in;                                  /* caller-owned maps for the GPU boundary-strength pass, or NULL */
     OhBsInputs own_bs; OhMvField *bs_mvf; uint8_t *bs_cbf, *bs_call, *bs_flags;     /* recorder-owned maps (oh_rec_bs_maps) */
     OhScalingList scaling;
@@ -59,7 +79,7 @@ struct OhRecorder {
 
 /* the table slots that feed the recorder cannot fail (void returns), so an allocation failure is latched in r->oom: the block
  * is kept as it was (no write through NULL, the old block is not lost), the item is dropped, and oh_rec_finish() reports it */
-static void *grow(OhRecorder *r, void *p, size_t elem, uint64_t *cap, uint64_t need)
+static void *grow(int *oom, void *p, size_t elem, uint64_t *cap, uint64_t need)
 {
     if (need <= *cap)
         return p;
@@ -68,13 +88,33 @@ static void *grow(OhRecorder *r, void *p, size_t elem, uint64_t *cap, uint64_t n
         n *= 2;
     void *q = realloc(p, (size_t)(n * elem));
     if (!q) {
-        r->oom = 1;
+        *oom = 1;
         return p;
     }
     *cap = n;
     return q;
 }
-#define GROW32(ptr, cap, need) do { uint64_t c_ = (cap); (ptr) = grow(r, (ptr), sizeof(*(ptr)), &c_, (need)); (cap) = (uint32_t)c_; } while (0)
+#define GROW32(own, ptr, cap, need) do { uint64_t c_ = (cap); (ptr) = grow(&(own)->oom, (ptr), sizeof(*(ptr)), &c_, (need)); (cap) = (uint32_t)c_; } while (0)
+
+static unsigned g_epoch;                          /* picture epochs are unique across recorders (a recorder may be re-created at the same address) */
+static __thread struct { const OhRecorder *r; unsigned epoch; Shard *s; } tls_shard;
+/* the calling thread's lists for the picture in flight */
+static Shard *my_shard(OhRecorder *r)
+{
+    if (tls_shard.r == r && tls_shard.epoch == r->epoch)
+        return tls_shard.s;
+    pthread_mutex_lock(&r->mu);
+    Shard *s;
+    if (r->n_sh < OH_MAX_SHARDS) {
+        s = &r->sh[r->n_sh++];
+    } else {                                              /* more recording threads than shards: the picture is refused (oh_rec_finish returns NULL) */
+        s = &r->sh[OH_MAX_SHARDS - 1];
+        r->oom = 1;
+    }
+    pthread_mutex_unlock(&r->mu);
+    tls_shard.r = r; tls_shard.epoch = r->epoch; tls_shard.s = s;
+    return s;
+}
 
 void oh_rec_destroy(OhRecorder *r);
 
@@ -134,7 +174,12 @@ void oh_rec_destroy(OhRecorder *r)
     if (r) pthread_mutex_destroy(&r->mu);
     if (!r)
         return;
-    free(r->pu); free(r->wp); free(r->tu); free(r->coeffs); free(r->intra); free(r->it_ctu); free(r->it_sub);
+    for (int k = 0; k < OH_MAX_SHARDS; k++) {
+        Shard *sh = &r->sh[k];
+        free(sh->pu); free(sh->wp); free(sh->tu); free(sh->coeffs); free(sh->intra); free(sh->it_ctu); free(sh->it_sub);
+        free(sh->sparse); free(sh->tu_sparse); free(sh->tu_cross);
+    }
+    free(r->pu); free(r->wp); free(r->tu); free(r->coeffs);
     free(r->sorted); free(r->ctu_dep); free(r->ctu_nsub); free(r->ctu_level); free(r->ctu_entry); free(r->ictu);
     free(r->sub_start); free(r->level_start);
     free(r->bs_mvf); free(r->bs_cbf); free(r->bs_call); free(r->bs_flags);
@@ -154,9 +199,16 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     for (int i = 0; i < OH_MAX_REFS; i++)
         r->f.ref_pics[i] = i < n_ref_pics ? ref_pics[i] : -1;
     r->f.n_pu = r->f.n_wp = r->f.n_tu = r->f.n_intra = r->f.n_levels = r->f.n_ictu = r->f.n_sub = 0;
-    r->f.n_sparse = 0; r->any_sparse = 0; r->any_matrix = 0; r->any_cross = 0; r->bs_in = NULL;
+    r->f.n_sparse = 0; r->bs_in = NULL;
     r->f.n_coeff = 0;
     r->oom = 0;
+    for (int k = 0; k < r->n_sh; k++) {
+        Shard *sh = &r->sh[k];
+        sh->n_pu = sh->n_wp = sh->n_tu = sh->n_intra = sh->n_sparse = 0; sh->n_coeff = 0;
+        sh->any_sparse = sh->any_matrix = sh->any_cross = sh->oom = 0;
+    }
+    r->n_sh = 0;
+    r->epoch = __sync_add_and_fetch(&g_epoch, 1);
     r->ctb_maps_on = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
@@ -172,7 +224,7 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     memset(r->decoded, 0, (size_t)r->dw * r->dh);
 }
 
-static int oh_rec_pu_u(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,
+static int oh_rec_pu_u(OhRecorder *r, Shard *s, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,
               int ref1, int mv1x, int mv1y, const OhWeights *wp)
 {
     const OhPicParams *p = &r->f.p;
@@ -180,11 +232,11 @@ static int oh_rec_pu_u(OhRecorder *r, int x, int y, int w, int h, int ref0, int 
         return -1;
     if (ref0 < 0 && ref1 < 0)
         return -1;
-    GROW32(r->pu, r->cap_pu, (uint64_t)r->f.n_pu + 1);
-    if (wp) GROW32(r->wp, r->cap_wp, (uint64_t)r->f.n_wp + 1);
-    if (r->oom)
+    GROW32(s, s->pu, s->cap_pu, (uint64_t)s->n_pu + 1);
+    if (wp) GROW32(s, s->wp, s->cap_wp, (uint64_t)s->n_wp + 1);
+    if (s->oom)
         return -1;
-    OhPu *it = &r->pu[r->f.n_pu++];
+    OhPu *it = &s->pu[s->n_pu++];
     memset(it, 0, sizeof(*it));
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->w = (uint8_t)w; it->h = (uint8_t)h;
     it->ref[0] = ref0 < 0 ? OH_NO_REF : (uint8_t)ref0;
@@ -193,58 +245,58 @@ static int oh_rec_pu_u(OhRecorder *r, int x, int y, int w, int h, int ref0, int 
     it->mv[1][0] = (int16_t)mv1x; it->mv[1][1] = (int16_t)mv1y;
     it->wp = OH_NO_WP;
     if (wp) {
-        r->wp[r->f.n_wp] = *wp;
-        it->wp = (uint16_t)r->f.n_wp++;
+        s->wp[s->n_wp] = *wp;
+        it->wp = (uint16_t)s->n_wp++;
     }
     return 0;
 }
 
-static uint32_t oh_rec_tu_u(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+static uint32_t oh_rec_tu_u(Shard *s, int c_idx, int x, int y, int log2_size, int kind, int flags,
                    const int16_t *coeffs)
 {
     uint32_t n2 = 1u << (2 * log2_size);
-    GROW32(r->tu, r->cap_tu, (uint64_t)r->f.n_tu + 1);
-    r->coeffs = (int16_t *)grow(r, r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
-    r->tu_sparse = (uint32_t *)grow(r, r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
-    if (r->any_cross) r->tu_cross = (uint32_t *)grow(r, r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
-    if (r->oom)
+    GROW32(s, s->tu, s->cap_tu, (uint64_t)s->n_tu + 1);
+    s->coeffs = (int16_t *)grow(&s->oom, s->coeffs, sizeof(int16_t), &s->cap_coeff, s->n_coeff + n2);
+    s->tu_sparse = (uint32_t *)grow(&s->oom, s->tu_sparse, sizeof(uint32_t), &s->cap_tu_sparse, (uint64_t)s->n_tu + 1);
+    if (s->any_cross) s->tu_cross = (uint32_t *)grow(&s->oom, s->tu_cross, sizeof(uint32_t), &s->cap_tu_cross, (uint64_t)s->n_tu + 1);
+    if (s->oom)
         return OH_NO_COEFF;
-    OhTu *it = &r->tu[r->f.n_tu];
+    OhTu *it = &s->tu[s->n_tu];
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
     it->kind = (uint8_t)kind; it->flags = (uint8_t)flags;
-    it->coeff_off = (uint32_t)r->f.n_coeff;
-    memcpy(r->coeffs + r->f.n_coeff, coeffs, n2 * sizeof(int16_t));
-    r->f.n_coeff += n2;
-    r->tu_sparse[r->f.n_tu] = OH_NO_COEFF;
-    if (r->any_cross) r->tu_cross[r->f.n_tu] = OH_NO_COEFF;
-    return r->f.n_tu++;
+    it->coeff_off = (uint32_t)s->n_coeff;
+    memcpy(s->coeffs + s->n_coeff, coeffs, n2 * sizeof(int16_t));
+    s->n_coeff += n2;
+    s->tu_sparse[s->n_tu] = OH_NO_COEFF;
+    if (s->any_cross) s->tu_cross[s->n_tu] = OH_NO_COEFF;
+    return s->n_tu++;
 }
 
-static uint32_t oh_rec_tu_sparse_u(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
+static uint32_t oh_rec_tu_sparse_u(Shard *s, int c_idx, int x, int y, int log2_size, int kind, int flags,
                           int qp, int matrix_id, int n, const uint32_t *pairs)
 {
     uint32_t n2 = 1u << (2 * log2_size);
-    GROW32(r->tu, r->cap_tu, (uint64_t)r->f.n_tu + 1);
-    r->coeffs = (int16_t *)grow(r, r->coeffs, sizeof(int16_t), &r->cap_coeff, r->f.n_coeff + n2);
-    r->tu_sparse = (uint32_t *)grow(r, r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)r->f.n_tu + 1);
-    r->sparse = (uint32_t *)grow(r, r->sparse, sizeof(uint32_t), &r->cap_sparse, (uint64_t)r->f.n_sparse + 1 + (uint64_t)n);
-    if (r->any_cross) r->tu_cross = (uint32_t *)grow(r, r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
-    if (r->oom)
+    GROW32(s, s->tu, s->cap_tu, (uint64_t)s->n_tu + 1);
+    s->coeffs = (int16_t *)grow(&s->oom, s->coeffs, sizeof(int16_t), &s->cap_coeff, s->n_coeff + n2);
+    s->tu_sparse = (uint32_t *)grow(&s->oom, s->tu_sparse, sizeof(uint32_t), &s->cap_tu_sparse, (uint64_t)s->n_tu + 1);
+    s->sparse = (uint32_t *)grow(&s->oom, s->sparse, sizeof(uint32_t), &s->cap_sparse, (uint64_t)s->n_sparse + 1 + (uint64_t)n);
+    if (s->any_cross) s->tu_cross = (uint32_t *)grow(&s->oom, s->tu_cross, sizeof(uint32_t), &s->cap_tu_cross, (uint64_t)s->n_tu + 1);
+    if (s->oom)
         return OH_NO_COEFF;
-    OhTu *it = &r->tu[r->f.n_tu];
+    OhTu *it = &s->tu[s->n_tu];
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c_idx; it->log2_size = (uint8_t)log2_size;
     it->kind = (uint8_t)kind; it->flags = (uint8_t)(flags | OH_TUF_SPARSE);
-    it->coeff_off = (uint32_t)r->f.n_coeff;
-    memset(r->coeffs + r->f.n_coeff, 0, n2 * sizeof(int16_t));
-    r->f.n_coeff += n2;
-    r->tu_sparse[r->f.n_tu] = r->f.n_sparse;
-    r->sparse[r->f.n_sparse] = (uint32_t)n | ((uint32_t)(qp & 0xff) << 16) | ((uint32_t)(matrix_id & 0xff) << 24);
-    memcpy(r->sparse + r->f.n_sparse + 1, pairs, sizeof(uint32_t) * (size_t)n);
-    r->f.n_sparse += 1 + (uint32_t)n;
-    r->any_sparse = 1;
-    if ((matrix_id & 0xff) != OH_FLAT_MATRIX) r->any_matrix = 1;
-    if (r->any_cross) r->tu_cross[r->f.n_tu] = OH_NO_COEFF;
-    return r->f.n_tu++;
+    it->coeff_off = (uint32_t)s->n_coeff;
+    memset(s->coeffs + s->n_coeff, 0, n2 * sizeof(int16_t));
+    s->n_coeff += n2;
+    s->tu_sparse[s->n_tu] = s->n_sparse;
+    s->sparse[s->n_sparse] = (uint32_t)n | ((uint32_t)(qp & 0xff) << 16) | ((uint32_t)(matrix_id & 0xff) << 24);
+    memcpy(s->sparse + s->n_sparse + 1, pairs, sizeof(uint32_t) * (size_t)n);
+    s->n_sparse += 1 + (uint32_t)n;
+    s->any_sparse = 1;
+    if ((matrix_id & 0xff) != OH_FLAT_MATRIX) s->any_matrix = 1;
+    if (s->any_cross) s->tu_cross[s->n_tu] = OH_NO_COEFF;
+    return s->n_tu++;
 }
 
 OhScalingList *oh_rec_scaling_list(OhRecorder *r) { return &r->scaling; }
@@ -349,21 +401,21 @@ OhCtbMaps *oh_rec_ctb_maps(OhRecorder *r)
 
 const OhCtbMaps *oh_rec_ctb_maps_in_use(const OhRecorder *r) { return r->ctb_maps_on ? &r->ctb_maps : NULL; }
 
-static int oh_rec_tu_cross_u(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
+static int oh_rec_tu_cross_u(Shard *s, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
 {
-    if (tu_c >= r->f.n_tu || tu_y >= r->f.n_tu || tu_y >= (1u << 24) || r->tu[tu_y].c_idx != 0 || r->tu[tu_c].c_idx == 0 ||
-        r->tu[tu_y].log2_size != r->tu[tu_c].log2_size)
+    if (tu_c >= s->n_tu || tu_y >= s->n_tu || tu_y >= (1u << 24) || s->tu[tu_y].c_idx != 0 || s->tu[tu_c].c_idx == 0 ||
+        s->tu[tu_y].log2_size != s->tu[tu_c].log2_size)
         return -1;
-    if (!r->any_cross) {                                  /* first one of the picture: start from "none" */
-        r->tu_cross = (uint32_t *)grow(r, r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)r->f.n_tu + 1);
-        if (r->oom)
+    if (!s->any_cross) {                                  /* first one of the picture (in this shard): start from "none" */
+        s->tu_cross = (uint32_t *)grow(&s->oom, s->tu_cross, sizeof(uint32_t), &s->cap_tu_cross, (uint64_t)s->n_tu + 1);
+        if (s->oom)
             return -1;
-        for (uint32_t i = 0; i < r->f.n_tu; i++) r->tu_cross[i] = OH_NO_COEFF;
-        r->any_cross = 1;
+        for (uint32_t i = 0; i < s->n_tu; i++) s->tu_cross[i] = OH_NO_COEFF;
+        s->any_cross = 1;
     }
-    r->tu_cross[tu_c] = tu_y | ((uint32_t)(res_scale_val & 0xff) << 24);
-    r->tu[tu_c].flags |= OH_TUF_CROSS;
-    r->tu[tu_y].flags |= OH_TUF_KEEP_RES;
+    s->tu_cross[tu_c] = tu_y | ((uint32_t)(res_scale_val & 0xff) << 24);
+    s->tu[tu_c].flags |= OH_TUF_CROSS;
+    s->tu[tu_y].flags |= OH_TUF_KEEP_RES;
     return 0;
 }
 
@@ -384,7 +436,7 @@ static inline void visit(OhRecorder *r, int c, int x, int y, int cx, int cy, uns
     }
 }
 
-static int oh_rec_intra_u(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
+static int oh_rec_intra_u(OhRecorder *r, Shard *s, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
 {
     const OhPicParams *p = &r->f.p;
     int n = 1 << log2_size, c = c_idx;
@@ -413,34 +465,34 @@ static int oh_rec_intra_u(OhRecorder *r, int c_idx, int x, int y, int log2_size,
     if (sub > r->ctu_nsub[ctu])
         r->ctu_nsub[ctu] = (uint16_t)sub;
 
-    uint32_t cap = r->cap_intra;
-    GROW32(r->intra, r->cap_intra, (uint64_t)r->f.n_intra + 1);
-    if (r->cap_intra != cap) {
-        uint32_t *nc = (uint32_t *)realloc(r->it_ctu, sizeof(uint32_t) * r->cap_intra);
-        if (nc) r->it_ctu = nc;
-        uint16_t *nsb = (uint16_t *)realloc(r->it_sub, sizeof(uint16_t) * r->cap_intra);
-        if (nsb) r->it_sub = nsb;
-        if (!nc || !nsb) { r->oom = 1; r->cap_intra = cap; }       /* the item list keeps its old capacity: nothing indexes past the side lists */
+    uint32_t cap = s->cap_intra;
+    GROW32(s, s->intra, s->cap_intra, (uint64_t)s->n_intra + 1);
+    if (s->cap_intra != cap) {
+        uint32_t *nc = (uint32_t *)realloc(s->it_ctu, sizeof(uint32_t) * s->cap_intra);
+        if (nc) s->it_ctu = nc;
+        uint16_t *nsb = (uint16_t *)realloc(s->it_sub, sizeof(uint16_t) * s->cap_intra);
+        if (nsb) s->it_sub = nsb;
+        if (!nc || !nsb) { s->oom = 1; s->cap_intra = cap; }       /* the item list keeps its old capacity: nothing indexes past the side lists */
     }
-    if (r->oom)
+    if (s->oom)
         return -1;
-    OhIntra *it = &r->intra[r->f.n_intra];
+    OhIntra *it = &s->intra[s->n_intra];
     it->x = (uint16_t)x; it->y = (uint16_t)y; it->c_idx = (uint8_t)c; it->log2_size = (uint8_t)log2_size;
     it->mode = (uint8_t)mode; it->avail = (uint8_t)avail; it->tu = tu;
-    r->it_ctu[r->f.n_intra] = (uint32_t)ctu;
-    r->it_sub[r->f.n_intra] = (uint16_t)sub;
-    r->f.n_intra++;
+    s->it_ctu[s->n_intra] = (uint32_t)ctu;
+    s->it_sub[s->n_intra] = (uint16_t)sub;
+    s->n_intra++;
     return 0;
 }
 
-uint32_t oh_rec_n_intra(const OhRecorder *r) { return r->f.n_intra; }
+uint32_t oh_rec_n_intra(const OhRecorder *r) { return my_shard((OhRecorder *)r)->n_intra; }
 
-static int oh_rec_intra_attach_tu_u(OhRecorder *r, uint32_t intra_index, uint32_t tu)
+static int oh_rec_intra_attach_tu_u(Shard *s, uint32_t intra_index, uint32_t tu)
 {
-    if (intra_index >= r->f.n_intra || tu >= r->f.n_tu)
+    if (intra_index >= s->n_intra || tu >= s->n_tu)
         return -1;
-    r->intra[intra_index].tu = tu;
-    r->tu[tu].flags &= (uint8_t)~OH_TUF_ADD_NOW;
+    s->intra[intra_index].tu = tu;
+    s->tu[tu].flags &= (uint8_t)~OH_TUF_ADD_NOW;
     return 0;
 }
 
@@ -458,8 +510,66 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     const int W = r->ctbw;
     uint32_t max_level = 0, n_ictu = 0, n_sub = 0;
 
-    if (r->oom)
+    /* 0. the threads' shards -> the picture's lists.  One shard (the common case: one decoding thread, the synthetic generator):
+     * its lists ARE the picture's.  Several: concatenated in shard order, with the links rebased (see struct Shard). */
+    int any_sparse = 0, any_matrix = 0, any_cross = 0;
+    uint32_t base_tu[OH_MAX_SHARDS + 1], base_wp[OH_MAX_SHARDS + 1], base_pu[OH_MAX_SHARDS + 1], base_sparse[OH_MAX_SHARDS + 1];
+    uint64_t base_coeff[OH_MAX_SHARDS + 1];
+    base_tu[0] = base_wp[0] = base_pu[0] = base_sparse[0] = 0; base_coeff[0] = 0;
+    f->n_intra = 0;
+    for (int k = 0; k < r->n_sh; k++) {
+        const Shard *sh = &r->sh[k];
+        if (sh->oom) r->oom = 1;
+        any_sparse |= sh->any_sparse; any_matrix |= sh->any_matrix; any_cross |= sh->any_cross;
+        base_pu[k + 1] = base_pu[k] + sh->n_pu; base_wp[k + 1] = base_wp[k] + sh->n_wp; base_tu[k + 1] = base_tu[k] + sh->n_tu;
+        base_sparse[k + 1] = base_sparse[k] + sh->n_sparse; base_coeff[k + 1] = base_coeff[k] + sh->n_coeff;
+        f->n_intra += sh->n_intra;
+    }
+    if (r->oom || base_coeff[r->n_sh] >= 0xffffffffull)    /* OhTu.coeff_off is 32 bits */
         return NULL;
+    f->n_pu = base_pu[r->n_sh]; f->n_wp = base_wp[r->n_sh]; f->n_tu = base_tu[r->n_sh]; f->n_sparse = base_sparse[r->n_sh];
+    f->n_coeff = base_coeff[r->n_sh];
+    const OhPu *l_pu = NULL; const OhWeights *l_wp = NULL; const OhTu *l_tu = NULL; const int16_t *l_coeffs = NULL;
+    const uint32_t *l_sparse = NULL, *l_tu_sparse = NULL, *l_tu_cross = NULL;
+    if (r->n_sh == 1) {
+        const Shard *sh = &r->sh[0];
+        l_pu = sh->pu; l_wp = sh->wp; l_tu = sh->tu; l_coeffs = sh->coeffs; l_sparse = sh->sparse; l_tu_sparse = sh->tu_sparse; l_tu_cross = sh->tu_cross;
+    } else if (r->n_sh > 1) {
+        GROW32(r, r->pu, r->cap_pu, (uint64_t)f->n_pu + 1);
+        GROW32(r, r->wp, r->cap_wp, (uint64_t)f->n_wp + 1);
+        GROW32(r, r->tu, r->cap_tu, (uint64_t)f->n_tu + 1);
+        r->coeffs = (int16_t *)grow(&r->oom, r->coeffs, sizeof(int16_t), &r->cap_coeff, f->n_coeff + 1);
+        r->tu_sparse = (uint32_t *)grow(&r->oom, r->tu_sparse, sizeof(uint32_t), &r->cap_tu_sparse, (uint64_t)f->n_tu + 1);
+        if (any_sparse) r->sparse = (uint32_t *)grow(&r->oom, r->sparse, sizeof(uint32_t), &r->cap_sparse, (uint64_t)f->n_sparse + 1);
+        if (any_cross) r->tu_cross = (uint32_t *)grow(&r->oom, r->tu_cross, sizeof(uint32_t), &r->cap_tu_cross, (uint64_t)f->n_tu + 1);
+        if (r->oom)
+            return NULL;
+        for (int k = 0; k < r->n_sh; k++) {
+            const Shard *sh = &r->sh[k];
+            for (uint32_t i = 0; i < sh->n_pu; i++) {
+                OhPu v = sh->pu[i];
+                if (v.wp != OH_NO_WP) v.wp = (uint16_t)(v.wp + base_wp[k]);
+                r->pu[base_pu[k] + i] = v;
+            }
+            if (sh->n_wp) memcpy(r->wp + base_wp[k], sh->wp, sizeof(OhWeights) * sh->n_wp);
+            for (uint32_t i = 0; i < sh->n_tu; i++) {
+                OhTu v = sh->tu[i];
+                v.coeff_off = (uint32_t)(v.coeff_off + base_coeff[k]);
+                r->tu[base_tu[k] + i] = v;
+                const uint32_t sp = sh->tu_sparse[i];
+                r->tu_sparse[base_tu[k] + i] = sp == OH_NO_COEFF ? OH_NO_COEFF : sp + base_sparse[k];
+                if (any_cross) {
+                    const uint32_t cr = sh->any_cross ? sh->tu_cross[i] : OH_NO_COEFF;
+                    r->tu_cross[base_tu[k] + i] = cr == OH_NO_COEFF ? OH_NO_COEFF : (((cr & 0xffffffu) + base_tu[k]) | (cr & 0xff000000u));
+                }
+            }
+            if (sh->n_coeff) memcpy(r->coeffs + base_coeff[k], sh->coeffs, sizeof(int16_t) * sh->n_coeff);
+            if (sh->n_sparse) memcpy(r->sparse + base_sparse[k], sh->sparse, sizeof(uint32_t) * sh->n_sparse);
+        }
+        if (f->n_wp > 0xfffe || (any_cross && f->n_tu >= (1u << 24)))     /* the 16-bit weight index / the 24-bit luma link of a cross-component block */
+            return NULL;
+        l_pu = r->pu; l_wp = r->wp; l_tu = r->tu; l_coeffs = r->coeffs; l_sparse = r->sparse; l_tu_sparse = r->tu_sparse; l_tu_cross = r->tu_cross;
+    }
     /* 1. CTU levels, in raster order (every dependency points to an earlier CTU) */
     for (int i = 0; i < r->n_ctb; i++) {
         unsigned lv = 0;
@@ -507,22 +617,31 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
         r->ictu[k].sub_first = n_sub;
         n_sub += r->ictu[k].n_sub;
     }
-    GROW32(r->sub_start, r->cap_sub, (uint64_t)n_sub + 2);
-    GROW32(r->sorted, r->cap_sorted, (uint64_t)f->n_intra + 1);
+    GROW32(r, r->sub_start, r->cap_sub, (uint64_t)n_sub + 2);
+    GROW32(r, r->sorted, r->cap_sorted, (uint64_t)f->n_intra + 1);
     uint32_t *pos = (uint32_t *)malloc(sizeof(uint32_t) * (n_sub + 1));
     if (r->oom || !pos) {
         free(pos);
         return NULL;
     }
     memset(r->sub_start, 0, sizeof(uint32_t) * (n_sub + 2));
-    for (uint32_t i = 0; i < f->n_intra; i++)              /* histogram at slot+1 */
-        r->sub_start[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1 + 1]++;
+    for (int k = 0; k < r->n_sh; k++) {                    /* histogram at slot+1 */
+        const Shard *sh = &r->sh[k];
+        for (uint32_t i = 0; i < sh->n_intra; i++)
+            r->sub_start[r->ictu[r->ctu_entry[sh->it_ctu[i]]].sub_first + sh->it_sub[i] - 1 + 1]++;
+    }
     for (uint32_t s = 0; s < n_sub; s++)
         r->sub_start[s + 1] += r->sub_start[s];
     /* 4. place the blocks (stable: recording order inside one (CTU, sub-level)) */
     memcpy(pos, r->sub_start, sizeof(uint32_t) * (n_sub + 1));
-    for (uint32_t i = 0; i < f->n_intra; i++)
-        r->sorted[pos[r->ictu[r->ctu_entry[r->it_ctu[i]]].sub_first + r->it_sub[i] - 1]++] = r->intra[i];
+    for (int k = 0; k < r->n_sh; k++) {
+        const Shard *sh = &r->sh[k];
+        for (uint32_t i = 0; i < sh->n_intra; i++) {
+            OhIntra v = sh->intra[i];
+            if (v.tu != OH_NO_COEFF) v.tu += base_tu[k];
+            r->sorted[pos[r->ictu[r->ctu_entry[sh->it_ctu[i]]].sub_first + sh->it_sub[i] - 1]++] = v;
+        }
+    }
     free(pos);
 
     f->sao_pending = NULL;
@@ -544,7 +663,7 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
             r->own_bs.loop_filter_across_tiles = r->ctb_maps.loop_filter_across_tiles;
         }
     }
-    f->pu = r->pu; f->wp = r->wp; f->tu = r->tu; f->coeffs = r->coeffs;
+    f->pu = l_pu; f->wp = l_wp; f->tu = l_tu; f->coeffs = l_coeffs;
     f->intra = r->sorted;
     f->n_ictu = n_ictu; f->ictu = r->ictu;
     f->n_sub = n_sub; f->sub_start = r->sub_start;
@@ -552,10 +671,10 @@ const OhFrame *oh_rec_finish(OhRecorder *r)
     f->vertical_bs = r->vbs; f->horizontal_bs = r->hbs; f->qp_y_tab = r->qp;
     f->is_pcm = (f->p.pcm_loop_filter_disable || f->p.transquant_bypass_enable) ? r->is_pcm : NULL;
     f->is_intra = f->p.constrained_intra_pred ? r->is_intra : NULL;
-    f->sparse = r->any_sparse ? r->sparse : NULL;
-    f->tu_sparse = r->any_sparse ? r->tu_sparse : NULL;
-    f->scaling = r->any_matrix ? &r->scaling : NULL;
-    f->tu_cross = r->any_cross ? r->tu_cross : NULL;
+    f->sparse = any_sparse ? l_sparse : NULL;
+    f->tu_sparse = any_sparse ? l_tu_sparse : NULL;
+    f->scaling = any_matrix ? &r->scaling : NULL;
+    f->tu_cross = any_cross ? l_tu_cross : NULL;
     f->bs_in = r->bs_in;
     f->deblock = r->deblock;
     f->sao = f->p.sao_enabled ? r->sao : NULL;
@@ -601,63 +720,46 @@ static void oh_rec_mark_decoded_u(OhRecorder *r, int x, int y, int w, int h)
             r->decoded[(yy >> 2) * r->dw + (xx >> 2)] = 1;
 }
 
-/* ---- the public appending entry points: the bodies above under the recorder's lock ---- */
+/* ---- the public appending entry points: the bodies above on the calling thread's own lists (no lock) ---- */
 int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,
               int ref1, int mv1x, int mv1y, const OhWeights *wp)
 {
-    pthread_mutex_lock(&r->mu);
-    int v = oh_rec_pu_u(r, x, y, w, h, ref0, mv0x, mv0y, ref1, mv1x, mv1y, wp);
-    pthread_mutex_unlock(&r->mu);
-    return v;
+    return oh_rec_pu_u(r, my_shard(r), x, y, w, h, ref0, mv0x, mv0y, ref1, mv1x, mv1y, wp);
 }
 uint32_t oh_rec_tu(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
                    const int16_t *coeffs)
 {
-    pthread_mutex_lock(&r->mu);
-    uint32_t v = oh_rec_tu_u(r, c_idx, x, y, log2_size, kind, flags, coeffs);
-    pthread_mutex_unlock(&r->mu);
-    return v;
+    return oh_rec_tu_u(my_shard(r), c_idx, x, y, log2_size, kind, flags, coeffs);
 }
 uint32_t oh_rec_tu_sparse(OhRecorder *r, int c_idx, int x, int y, int log2_size, int kind, int flags,
                           int qp, int matrix_id, int n, const uint32_t *pairs)
 {
-    pthread_mutex_lock(&r->mu);
-    uint32_t v = oh_rec_tu_sparse_u(r, c_idx, x, y, log2_size, kind, flags, qp, matrix_id, n, pairs);
-    pthread_mutex_unlock(&r->mu);
-    return v;
+    return oh_rec_tu_sparse_u(my_shard(r), c_idx, x, y, log2_size, kind, flags, qp, matrix_id, n, pairs);
 }
 int oh_rec_tu_cross(OhRecorder *r, uint32_t tu_c, uint32_t tu_y, int res_scale_val)
 {
-    pthread_mutex_lock(&r->mu);
-    int v = oh_rec_tu_cross_u(r, tu_c, tu_y, res_scale_val);
-    pthread_mutex_unlock(&r->mu);
-    return v;
+    return oh_rec_tu_cross_u(my_shard(r), tu_c, tu_y, res_scale_val);
 }
+/* The sub-level map (lvl[]) and the per-CTU dependency words are shared and written without a lock: a block only reads cells of
+ * blocks decoded BEFORE it in the same slice and tile (its available neighbours), and the reference's wavefront threads are ordered
+ * exactly there (row r starts CTU k when row r-1 has finished k+2: ff_thread_await_progress2, a mutex); a CTU's own words are
+ * written by the one thread that decodes it. */
 int oh_rec_intra(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
 {
-    pthread_mutex_lock(&r->mu);
-    int v = oh_rec_intra_u(r, c_idx, x, y, log2_size, mode, avail, tu);
-    pthread_mutex_unlock(&r->mu);
-    return v;
+    return oh_rec_intra_u(r, my_shard(r), c_idx, x, y, log2_size, mode, avail, tu);
 }
 int oh_rec_intra_attach_tu(OhRecorder *r, uint32_t intra_index, uint32_t tu)
 {
-    pthread_mutex_lock(&r->mu);
-    int v = oh_rec_intra_attach_tu_u(r, intra_index, tu);
-    pthread_mutex_unlock(&r->mu);
-    return v;
+    return oh_rec_intra_attach_tu_u(my_shard(r), intra_index, tu);
 }
 void oh_rec_mark_decoded(OhRecorder *r, int x, int y, int w, int h)
 {
-    pthread_mutex_lock(&r->mu);
     oh_rec_mark_decoded_u(r, x, y, w, h);
-    pthread_mutex_unlock(&r->mu);
 }
 uint32_t oh_rec_intra_idx(OhRecorder *r, int c_idx, int x, int y, int log2_size, int mode, int avail, uint32_t tu)
 {
-    pthread_mutex_lock(&r->mu);
-    const uint32_t idx = r->f.n_intra;
-    const int rc = oh_rec_intra_u(r, c_idx, x, y, log2_size, mode, avail, tu);
-    pthread_mutex_unlock(&r->mu);
+    Shard *s = my_shard(r);
+    const uint32_t idx = s->n_intra;
+    const int rc = oh_rec_intra_u(r, s, c_idx, x, y, log2_size, mode, avail, tu);
     return rc ? OH_NO_COEFF : idx;
 }

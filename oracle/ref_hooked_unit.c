@@ -268,6 +268,10 @@ static struct {
 static __thread HEVCContext *tls_s;           /* the context whose access unit this thread is decoding (hooked_decode_frame) */
 static __thread int tls_md5_plane;            /* calc_md5 calls seen for the picture (0..2) */
 static __thread uint8_t tls_md5[48];
+/* OHEVC_HOOK_TIMING=1: where the wall time of the decode callback goes (printed when the decoder is closed) */
+#include <time.h>
+static double hook_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+static struct { double decode, finish, submit, fetch; int pictures; } HT;
 
 static OhEngine *the_engine(void)
 {
@@ -312,9 +316,13 @@ static int finish_and_submit(HEVCContext *s)
     int cur = -1, poc = 0, bad = 0;
     if (!H.open || H.s != s)
         return 0;
+    const double t_f0 = hook_now();
     const OhFrame *f = ref_hooked_finish(&cur, &poc, &bad);
+    HT.finish += hook_now() - t_f0;
     if (!f)
         return 0;
+    const double t_s0 = hook_now();
+    HT.pictures++;
     if (bad) { fprintf(stderr, "libopenhevc_hip: %d table-slot calls of the picture (poc %d) could not be turned into work-list items\n", bad, poc); return -1; }
     pthread_mutex_lock(&E.lock);
     OhEngine *e = the_engine();
@@ -335,6 +343,7 @@ static int finish_and_submit(HEVCContext *s)
     if (!rc && oh_frame_submit(e, &g) != OH_OK) { fprintf(stderr, "libopenhevc_hip: picture poc %d: %s\n", poc, oh_engine_last_error(e)); rc = -1; }
     H.last_engine_pic = rc ? -1 : g.cur_pic;
     pthread_mutex_unlock(&E.lock);
+    HT.submit += hook_now() - t_s0;
     return rc;
 }
 
@@ -363,6 +372,7 @@ static void hooked_md5_final(uint8_t *dst)
 __attribute__((visibility("default"))) int oh_hooked_fetch_output(AVFrame *out)
 {
     int rc = -1;
+    const double t_g0 = hook_now();
     pthread_mutex_lock(&E.lock);
     for (int i = 0; i < E.n && E.e; i++) {
         const ptrdiff_t off = out->data[0] - E.pic[i].base;
@@ -383,10 +393,34 @@ __attribute__((visibility("default"))) int oh_hooked_fetch_output(AVFrame *out)
         break;
     }
     pthread_mutex_unlock(&E.lock);
+    HT.fetch += hook_now() - t_g0;
     return rc;
+}
+/* libOpenHevcStartDecoder: the engine (HIP start-up, streams, kernels' attributes) comes up with the decoder, not with its first picture */
+__attribute__((visibility("default"))) int oh_hooked_engine_open(void)
+{
+    pthread_mutex_lock(&E.lock);
+    const int ok = the_engine() != NULL;
+    pthread_mutex_unlock(&E.lock);
+    return ok ? 0 : -1;
 }
 __attribute__((visibility("default"))) void oh_hooked_engine_close(void)
 {
+    if (getenv("OHEVC_HOOK_TIMING") && HT.pictures)
+        fprintf(stderr, "libopenhevc_hip timing, ms per picture over %d pictures: decode callback (host decoder incl. recording slots) %.2f, "
+                        "finish (side arrays + intra schedule) %.2f, hand-over to the engine %.2f, output fetch %.2f\n", HT.pictures,
+                HT.decode * 1e3 / HT.pictures, HT.finish * 1e3 / HT.pictures, HT.submit * 1e3 / HT.pictures, HT.fetch * 1e3 / HT.pictures);
+    if (getenv("OHEVC_HOOK_TIMING") && HT.pictures && E.e) {
+        double ms[OH_N_HOST_TIMES]; uint64_t calls[OH_N_HOST_TIMES];
+        static const char *nm[OH_N_HOST_TIMES] = { "upload", "upload: count loops", "upload: arena", "upload: wait for a staging buffer", "upload: memcpy to pinned",
+                                                   "upload: enqueue", "execute", "execute: wait for the preparation", "release" };
+        if (oh_engine_host_times(E.e, ms, calls, OH_N_HOST_TIMES, 0) == OH_OK) {
+            fprintf(stderr, "   engine host time, ms per picture:");
+            for (int i = 0; i < OH_N_HOST_TIMES; i++) fprintf(stderr, " %s %.2f;", nm[i], ms[i] / HT.pictures);
+            fprintf(stderr, " bytes over PCIe per picture %.2f MB\n", (double)oh_engine_upload_bytes(E.e, 0) / HT.pictures / 1e6);
+        }
+    }
+    memset(&HT, 0, sizeof(HT));
     pthread_mutex_lock(&E.lock);
     if (E.e) { oh_engine_sync(E.e); oh_engine_destroy(E.e); }
     E.e = NULL; E.n = 0; E.failed = 0;
@@ -420,7 +454,9 @@ static int hooked_decode_frame(AVCodecContext *avctx, void *data, int *got_outpu
 {
     tls_s = avctx->priv_data;
     tls_md5_plane = 0;
+    const double t_d0 = hook_now();
     const int ret = hevc_decode_frame(avctx, data, got_output, avpkt);
+    HT.decode += hook_now() - t_d0;
     if (finish_and_submit(avctx->priv_data) < 0)
         return AVERROR_EXTERNAL;
     return ret;

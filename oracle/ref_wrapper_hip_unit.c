@@ -16,6 +16,7 @@
 #include "libavcodec/avcodec.h"
 
 int  oh_hooked_fetch_output(AVFrame *out);       /* ref_hooked_unit.c, engine build */
+int  oh_hooked_engine_open(void);
 void oh_hooked_engine_close(void);
 int  oh_hooked_engine_sync(void);
 
@@ -54,6 +55,8 @@ int libOpenHevcStartDecoder(OpenHevc_Handle openHevcHandle)
             fprintf(stderr, "libopenhevc_hip: frame threads are not supported by the recording hooks (use slice / wavefront threads: thread type 2)\n");
             return -1;
         }
+    if (rc == 1 && oh_hooked_engine_open() != 0)
+        return -1;                               /* no MI355X: there is no CPU fallback behind this library */
     return rc;
 }
 

@@ -204,10 +204,10 @@ def end_to_end(n_pictures=60):
     threads = min(len(os.sched_getaffinity(0)), 16)
     out = dict(what="ohevc_dec (the reference's harness loop, public libOpenHevc* API only) on written streams: the drop-in library (engine inside) "
                     "next to the reference's own library on the same file, the same loop and the same clock",
-               front_end_threads=threads, thread_type="slice (wavefront rows)", cpu_model=cpu_model(), streams={})
+               front_end_threads=threads, cpu_model=cpu_model(), streams={})
 
-    def run(lib, path, extra=()):
-        r = subprocess.run([harness, "-i", path, "-F", lib, "-c", "-n", "-p", str(threads), "-f", "2", *extra], capture_output=True, text=True, timeout=600)
+    def run(lib, path, ttype, extra=()):
+        r = subprocess.run([harness, "-i", path, "-F", lib, "-c", "-n", "-p", str(threads), "-f", str(ttype), *extra], capture_output=True, text=True, timeout=600)
         last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
         if r.returncode != 0 or not last.startswith("frame= "):
             return dict(error=(r.stdout[-300:] + r.stderr[-300:]).strip())
@@ -224,21 +224,29 @@ def end_to_end(n_pictures=60):
             path = fh.name
         del data
         try:
-            run(libs["dropin"], path)                                      # warm-up: library load, HIP start-up, arenas
-            rec["dropin"] = run(libs["dropin"], path)                      # decode only: pictures stay in HBM (as `hevc -n` never looks at them)
-            rec["dropin_with_output"] = run(libs["dropin"], path, ("-g",)) # every released picture fetched into host planes (libOpenHevcGetOutput)
+            run(libs["dropin"], path, 1)                                              # warm-up: library load, file cache
+            # decode only: pictures stay in HBM (as `hevc -n` never looks at them); _with_output: every released picture fetched into
+            # host planes (libOpenHevcGetOutput).  Front end on the reference's FRAME threads (every worker records its own picture;
+            # recording needs no reference samples, so its motion-compensation waits fall away) and on its slice / wavefront threads
+            rec["dropin_frame_threads"] = run(libs["dropin"], path, 1)
+            rec["dropin_frame_threads_with_output"] = run(libs["dropin"], path, 1, ("-g",))
+            rec["dropin_slice_threads"] = run(libs["dropin"], path, 2)
+            rec["dropin_slice_threads_with_output"] = run(libs["dropin"], path, 2, ("-g",))
             for k in ("reference_sse", "reference_c"):
                 if os.path.exists(libs[k]):
-                    rec[k] = run(libs[k], path)
+                    rec[k + "_slice_threads"] = run(libs[k], path, 2)
+                    rec[k + "_frame_threads"] = run(libs[k], path, 1)
         finally:
             os.unlink(path)
-        for k in ("dropin", "dropin_with_output", "reference_sse", "reference_c"):
-            if k in rec and rec[k].get("fps"):
-                rec[k]["Mpixels_per_s"] = round(rec[k]["fps"] * w * h / 1e6, 1)
+        for k, v in rec.items():
+            if isinstance(v, dict) and v.get("fps"):
+                v["Mpixels_per_s"] = round(v["fps"] * w * h / 1e6, 1)
         out["streams"][name] = rec
     r8 = out["streams"].get("4320p_main10", {})
-    fps8 = (r8.get("dropin_with_output") or {}).get("fps")
-    out["north_star_8K60"] = dict(target_fps=60, measured_fps=fps8, met=bool(fps8 and fps8 >= 60),
+    fps8 = (r8.get("dropin_frame_threads") or {}).get("fps")
+    fps8o = (r8.get("dropin_frame_threads_with_output") or {}).get("fps")
+    out["north_star_8K60"] = dict(target_fps=60, measured_fps_decode=fps8, measured_fps_with_every_picture_fetched_to_host=fps8o,
+                                  met_decode=bool(fps8 and fps8 >= 60), met_with_output=bool(fps8o and fps8o >= 60),
                                   note="end to end on ONE stream the host front end (the reference's CABAC / syntax / motion derivation on slice threads) sets the pace: "
                                        "the GPU passes of a picture take a fraction of its parse time (compare the headline: thousands of pictures per second over work lists)")
     return out

@@ -34,6 +34,10 @@ void        oh_rec_destroy(OhRecorder *r);
  * does (hevc.c:3207-3210; is_pcm is cleared too — the reference's leak of stale flags across
  * pictures, SURVEY.md §7, is a host-side matter of what the caller writes into it). */
 void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref_pics);
+/* optional, once the work list oh_rec_finish() returned has been consumed (uploaded / copied): clears the per-picture maps NOW so that
+ * the next oh_rec_begin() does not have to (frame threads: oh_rec_begin runs inside the stretch that is serial across the workers).
+ * The lists the OhFrame points at stay valid until that oh_rec_begin(); the maps it points at (BS grids, QP, PCM, SAO, deblock) do not. */
+void oh_rec_recycle(OhRecorder *r);
 
 /* inter PU; returns 0 or -1 on invalid geometry.  wp may be NULL (default weighting). */
 int oh_rec_pu(OhRecorder *r, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,

@@ -75,6 +75,7 @@ struct OhRecorder {
     uint16_t *lvl[3]; int lw[3], lh[3];
     uint8_t  *decoded; int dw, dh;
     int oom;                                     /* an allocation failed while recording this picture: items were dropped, oh_rec_finish() returns NULL */
+    int clean;                                   /* the per-picture maps are already zero (oh_rec_recycle) */
 };
 
 /* the table slots that feed the recorder cannot fail (void returns), so an allocation failure is latched in r->oom: the block
@@ -192,9 +193,9 @@ void oh_rec_destroy(OhRecorder *r)
     free(r);
 }
 
+static void oh_rec_clear_maps(OhRecorder *r);
 void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref_pics)
 {
-    const OhPicParams *p = &r->f.p;
     r->f.cur_pic = cur_pic;
     for (int i = 0; i < OH_MAX_REFS; i++)
         r->f.ref_pics[i] = i < n_ref_pics ? ref_pics[i] : -1;
@@ -209,6 +210,19 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
     }
     r->n_sh = 0;
     r->epoch = __sync_add_and_fetch(&g_epoch, 1);
+    if (r->clean) {                                          /* oh_rec_recycle() already cleared the maps behind the previous picture */
+        r->clean = 0;
+        return;
+    }
+    oh_rec_clear_maps(r);
+}
+
+/* the per-picture maps back to zero: ~4.6 MB for a 4K picture.  oh_rec_begin() does it unless oh_rec_recycle() has: a decoder with
+ * frame threads calls that one behind the hand-over of the previous picture, on the worker's own time — oh_rec_begin() sits between
+ * frame start and ff_thread_finish_setup, the one stretch that is serial across the workers */
+static void oh_rec_clear_maps(OhRecorder *r)
+{
+    const OhPicParams *p = &r->f.p;
     r->ctb_maps_on = 0;
     memset(r->vbs, 0, r->f.bs_size);
     memset(r->hbs, 0, r->f.bs_size);
@@ -222,6 +236,13 @@ void oh_rec_begin(OhRecorder *r, int cur_pic, const int32_t *ref_pics, int n_ref
         if (r->lvl[c])
             memset(r->lvl[c], 0, (size_t)r->lw[c] * r->lh[c] * sizeof(uint16_t));
     memset(r->decoded, 0, (size_t)r->dw * r->dh);
+}
+void oh_rec_recycle(OhRecorder *r)
+{
+    if (!r || r->clean)
+        return;
+    oh_rec_clear_maps(r);
+    r->clean = 1;
 }
 
 static int oh_rec_pu_u(OhRecorder *r, Shard *s, int x, int y, int w, int h, int ref0, int mv0x, int mv0y,

@@ -40,8 +40,10 @@ void oh_tables_set_intra_accessor(oh_intra_accessor fn);
 int  oh_tables_finish(void);
 void oh_tables_untranslated_by_family(int out[8]);
 
-static struct {
-    HEVCContext *s;                   /* the context whose picture is being recorded (single-threaded decode) */
+/* per decoding THREAD: the main thread (no threads, or slice / wavefront threads: it starts and ends every picture), or each of the
+ * reference's frame threads (pthread_frame.c: a worker keeps its own HEVCContext and decodes whole pictures) */
+static __thread struct {
+    HEVCContext *s;                   /* the context whose picture is being recorded on this thread */
     OhRecorder *rec;
     OhPicParams p;
     int open;                         /* a picture was started and not finished yet */
@@ -50,11 +52,15 @@ static struct {
     int scaling_on;
     OhScalingList scaling;
     int last_engine_pic;              /* engine build: the engine picture the last submitted work list reconstructs */
+    unsigned long long seq;           /* engine build: position of the picture in decode order (hand-over order) */
 } H;
 
 static int g_bs_from_motion;          /* ref_hooked_bs_from_motion(): the work lists carry the boundary-strength INPUTS */
-static uint8_t *g_bs_call;            /* per min-TB cell: log2 size ff_hevc_deblocking_boundary_strengths was called with there, 0 = never */
-static size_t g_bs_call_n;
+static __thread uint8_t *g_bs_call;   /* per min-TB cell: log2 size ff_hevc_deblocking_boundary_strengths was called with there, 0 = never */
+static __thread size_t g_bs_call_n;
+#ifdef OH_WITH_ENGINE
+static unsigned long long next_picture_seq(void);
+#endif
 
 /* INTEGRATION.md §3 */
 static void intra_from_hevc(struct HEVCContext *s, int x0, int y0, int c_idx, int log2_size, int *mode, int *avail)
@@ -79,8 +85,25 @@ static void intra_from_hevc(struct HEVCContext *s, int x0, int y0, int c_idx, in
     }
 }
 
+#ifdef OH_WITH_ENGINE
+double hook_now(void);
+static __thread double tls_t_entry;
+static struct { double to_rps, bind, to_newref, newref; } HT2;
+static int timed_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
+{
+    const double t0 = hook_now();
+    HT2.to_newref += t0 - tls_t_entry;
+    const int r = ff_hevc_set_new_ref(s, frame, poc);
+    HT2.newref += hook_now() - t0;
+    return r;
+}
+#endif
 static int frame_rps_and_bind(HEVCContext *s)
 {
+#ifdef OH_WITH_ENGINE
+    const double t_b0 = hook_now();
+    HT2.to_rps += t_b0 - tls_t_entry;
+#endif
     int ret = ff_hevc_frame_rps(s);
     if (ret < 0)
         return ret;
@@ -118,11 +141,17 @@ static int frame_rps_and_bind(HEVCContext *s)
         if (g_bs_call_n != n_tb) { free(g_bs_call); g_bs_call = (uint8_t *)malloc(n_tb); g_bs_call_n = g_bs_call ? n_tb : 0; }
         if (g_bs_call) memset(g_bs_call, 0, n_tb);
     }
+#ifdef OH_WITH_ENGINE
+    H.seq = next_picture_seq();       /* frame starts are serialised by the frame-thread protocol (ff_thread_finish_setup): decode order */
+#endif
     oh_tables_set_intra_accessor(intra_from_hevc);
     oh_tables_bind(H.rec, s->frame->data, s->frame->linesize);
     for (int i = 0; i < H.n_refs; i++)
         oh_tables_bind_ref(i, s->DPB[H.ref_ids[i]].frame->data, s->DPB[H.ref_ids[i]].frame->linesize);
     H.open = 1;
+#ifdef OH_WITH_ENGINE
+    HT2.bind += hook_now() - t_b0;
+#endif
     return ret;
 }
 
@@ -270,8 +299,33 @@ static __thread int tls_md5_plane;            /* calc_md5 calls seen for the pic
 static __thread uint8_t tls_md5[48];
 /* OHEVC_HOOK_TIMING=1: where the wall time of the decode callback goes (printed when the decoder is closed) */
 #include <time.h>
-static double hook_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
-static struct { double decode, finish, submit, fetch; int pictures; } HT;
+double hook_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+static struct { double decode, finish, submit, fetch, setup, turn; int pictures; } HT;
+
+/* hand-over in DECODE order: with frame threads a picture may finish parsing before the one it references; the engine runs work
+ * lists in the order they are submitted (that order IS the dependency order on its stream), so a worker waits for its turn */
+static struct { pthread_mutex_t mu; pthread_cond_t cv; unsigned long long next, turn; } SEQ = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0 };
+static unsigned long long next_picture_seq(void)
+{
+    pthread_mutex_lock(&SEQ.mu);
+    const unsigned long long v = SEQ.next++;
+    pthread_mutex_unlock(&SEQ.mu);
+    return v;
+}
+static void seq_wait_turn(unsigned long long seq)
+{
+    pthread_mutex_lock(&SEQ.mu);
+    while (SEQ.turn != seq)
+        pthread_cond_wait(&SEQ.cv, &SEQ.mu);
+    pthread_mutex_unlock(&SEQ.mu);
+}
+static void seq_done(void)
+{
+    pthread_mutex_lock(&SEQ.mu);
+    SEQ.turn++;
+    pthread_cond_broadcast(&SEQ.cv);
+    pthread_mutex_unlock(&SEQ.mu);
+}
 
 static OhEngine *the_engine(void)
 {
@@ -299,6 +353,15 @@ static int engine_pic_of(const AVFrame *fr, const OhPicParams *p)
     if (slot >= 0 && same_geometry(&E.pic[slot].p, p))
         return E.pic[slot].id;
     if (slot < 0) {
+        /* a NEW buffer: whatever the map still holds inside its range belongs to buffers the frame pool has freed since */
+        const uint8_t *lo = fr->data[0], *hi = lo + (size_t)fr->linesize[0] * (size_t)p->height;
+        for (int i = 0; i < E.n; ) {
+            if (E.pic[i].base < hi && E.pic[i].base + E.pic[i].span > lo) {
+                oh_pic_free(e, E.pic[i].id);
+                E.pic[i] = E.pic[--E.n];
+            } else
+                i++;
+        }
         if (E.n == (int)(sizeof(E.pic) / sizeof(E.pic[0]))) { fprintf(stderr, "libopenhevc_hip: more than %d host frame buffers in use\n", E.n); return -1; }
         slot = E.n++;
     } else {
@@ -316,14 +379,20 @@ static int finish_and_submit(HEVCContext *s)
     int cur = -1, poc = 0, bad = 0;
     if (!H.open || H.s != s)
         return 0;
+    const unsigned long long seq = H.seq;
     const double t_f0 = hook_now();
     const OhFrame *f = ref_hooked_finish(&cur, &poc, &bad);
     HT.finish += hook_now() - t_f0;
-    if (!f)
+    { const double t_w0 = hook_now();
+    seq_wait_turn(seq);                                       /* every picture that was started takes its turn, submitted or not */
+    HT.turn += hook_now() - t_w0; }
+    if (!f) {
+        seq_done();
         return 0;
+    }
     const double t_s0 = hook_now();
     HT.pictures++;
-    if (bad) { fprintf(stderr, "libopenhevc_hip: %d table-slot calls of the picture (poc %d) could not be turned into work-list items\n", bad, poc); return -1; }
+    if (bad) { seq_done(); fprintf(stderr, "libopenhevc_hip: %d table-slot calls of the picture (poc %d) could not be turned into work-list items\n", bad, poc); return -1; }
     pthread_mutex_lock(&E.lock);
     OhEngine *e = the_engine();
     int rc = e ? 0 : -1;
@@ -343,7 +412,9 @@ static int finish_and_submit(HEVCContext *s)
     if (!rc && oh_frame_submit(e, &g) != OH_OK) { fprintf(stderr, "libopenhevc_hip: picture poc %d: %s\n", poc, oh_engine_last_error(e)); rc = -1; }
     H.last_engine_pic = rc ? -1 : g.cur_pic;
     pthread_mutex_unlock(&E.lock);
+    seq_done();
     HT.submit += hook_now() - t_s0;
+    oh_rec_recycle(H.rec);                                    /* the lists are in the engine's staging buffer: clear the maps on this worker's own time */
     return rc;
 }
 
@@ -374,10 +445,17 @@ __attribute__((visibility("default"))) int oh_hooked_fetch_output(AVFrame *out)
     int rc = -1;
     const double t_g0 = hook_now();
     pthread_mutex_lock(&E.lock);
-    for (int i = 0; i < E.n && E.e; i++) {
+    int hit = -1;
+    for (int i = 0; i < E.n && hit < 0; i++)                  /* the buffer itself (no window) ... */
+        if (E.pic[i].base == out->data[0]) hit = i;
+    for (int i = 0; i < E.n && hit < 0; i++) {                /* ... or a position inside one (the conformance window's origin) */
         const ptrdiff_t off = out->data[0] - E.pic[i].base;
-        if (off < 0 || (size_t)off >= E.pic[i].span || out->linesize[0] <= 0)
-            continue;
+        if (off >= 0 && (size_t)off < E.pic[i].span) hit = i;
+    }
+    for (int i = hit; i >= 0 && i == hit && E.e; i++) {
+        const ptrdiff_t off = out->data[0] - E.pic[i].base;
+        if (out->linesize[0] <= 0)
+            break;
         const OhPicParams *p = &E.pic[i].p;
         const int ps = p->bit_depth > 8;
         const int y = (int)(off / out->linesize[0]), x = (int)(off % out->linesize[0]) >> ps;
@@ -408,8 +486,15 @@ __attribute__((visibility("default"))) void oh_hooked_engine_close(void)
 {
     if (getenv("OHEVC_HOOK_TIMING") && HT.pictures)
         fprintf(stderr, "libopenhevc_hip timing, ms per picture over %d pictures: decode callback (host decoder incl. recording slots) %.2f, "
-                        "finish (side arrays + intra schedule) %.2f, hand-over to the engine %.2f, output fetch %.2f\n", HT.pictures,
-                HT.decode * 1e3 / HT.pictures, HT.finish * 1e3 / HT.pictures, HT.submit * 1e3 / HT.pictures, HT.fetch * 1e3 / HT.pictures);
+                        "finish (side arrays + intra schedule) %.2f, hand-over to the engine %.2f, output fetch %.2f; frame threads: callback entry -> "
+                        "ff_thread_finish_setup (serial across workers) %.2f, waiting for the hand-over turn %.2f\n", HT.pictures,
+                HT.decode * 1e3 / HT.pictures, HT.finish * 1e3 / HT.pictures, HT.submit * 1e3 / HT.pictures, HT.fetch * 1e3 / HT.pictures,
+                HT.setup * 1e3 / HT.pictures, HT.turn * 1e3 / HT.pictures);
+    if (getenv("OHEVC_HOOK_TIMING") && HT.pictures)
+        fprintf(stderr, "   of the serial stretch: callback entry -> ff_hevc_set_new_ref %.2f (NAL split, slice header, frame-start memsets), ff_hevc_set_new_ref %.2f (frame buffers), "
+                        "callback entry -> ff_hevc_frame_rps %.2f, frame_rps + recorder begin + binding %.2f\n",
+                HT2.to_newref * 1e3 / HT.pictures, HT2.newref * 1e3 / HT.pictures, HT2.to_rps * 1e3 / HT.pictures, HT2.bind * 1e3 / HT.pictures);
+    memset(&HT2, 0, sizeof(HT2));
     if (getenv("OHEVC_HOOK_TIMING") && HT.pictures && E.e) {
         double ms[OH_N_HOST_TIMES]; uint64_t calls[OH_N_HOST_TIMES];
         static const char *nm[OH_N_HOST_TIMES] = { "upload", "upload: count loops", "upload: arena", "upload: wait for a staging buffer", "upload: memcpy to pinned",
@@ -421,6 +506,7 @@ __attribute__((visibility("default"))) void oh_hooked_engine_close(void)
         }
     }
     memset(&HT, 0, sizeof(HT));
+    pthread_mutex_lock(&SEQ.mu); SEQ.next = SEQ.turn = 0; pthread_mutex_unlock(&SEQ.mu);
     pthread_mutex_lock(&E.lock);
     if (E.e) { oh_engine_sync(E.e); oh_engine_destroy(E.e); }
     E.e = NULL; E.n = 0; E.failed = 0;
@@ -441,8 +527,23 @@ __attribute__((visibility("default"))) int oh_hooked_engine_sync(void)
 #define ff_hevc_pred_init(c, bd)  do { ff_hevc_pred_init(c, bd); ff_hevcpred_init_hip((void *)(c), bd); } while (0)
 #define ff_videodsp_init(c, bd)   do { ff_videodsp_init(c, bd);  ff_videodsp_init_hip((void *)(c), bd); } while (0)
 #define ff_hevc_frame_rps(s)      frame_rps_and_bind(s)
-#define ff_hevc_hls_filters(s, x, y, c) ((void)0)
-#define ff_hevc_hls_filter(s, x, y, c)  ((void)0)
+/* The in-loop filter drivers are dropped (passes 4-5 run on the GPU) — but with FRAME threads they also carry the row progress the
+ * next picture's thread waits for (hevc_filter.c:1040-1050 ff_thread_report_progress).  With recording slots nobody on the host
+ * reads reference SAMPLES any more, so the motion-compensation waits (hevc.c:1951-1958 hevc_await_progress) fall away; what a later
+ * picture still reads on the host is the collocated MOTION FIELD (hevc_mvs.c:262 temporal_luma_motion_vector waits for row y), and a
+ * CTB row's motion field is complete when its last CTB has been parsed: that is reported here. */
+static void hooked_row_progress(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size)
+{
+    if ((s->threads_type & FF_THREAD_FRAME) && s->ref && x_ctb >= s->sps->width - ctb_size)
+        ff_thread_report_progress(&s->ref->tf, y_ctb + ctb_size, 0);
+}
+#define ff_hevc_hls_filters(s, x, y, c) hooked_row_progress(s, x, y, c)
+#define ff_hevc_hls_filter(s, x, y, c)  hooked_row_progress(s, x, y, c)
+#define ff_thread_await_progress(tf, y, field) ((void)0)
+#ifdef OH_WITH_ENGINE
+#define ff_hevc_set_new_ref(s, f, poc) timed_set_new_ref(s, f, poc)
+#define ff_thread_finish_setup(avctx) do { HT.setup += hook_now() - tls_t_entry; ff_thread_finish_setup(avctx); } while (0)
+#endif
 
 #include "libavcodec/hevc.c"
 
@@ -455,6 +556,7 @@ static int hooked_decode_frame(AVCodecContext *avctx, void *data, int *got_outpu
     tls_s = avctx->priv_data;
     tls_md5_plane = 0;
     const double t_d0 = hook_now();
+    tls_t_entry = t_d0;
     const int ret = hevc_decode_frame(avctx, data, got_output, avpkt);
     HT.decode += hook_now() - t_d0;
     if (finish_and_submit(avctx->priv_data) < 0)

@@ -49,10 +49,11 @@ int libOpenHevcStartDecoder(OpenHevc_Handle openHevcHandle)
     OpenHevcWrapperContexts *ctxs = (OpenHevcWrapperContexts *)openHevcHandle;
     const int rc = oh_host_StartDecoder(openHevcHandle);
     for (int i = 0; rc == 1 && i < ctxs->nb_decoders; i++)
-        if (ctxs->wraper[i]->c->active_thread_type & FF_THREAD_FRAME) {
-            /* frame threads keep several pictures between hevc_frame_start and output at once; the recording slots bind one
-             * picture per thread, but the hand-over (ref_hooked_unit.c) still keeps ONE picture's state: INTEGRATION.md 7b */
-            fprintf(stderr, "libopenhevc_hip: frame threads are not supported by the recording hooks (use slice / wavefront threads: thread type 2)\n");
+        if ((ctxs->wraper[i]->c->active_thread_type & FF_THREAD_FRAME) && (ctxs->wraper[i]->c->active_thread_type & FF_THREAD_SLICE)) {
+            /* frame threads: every worker records its own picture (per-thread binding, ordered hand-over); slice / wavefront threads:
+             * the workers adopt the picture in flight.  Both at once: a slice worker could not tell WHICH picture in flight is its
+             * own (the table slots carry no context): INTEGRATION.md 7b */
+            fprintf(stderr, "libopenhevc_hip: frame AND slice threads together are not supported by the recording hooks (thread type 1 or 2, not 4)\n");
             return -1;
         }
     if (rc == 1 && oh_hooked_engine_open() != 0)

@@ -131,8 +131,15 @@ def test_harness_decodes_streams_and_the_gpu_md5_matches_the_sei(case, tmp_path)
     if kw.get("wpp"):                                        # the front end on 4 slice threads (wavefront entry points): same verdict
         r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-p", "4", "-f", "2"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1
-        r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-p", "4", "-f", "1"], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 2                             # frame threads are not what the recording slots support
+        r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-p", "4", "-f", "4"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 2                             # frame AND slice threads together are not what the recording slots support
+    # the front end on 4 FRAME threads (pthread_frame.c: every worker records its own picture, hand-over in decode order): same verdict
+    # (not for streams with PCM / bypass and the loop filter off: there the REFERENCE's own pictures depend on the thread configuration —
+    # s->is_pcm is never cleared per picture and every frame thread's context keeps its own, hevc.c:147,1440 — so digests taken from its
+    # single-threaded run do not describe its frame-threaded one either)
+    if not (kw.get("pcm") or kw.get("transquant_bypass")):
+      r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-p", "4", "-f", "1"], capture_output=True, text=True, timeout=600)
+      assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1, r.stdout[-1500:] + r.stderr[-1500:]
     # -b: the front end hands over its motion field, the engine derives the boundary strengths (bs_kernel): same verdict
     r = subprocess.run([HARNESS, "-i", str(path), "-F", HOOKED, "-b"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 3 and r.stdout.count("Incorrect MD5") == 1 and r.stdout.count("Correct MD5") == 3 * n - 1

@@ -283,6 +283,10 @@ def main():
                     help="gloo: REHEARSAL of the N>1 control flow with several ranks on one GPU (transfers staged through host memory)")
     ap.add_argument("--bs-from-motion", action="store_true", help="work lists carry the motion field instead of finished boundary-strength grids; "
                     "the engine derives the grids at upload (bs_kernel: inside the timed region in decode mode)")
+    ap.add_argument("--pinned-lists", action="store_true", help="experiment: keep the host work lists in page-locked blocks from oh_host_alloc (OH_FRAME_PINNED, "
+                    "boundary strengths packed): the engine copies them by DMA from where they lie, array by array, instead of staging them on the host "
+                    "thread.  Measured SLOWER (fifteen small DMAs per picture keep the copy queue busy: 47 against 82 Gpixels/s): the default is ordinary host "
+                    "memory, staged into one pinned block by the calling thread and the engine's copy helpers, ONE DMA per picture")
     ap.add_argument("--host-threads", type=int, default=0, help="1: a single host thread enqueues every stream (default: one thread per stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end stream decode through the drop-in library (ohevc_dec child processes, ~1-2 min)")
@@ -303,6 +307,8 @@ def main():
     from openhevc_amd import frame as F
     from openhevc_amd import parallel as P
     from openhevc_amd.engine import Engine
+    from openhevc_amd.engine import lib as _engine_lib
+    engine_lib = _engine_lib()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -359,7 +365,7 @@ def main():
     host = []
     for m in range(n_host):
         plan_m = P.make_step_plan(world, rank, n_waves=args.waves, n_tail=args.tail, seed=0x48455643 + m, gop=args.gop)
-        host.append((plan_m, P.host_work_lists(params, plan_m, knobs)))
+        host.append((plan_m, P.host_work_lists(params, plan_m, knobs, pinned_by=engine_lib if args.pinned_lists else None)))
     host_bytes = sum(fc.bytes for _, (lists, _) in host for fc in lists.values())
     # N > 1: every stream keeps its own host thread (one thread hands over 3.2 k 4K pictures/s, four 8.5 k); their exchanges are
     # issued through a turnstile in one order on every rank (parallel.Turnstile)
@@ -469,6 +475,19 @@ def main():
             exchange_stats.extend(every)
         return dt, dt_enqueue
 
+    # who takes part: what the communication library itself reports (world size, backend) and every rank's device (index, name, UUID):
+    # the first run on real xGMI should say what it ran on
+    def device_info():
+        pr = torch.cuda.get_device_properties(local_rank)
+        return dict(rank=rank, local_rank=local_rank, device=pr.name, uuid=str(getattr(pr, "uuid", "")), gcn_arch=getattr(pr, "gcnArchName", ""),
+                    hbm_GB=round(pr.total_memory / 1e9, 1), compute_units=pr.multi_processor_count)
+    ranks_info = None
+    if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, device_info())
+        ranks_info = dict(world_size_reported_by_backend=dist.get_world_size(), backend=dist.get_backend(), devices=every)
+    else:
+        ranks_info = dict(world_size_reported_by_backend=1, backend=None, devices=[device_info()])
     exchange_stats = []
     prof_level = [1]            # the timed regions carry the per-pass events only; per-launch events get a short region of their own
 
@@ -665,7 +684,9 @@ def main():
                        "step": f"every chain in flight advances by one closed GOP (1 I + {args.waves - 1} reference B + {args.tail} "
                                f"non-reference B pictures): {n_chains} GOPs per GPU and step",
                        "chains_in_flight_per_gpu": n_chains, "chains_asked_per_gpu": chains_asked, "streams_per_gpu": n_streams,
-                       "host_work_lists": f"{n_host} distinct GOPs, {round(host_bytes / n_host / P.pictures_per_step(plan) / 1e6, 2)} MB per picture on average",
+                       "host_work_lists": f"{n_host} distinct GOPs, {round(host_bytes / n_host / P.pictures_per_step(plan) / 1e6, 2)} MB per picture on average, held in "
+                                          + ("page-locked blocks lent by the engine (oh_host_alloc), boundary strengths packed four to the byte: handed over by DMA from where they lie"
+                                             if args.pinned_lists else "ordinary host memory (staged into one pinned block by the calling thread + the engine's 2 copy helpers, one DMA per picture)"),
                        "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
                        "gop": args.gop,
                        "exchange": ("none (1 GPU)" if world == 1 else
@@ -673,6 +694,7 @@ def main():
                                     "stream (the pictures of all chains of the stream are contiguous per rank), on the stream's own exchange stream between HIP events"
                                     if exchange is not None else "one RCCL all-gather of the finished reference pictures per wave and stream, on the stream's own exchange stream"),
                        "exchange_per_rank": decode_exchange if world > 1 else None,
+                       "ranks": ranks_info,
                        "generator": dict(gen, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
             "roofline": head["roofline"],
             "check": check,

@@ -20,6 +20,7 @@
 #ifndef OHEVC_FRAME_H
 #define OHEVC_FRAME_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -195,7 +196,28 @@ typedef struct OhFrame {
      * simulates ff_hevc_hls_filters / ff_hevc_hls_filter, hevc_filter.c:1027-1064, over the picture's decoding order).
      * NULL: CTBs decoded in raster order, one thread — the engine derives the same bits in closed form. */
     const uint8_t      *sao_pending;  /* ctb_width x ctb_height, may be NULL */
+    uint32_t flags;                   /* OH_FRAME_*: how the arrays are held (0: ordinary host memory, byte grids) */
 } OhFrame;
+/* OhFrame.flags.
+ * OH_FRAME_PINNED     every array the list points at lies in memory from oh_host_alloc() (ohevc_hip.h): the engine copies them to the
+ *                     GPU by DMA straight from where they lie — no staging copy on the host.  They must stay untouched until the
+ *                     list's copy has completed (oh_frames_execute of the list, or any wait on the engine, is behind it).  This is
+ *                     the hand-over of a recorder that writes its lists into blocks the engine lent it.
+ * OH_FRAME_BS_PACKED  vertical_bs / horizontal_bs hold the strengths FOUR TO THE BYTE (entry i in bits 2 (i & 3) of byte i >> 2,
+ *                     (bs_size + 3) / 4 bytes each): the form they travel in and live in on the GPU (a strength is 0..2).  A
+ *                     recorder packs them while it copies the decoder's byte grids (oh_pack_bs). */
+enum { OH_FRAME_PINNED = 1, OH_FRAME_BS_PACKED = 2 };
+static inline void oh_pack_bs(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        dst[i >> 2] = (uint8_t)((src[i] & 3) | (src[i + 1] & 3) << 2 | (src[i + 2] & 3) << 4 | (src[i + 3] & 3) << 6);
+    if (i < n) {
+        unsigned v = 0;
+        for (size_t k = i; k < n; k++) v |= (unsigned)(src[k] & 3) << (2 * (k & 3));
+        dst[i >> 2] = (uint8_t)v;
+    }
+}
 
 /* one entry of the reference's motion field = MvField as compiled (TEST_MV_POC defined, hevc.h:73, 1032-1041): 24 bytes, compared
  * as a whole by boundary_strength()'s memcmp (hevc_filter.c:600), padding included */

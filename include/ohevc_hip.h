@@ -52,6 +52,10 @@ typedef struct OhEngine   OhEngine;
 typedef struct OhDevFrame OhDevFrame;
 
 int  oh_engine_create(OhEngine **out, int device);
+/* page-locked host memory: a work list whose arrays ALL lie in blocks from oh_host_alloc() may carry OH_FRAME_PINNED (ohevc_frame.h) and
+ * is then copied to the GPU by DMA from where it lies (no staging copy on the host thread) */
+void *oh_host_alloc(size_t bytes);
+void  oh_host_free(void *p);
 /* same, but every kernel and copy is enqueued on the caller's stream (hipStream_t passed as
  * void*; e.g. torch.cuda.current_stream().cuda_stream) so that RCCL collectives issued by the
  * caller on that stream are ordered with the engine's passes.  The stream is not destroyed. */

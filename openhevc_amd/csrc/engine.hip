@@ -11,6 +11,9 @@
 #include <algorithm>
 #include <chrono>
 #include <string>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ohevc_hip.h"
@@ -70,6 +73,66 @@ struct OhDevFrame {
     std::vector<Level> levels;
 };
 
+/* helper threads for the one host copy of the hand-over (the work list into a pinned staging buffer): the lists of a 4K picture are
+ * ~4 MB, 0.22 ms for one thread — most of what the hand-over costs the decoder's thread.  The calling thread keeps a share. */
+struct CopyJob { char *dst; const char *src; size_t n; bool pack; };
+static void pack_bs(uint8_t *dst, const uint8_t *src, size_t n);
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    const std::vector<CopyJob> *jobs = nullptr;
+    int pending = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+    static void run_share(const std::vector<CopyJob> &jobs, int share, int shares)
+    {
+        for (size_t i = (size_t)share; i < jobs.size(); i += (size_t)shares) {
+            const CopyJob &j = jobs[i];
+            if (j.pack) pack_bs((uint8_t *)j.dst, (const uint8_t *)j.src, j.n);
+            else memcpy(j.dst, j.src, j.n);
+        }
+    }
+    void worker(int k)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::vector<CopyJob> *my;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                my = jobs;
+            }
+            run_share(*my, k + 1, (int)th.size() + 1);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) done_cv.notify_one();
+            }
+        }
+    }
+    void start(int n) { for (int k = 0; k < n; k++) th.emplace_back(&CopyPool::worker, this, k); }
+    void run(const std::vector<CopyJob> &j)                    /* returns when every job has been copied */
+    {
+        if (th.empty()) { run_share(j, 0, 1); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs = &j; pending = (int)th.size(); gen++;
+        }
+        cv.notify_all();
+        run_share(j, 0, (int)th.size() + 1);
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+
 struct OhEngine {
     int         device = 0;
     int         n_cu = 256;              /* compute units of the device */
@@ -112,6 +175,13 @@ struct OhEngine {
     hipEvent_t  batch_ev[BATCH_RING] = {};
     uint64_t    batch_seq = 0;
     hipStream_t dl_stream = nullptr;
+    /* ticket counters of the one-launch intra forms: a ring of pairs (direct, staged) in HBM; a batch uses the next pair, cleared on
+     * the stream in front of its launches (a pair comes round again 128 batches later: long after its launch has drained) */
+    enum { TICKET_RING = 128, TICKET_WORDS = 2 * OH_MAX_BATCH * 32 };      /* per batch: (direct, staged) x pictures, a cache line each (intra.hip: OH_TICKET_STRIDE) */
+    uint32_t   *tickets = nullptr;
+    uint64_t    ticket_seq = 0;
+    CopyPool   *copiers = nullptr;      /* created with the first hand-over (OHEVC_COPY_THREADS helpers, default 2) */
+    std::vector<CopyJob> copy_jobs;
     uint32_t   *kerr = nullptr;
     uint32_t    spin_limit = 1u << 22;   /* polls (with s_sleep between them, ~1 s in all) before a waiting workgroup gives up; OHEVC_SPIN_LIMIT */
 };
@@ -219,6 +289,11 @@ static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_e
         return OH_E_HIP;
     }
     memset(e->kerr, 0, 4 * sizeof(uint32_t));
+    if (hipMalloc((void **)&e->tickets, (size_t)OhEngine::TICKET_WORDS * OhEngine::TICKET_RING * sizeof(uint32_t)) != hipSuccess) {
+        fprintf(stderr, "ohevc_hip: no device memory for the ticket counters\n");
+        delete e;
+        return OH_E_HIP;
+    }
     if (const char *sl = getenv("OHEVC_SPIN_LIMIT"))          /* tests: make a waiting workgroup give up at once */
         e->spin_limit = (uint32_t)std::max(1l, atol(sl));
     if (getenv("OHEVC_STAMPS")) {
@@ -242,6 +317,14 @@ extern "C" int oh_debug_read(OhEngine *e, uint64_t *out, size_t n_u64)
     HIPCHK(e, hipMemset(e->dbg, 0, total * sizeof(uint64_t)));
     return OH_OK;
 }
+
+/* page-locked host memory for work lists handed over with OH_FRAME_PINNED (the GPU reads them by DMA where they lie) */
+extern "C" void *oh_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+extern "C" void oh_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int oh_engine_create(OhEngine **out, int device) { return engine_create(out, device, nullptr, false); }
 extern "C" int oh_engine_create_on_stream(OhEngine **out, int device, void *hip_stream)
@@ -328,7 +411,9 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &a : e->arenas) { if (a.free_ev) (void)hipEventDestroy(a.free_ev); (void)hipFree(a.p); }
     for (auto &ev : e->sync_events) (void)hipEventDestroy(ev);
     for (void *b : e->sum_pool) (void)hipHostFree(b);
+    delete e->copiers;
     if (e->kerr) (void)hipHostFree(e->kerr);
+    if (e->tickets) (void)hipFree(e->tickets);
     for (auto &ev : e->batch_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->dl_stream) { (void)hipStreamSynchronize(e->dl_stream); (void)hipStreamDestroy(e->dl_stream); }
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -933,7 +1018,8 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     const size_t bs_packed = (bs_bytes + 3) / 4;
     int s_vbs = add(has_db && !bsi ? f->vertical_bs : nullptr, has_db ? bs_packed : 0);    /* with bs_in: written by bs_kernel after the copy */
     int s_hbs = add(has_db && !bsi ? f->horizontal_bs : nullptr, has_db ? bs_packed : 0);
-    if (has_db && !bsi) seg[s_vbs].pack_n = seg[s_hbs].pack_n = bs_bytes;
+    const bool bs_packed_in = (f->flags & OH_FRAME_BS_PACKED) != 0;          /* the grids come four to the byte already */
+    if (has_db && !bsi && !bs_packed_in) seg[s_vbs].pack_n = seg[s_hbs].pack_n = bs_bytes;
     const size_t n_mtb = (size_t)(p.width >> p.log2_min_tb_size) * (p.height >> p.log2_min_tb_size);
     int s_mvf = add(bsi ? bsi->mvf : nullptr, bsi ? n_pcm * sizeof(OhMvField) : 0);
     int s_cbf = add(bsi ? bsi->cbf_luma : nullptr, bsi ? n_mtb : 0);
@@ -1069,11 +1155,14 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hd.dbg = e->dbg;
     (void)s_hdr;
 
-    /* stage everything in one host buffer -> one H2D copy */
+    /* stage everything in one host buffer -> one H2D copy; a list that lies in pinned memory (OH_FRAME_PINNED) is copied by DMA from
+     * where it lies, segment by segment: only what this function made itself (the header, the PU block offsets) is staged */
     auto t_alloc = tnow();
+    const bool direct = (f->flags & OH_FRAME_PINNED) != 0 && !(has_db && !bsi && !bs_packed_in);     /* byte grids still have to be packed on the way */
+    const size_t own_bytes = align_up(sizeof(DevFrame), 256) + align_up(2 * ((size_t)f->n_pu + 1) * sizeof(uint32_t), 256);
     OhEngine::Stage *sg;
     { HostTimer t(e, OH_HT_UPLOAD_STAGE_WAIT);
-    sg = stage_acquire(e, copy_bytes);   /* a pinned buffer whose previous copy has completed */
+    sg = stage_acquire(e, direct ? own_bytes : copy_bytes);   /* a pinned buffer whose previous copy has completed */
     }
     df->sum_host = summary_block_get(e, sum_bytes, &df->sum_pooled);
     df->sum_bytes = sum_bytes;
@@ -1083,17 +1172,51 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", copy_bytes);
     }
     void *stage = sg->p;
-    { HostTimer t(e, OH_HT_UPLOAD_MEMCPY);
-    for (int i = 0; i < ns; i++)
-        if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes) {
-            if (seg[i].pack_n) pack_bs((uint8_t *)stage + seg[i].off, (const uint8_t *)seg[i].src, seg[i].pack_n);
-            else memcpy((char *)stage + seg[i].off, seg[i].src, seg[i].bytes);
-        }
-    }
-    /* asynchronous: the caller's arrays are already copied out; the pinned buffer stays busy until `done` */
-    HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
     hipStream_t cs = e->copy_stream;
-    hipError_t hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, cs);
+    hipError_t hrc = hipSuccess;
+    if (direct) {
+        /* the two segments made here go through the staging buffer (they lie side by side at the head of the arena: one copy),
+         * every other one straight from the caller's pinned memory */
+        { HostTimer t(e, OH_HT_UPLOAD_MEMCPY);
+        memcpy((char *)stage + seg[s_hdr].off, seg[s_hdr].src, seg[s_hdr].bytes);
+        }
+        HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
+        hrc = hipMemcpyAsync(df->arena, stage, align_up(sizeof(DevFrame), 256), hipMemcpyHostToDevice, cs);
+        if (hrc == hipSuccess && seg[s_puoff].bytes) {
+            memcpy((char *)stage + align_up(sizeof(DevFrame), 256), seg[s_puoff].src, seg[s_puoff].bytes);
+            hrc = hipMemcpyAsync((char *)df->arena + seg[s_puoff].off, (char *)stage + align_up(sizeof(DevFrame), 256), seg[s_puoff].bytes, hipMemcpyHostToDevice, cs);
+        }
+        for (int i = 0; i < ns && hrc == hipSuccess; i++)
+            if (i != s_hdr && i != s_puoff && seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
+                hrc = hipMemcpyAsync((char *)df->arena + seg[i].off, seg[i].src, seg[i].bytes, hipMemcpyHostToDevice, cs);
+    } else {
+        { HostTimer t(e, OH_HT_UPLOAD_MEMCPY);
+        if (!e->copiers) {
+            static const char *cenv = getenv("OHEVC_COPY_THREADS");
+            e->copiers = new CopyPool();
+            e->copiers->start(cenv ? std::max(0, std::min(atoi(cenv), 8)) : 2);
+        }
+        /* pieces of at most 128 KB, dealt round-robin to the calling thread and the helpers */
+        std::vector<CopyJob> &jobs = e->copy_jobs;
+        jobs.clear();
+        const size_t piece = 128 * 1024;
+        for (int i = 0; i < ns; i++)
+            if (seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes) {
+                if (seg[i].pack_n) {                                      /* four source bytes per byte: pieces of 4 x 128 KB strengths */
+                    for (size_t o = 0; o < seg[i].pack_n; o += 4 * piece)
+                        jobs.push_back({ (char *)stage + seg[i].off + o / 4, (const char *)seg[i].src + o, std::min(4 * piece, seg[i].pack_n - o), true });
+                } else {
+                    for (size_t o = 0; o < seg[i].bytes; o += piece)
+                        jobs.push_back({ (char *)stage + seg[i].off + o, (const char *)seg[i].src + o, std::min(piece, seg[i].bytes - o), false });
+                }
+            }
+        e->copiers->run(jobs);
+        }
+        /* asynchronous: the caller's arrays are already copied out; the pinned buffer stays busy until `done` */
+        HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
+        hrc = hipMemcpyAsync(df->arena, stage, copy_bytes, hipMemcpyHostToDevice, cs);
+    }
+    HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
     if (hrc == hipSuccess)
         hrc = hipEventRecord(sg->done, cs);
     sg->busy = hrc == hipSuccess;
@@ -1403,11 +1526,15 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
                     else HIPCHK(e, hipEventCreate(pe));
                 }
             }
+            uint32_t *tk = e->tickets + (size_t)OhEngine::TICKET_WORDS * (e->ticket_seq++ % OhEngine::TICKET_RING);
             if (nd || nsd)
-                ohk_intra_dag_reset(&all, nb, max_ictu_all, st);
+                ohk_intra_dag_reset(&all, nb, max_ictu_all, tk, st);
             if (a) HIPCHK(e, hipEventRecord(a, st));
+            /* persistent workers: as many as the chip holds at once (OHEVC_INTRA_WORKERS scales it: experiments) */
+            static const char *wkenv = getenv("OHEVC_INTRA_WORKERS");
+            const double wk_scale = wkenv ? atof(wkenv) : 1.0;
             if (nd)
-                ohk_intra_direct(&bd, nd, p, max_ictu_d, e->spin_limit, st);
+                ohk_intra_direct(&bd, nd, p, max_ictu_d, (uint32_t)std::max(1.0, wk_scale * 32.0 * e->n_cu), tk, e->spin_limit, st);
             if (nsd) {
                 OhIntraLaunch IL;
                 /* residual spans in LDS only while the chip holds the whole launch (a picture alone); else the blocks fetch theirs a sub-level ahead */
@@ -1426,7 +1553,8 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
                 IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)(IL.staged ? max_res : 0) * sizeof(int16_t), 16);
                 IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
                 IL.lds_bytes = (uint32_t)off;
-                ohk_intra_dag(&bs, nsd, p, &IL, max_ictu_s, e->spin_limit, st);
+                const uint32_t by_lds = std::max<uint32_t>(1u, (160u * 1024u) / std::max<uint32_t>(IL.lds_bytes, 1024u)), by_waves = std::max<uint32_t>(1u, 24u / IL.waves);
+                ohk_intra_dag(&bs, nsd, p, &IL, max_ictu_s, (uint32_t)std::max(1.0, wk_scale * std::min(by_lds, by_waves) * e->n_cu), tk + OH_MAX_BATCH * 32, e->spin_limit, st);
             }
             if (b) {
                 HIPCHK(e, hipEventRecord(b, st));

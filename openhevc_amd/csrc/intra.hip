@@ -26,6 +26,7 @@
  * trip.  CTUs of one launch are mutually independent (same wavefront level, recorder.c).
  * ======================================================================================= */
 #define INTRA_MAX_WAVES 8
+#define OH_TICKET_STRIDE 32u                       /* words between ticket counters: a cache line each */
 /* diagnostic build (-DOH_STAMPS, tools/intra_stamps.py): in-kernel cycle accounting of workgroup 0 */
 #ifdef OH_STAMPS
 #define STAMP(var) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; } while (0)
@@ -878,22 +879,33 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
 
 
 /* =========================================================================================
- * The whole picture's intra pass in ONE launch, staged form: a workgroup per schedule entry (CTU), id = entry x pictures + picture,
- * so the dispatcher hands the entries out in schedule order (level by level) interleaved over the pictures of the batch; an entry
- * stages its descriptors, waits for the entries it depends on (ctu_wait[]), and runs the same body as a level launch.  A wait only
- * ever points at a LOWER workgroup id, which has been dispatched before: no level launches, no launch as long as its slowest CTU,
- * an I picture costs its dependency chain at the CTUs' own lengths (what intra_rows_kernel gives, without holding a workgroup
- * slot per CTU row) and a B picture's handful of levels overlap.
+ * The whole picture's intra pass in ONE launch, staged form: a workgroup per schedule entry.  A workgroup does not take the entry of
+ * its blockIdx: when it STARTS it draws a ticket from a counter (atomicAdd): ticket t = schedule entry t / pictures of picture
+ * t % pictures, i.e. the entries in schedule order (level by level) interleaved over the pictures of the batch.  It stages its
+ * entry's descriptors, waits for the entries it depends on (ctu_wait[]: lower tickets), and runs the same body as a level launch.
+ * A ticket is only ever held by a workgroup that is RUNNING, and a wait only points at lower tickets — drawn earlier, by running
+ * workgroups, or finished — so the lowest unfinished ticket never waits: progress depends neither on the order in which the hardware
+ * dispatches workgroups nor on what other streams' kernels hold on the chip.  (With entry = blockIdx two such launches on two
+ * streams deadlocked: each filled the CUs the other's not-yet-dispatched low ids needed — seen with six streams.  Persistent
+ * workgroups looping over tickets are as safe but keep their CUs until the queue is empty: the other streams' kernels, which fill
+ * the gaps of this latency-bound pass, lost more than the loop saved.)  No level launches, no launch as long as its slowest CTU: an
+ * I picture costs its dependency chain at the CTUs' own lengths and a B picture's handful of levels overlap.
  * ======================================================================================= */
 template <typename PX, bool CIP, bool STAGED>
-__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void intra_dag_kernel(const OhBatch B, const OhIntraLaunch L, const int n_pics, const uint32_t spin_limit)
+__global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void intra_dag_kernel(const OhBatch B, const OhIntraLaunch L, const int n_pics, const uint32_t total, uint32_t *__restrict__ ticket, const uint32_t spin_limit)
 {
-    const uint32_t k = blockIdx.x / (uint32_t)n_pics;
-    const DevFrame *__restrict__ f = B.f[blockIdx.x - k * (uint32_t)n_pics];
-    if (k >= f->n_ictu)
-        return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    intra_ctu_body<PX, CIP, STAGED, true>(f, L, k, smem, spin_limit);
+    __shared__ uint32_t s_ticket;
+    /* a counter per picture (waits never cross pictures), each on a cache line of its own: one word takes ~88 atomics per
+     * microsecond, a B-picture batch draws 24 k tickets */
+    const uint32_t pic = blockIdx.x % (uint32_t)n_pics;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket + OH_TICKET_STRIDE * pic, 1u);
+    __syncthreads();
+    const uint32_t k = s_ticket;
+    const DevFrame *__restrict__ f = B.f[pic];
+    (void)total;
+    if (k < f->n_ictu)
+        intra_ctu_body<PX, CIP, STAGED, true>(f, L, k, smem, spin_limit);
 }
 
 /* =========================================================================================
@@ -907,18 +919,22 @@ __global__ __launch_bounds__(64 * INTRA_MAX_WAVES) __attribute__((amdgpu_waves_p
  * the rectangles and ran 5 workgroups per CU: profiles/r02_intra_staging_experiment.txt).  Hand-off between entries as above.
  * ======================================================================================= */
 template <typename PX, bool CIP>
-__global__ __launch_bounds__(64) void intra_direct_kernel(const OhBatch B, const int n_pics, const uint32_t spin_limit, const int exp)
+__global__ __launch_bounds__(64) void intra_direct_kernel(const OhBatch B, const int n_pics, const uint32_t total, uint32_t *__restrict__ ticket, const uint32_t spin_limit, const int exp)
 {
     /* per wave: the edge arrays, and a window of 64 block descriptors (a wave reads its entry's lists front to back: tables and
      * descriptors arrive 64 at a time, so a pass waits for ONE round trip to HBM — its samples and residual — not for four) */
     __shared__ IntraLds edges;
     __shared__ __attribute__((aligned(16))) DevIntra items_l[64];
-    const uint32_t pos = blockIdx.x / (uint32_t)n_pics;
-    const DevFrame *__restrict__ f = B.f[blockIdx.x - pos * (uint32_t)n_pics];
+    const int lane = threadIdx.x;
+    const uint32_t pic = blockIdx.x % (uint32_t)n_pics;     /* the entry is the ticket the wave draws when it starts (see intra_dag_kernel) */
+    uint32_t pos = 0;
+    if (lane == 0) pos = atomicAdd(ticket + OH_TICKET_STRIDE * pic, 1u);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    const DevFrame *__restrict__ f = B.f[pic];
+    (void)total;
     if (pos >= f->n_ictu)
         return;
     const uint32_t k = (exp & 4) ? pos : G_CONST(uint32_t, f->ctu_order)[pos];      /* chains first (prep_intra_order) */
-    const int lane = threadIdx.x;
     const DevIntraCtu ctu = gload(f->ictu + k);
     const uint32_t aux = __builtin_amdgcn_readfirstlane(G_CONST(uint32_t, f->ctu_aux)[k]);
     const GLOBAL uint32_t *__restrict__ ss = G_CONST(uint32_t, f->sub_start) + ctu.sub_first;
@@ -971,11 +987,12 @@ __global__ __launch_bounds__(64) void intra_direct_kernel(const OhBatch B, const
 }
 
 /* ctu_done[] of every picture of the batch back to zero: a work list may be executed more than once */
-__global__ __launch_bounds__(256) void intra_dag_reset_kernel(const OhBatch B)
+__global__ __launch_bounds__(256) void intra_dag_reset_kernel(const OhBatch B, uint32_t *__restrict__ tickets)
 {
     const DevFrame *__restrict__ f = B.f[blockIdx.y];
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < f->n_ictu) f->ctu_done[k] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 2) tickets[(threadIdx.x * OH_MAX_BATCH + blockIdx.y) * OH_TICKET_STRIDE] = 0u;      /* counter blockIdx.y of the wave-per-CTU launch / of the staged launch */
 }
 
 /* =========================================================================================
@@ -1075,18 +1092,21 @@ int ohk_init_intra(void)
 }
 
 /* ctu_done[] cleared for the n pictures of B (max_ictu: the largest schedule among them) */
-extern "C" void ohk_intra_dag_reset(const OhBatch *B, int n, uint32_t max_ictu, hipStream_t st)
+extern "C" void ohk_intra_dag_reset(const OhBatch *B, int n, uint32_t max_ictu, uint32_t *tickets, hipStream_t st)
 {
     if (n <= 0 || !max_ictu) return;
-    hipLaunchKernelGGL(intra_dag_reset_kernel, dim3((max_ictu + 255) / 256, n), dim3(256), 0, st, *B);
+    hipLaunchKernelGGL(intra_dag_reset_kernel, dim3((max_ictu + 255) / 256, n), dim3(256), 0, st, *B, tickets);
 }
 
 /* n pictures, each one's whole schedule, staged form: l = the LDS carve-up that fits every CTU of all of them (l->level unused) */
-extern "C" void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ictu, uint32_t spin_limit, hipStream_t st)
+extern "C" void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ictu, uint32_t workers, uint32_t *ticket,
+                              uint32_t spin_limit, hipStream_t st)
 {
     if (n <= 0 || !max_ictu) return;
-    dim3 g(max_ictu * (uint32_t)n), b(64 * l->waves);
-#define DAG_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_dag_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l, n, spin_limit)
+    const uint32_t total = max_ictu * (uint32_t)n;
+    (void)workers;
+    dim3 g(total), b(64 * l->waves);
+#define DAG_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_dag_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l, n, total, ticket, spin_limit)
 #define DAG_BY_FLAGS(PX)                                                                       \
     do {                                                                                       \
         if (p->constrained_intra_pred) { if (l->staged) DAG_LAUNCH(PX, true, true); else DAG_LAUNCH(PX, true, false); }   \
@@ -1098,13 +1118,15 @@ extern "C" void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, con
 }
 
 /* n pictures, each one's whole schedule, a wave per CTU straight on the picture in HBM */
-extern "C" void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_ictu, uint32_t spin_limit, hipStream_t st)
+extern "C" void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_ictu, uint32_t workers, uint32_t *ticket, uint32_t spin_limit, hipStream_t st)
 {
     if (n <= 0 || !max_ictu) return;
-    dim3 g(max_ictu * (uint32_t)n), b(64);
+    const uint32_t total = max_ictu * (uint32_t)n;
+    (void)workers;
+    dim3 g(total), b(64);
     static const char *xenv = getenv("OHEVC_EXP");           /* experiments only: 1 no waits, 2 no publishing (wrong pictures) */
     const int exp = xenv ? atoi(xenv) : 0;
-#define DIRECT_LAUNCH(PX, CIP) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_direct_kernel<PX, CIP>), g, b, 0, st, *B, n, spin_limit, exp)
+#define DIRECT_LAUNCH(PX, CIP) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_direct_kernel<PX, CIP>), g, b, 0, st, *B, n, total, ticket, spin_limit, exp)
     if (p->bit_depth == 8) { if (p->constrained_intra_pred) DIRECT_LAUNCH(uint8_t, true); else DIRECT_LAUNCH(uint8_t, false); }
     else                   { if (p->constrained_intra_pred) DIRECT_LAUNCH(uint16_t, true); else DIRECT_LAUNCH(uint16_t, false); }
 #undef DIRECT_LAUNCH

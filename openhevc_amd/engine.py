@@ -76,6 +76,10 @@ def lib():
         L.oh_engine_upload_bytes.restype = C.c_uint64
         L.oh_engine_stream.argtypes = [V]
         L.oh_engine_stream.restype = V
+        L.oh_host_alloc.argtypes = [C.c_size_t]
+        L.oh_host_alloc.restype = V
+        L.oh_host_free.argtypes = [V]
+        L.oh_host_free.restype = None
         L.oh_pic_device_planes.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         _lib = L
     return _lib

@@ -76,8 +76,11 @@ class OhFrame(C.Structure):
         ("deblock", C.POINTER(OhDeblockCtb)), ("sao", C.POINTER(OhSaoCtb)), ("is_intra", C.POINTER(C.c_uint8)),
         ("n_sparse", C.c_uint32), ("sparse", C.POINTER(C.c_uint32)), ("tu_sparse", C.POINTER(C.c_uint32)),
         ("scaling", C.c_void_p), ("tu_cross", C.POINTER(C.c_uint32)), ("bs_in", C.c_void_p),
-        ("sao_pending", C.POINTER(C.c_uint8)),
+        ("sao_pending", C.POINTER(C.c_uint8)), ("flags", C.c_uint32),
     ]
+
+
+OH_FRAME_PINNED, OH_FRAME_BS_PACKED = 1, 2                  # OhFrame.flags (include/ohevc_frame.h)
 
 
 def bs_size(p):
@@ -318,18 +321,36 @@ class FrameCopy:
     """Deep copy of a finished work list: every array the OhFrame points at is copied into memory this object owns, so the
     list outlives the recorder's next picture.  `.frame` is an OhFrame over the copies (cur_pic / ref_pics as recorded)."""
 
-    def __init__(self, f):
+    def __init__(self, f, pinned_by=None):
+        """pinned_by: the engine library (ctypes handle with oh_host_alloc / oh_host_free): every array is copied into page-locked memory
+        from oh_host_alloc and the boundary-strength grids are packed four to the byte (oh_pack_bs), i.e. the list is what a recorder
+        that writes into blocks lent by the engine hands over: OhFrame.flags = OH_FRAME_PINNED | OH_FRAME_BS_PACKED, the engine
+        copies it to the GPU by DMA from where it lies."""
         p = f.p
         self.keep = []
+        self._pinned, self._lib = [], pinned_by
         g = OhFrame()
         C.memmove(C.byref(g), C.byref(f), C.sizeof(OhFrame))
 
-        def dup(ptr, nbytes, ctype):
+        def dup(ptr, nbytes, ctype, data=None):
             if not ptr or nbytes == 0:
                 return C.cast(None, C.POINTER(ctype))
-            buf = np.frombuffer(C.string_at(ptr, int(nbytes)), dtype=np.uint8).copy()
-            self.keep.append(buf)
-            return C.cast(buf.ctypes.data, C.POINTER(ctype))
+            src = data if data is not None else np.frombuffer(C.string_at(ptr, int(nbytes)), dtype=np.uint8)
+            if pinned_by is None:
+                buf = src.copy()
+                self.keep.append(buf)
+                return C.cast(buf.ctypes.data, C.POINTER(ctype))
+            mem = pinned_by.oh_host_alloc(C.c_size_t(len(src)))
+            if not mem:
+                raise MemoryError("oh_host_alloc")
+            self._pinned.append((mem, len(src)))
+            C.memmove(mem, src.ctypes.data, len(src))
+            return C.cast(mem, C.POINTER(ctype))
+
+        def packed(ptr, n):                                    # oh_pack_bs: entry i in bits 2 (i & 3) of byte i >> 2
+            a = np.frombuffer(C.string_at(ptr, int(n)), dtype=np.uint8) & 3
+            a = np.concatenate([a, np.zeros((-len(a)) % 4, np.uint8)]).reshape(-1, 4)
+            return (a[:, 0] | a[:, 1] << 2 | a[:, 2] << 4 | a[:, 3] << 6).astype(np.uint8)
 
         hs, vs = hshift(p, 1), vshift(p, 1)
         n_ctb = ((p.width + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size) * ((p.height + (1 << p.log2_ctb_size) - 1) >> p.log2_ctb_size)
@@ -344,8 +365,14 @@ class FrameCopy:
         g.ictu = dup(f.ictu, f.n_ictu * C.sizeof(OhIntraCtu), OhIntraCtu)
         g.sub_start = dup(f.sub_start, (f.n_sub + 1) * 4 if f.n_intra else 0, C.c_uint32)
         g.level_start = dup(f.level_start, (f.n_levels + 1) * 4 if f.n_intra else 0, C.c_uint32)
-        g.vertical_bs = dup(f.vertical_bs, f.bs_size, C.c_uint8)
-        g.horizontal_bs = dup(f.horizontal_bs, f.bs_size, C.c_uint8)
+        if pinned_by is not None and f.vertical_bs and f.horizontal_bs and not (f.flags & OH_FRAME_BS_PACKED):
+            g.vertical_bs = dup(f.vertical_bs, f.bs_size, C.c_uint8, packed(f.vertical_bs, f.bs_size))
+            g.horizontal_bs = dup(f.horizontal_bs, f.bs_size, C.c_uint8, packed(f.horizontal_bs, f.bs_size))
+            g.flags |= OH_FRAME_BS_PACKED
+        else:
+            nb = (f.bs_size + 3) // 4 if f.flags & OH_FRAME_BS_PACKED else f.bs_size
+            g.vertical_bs = dup(f.vertical_bs, nb, C.c_uint8)
+            g.horizontal_bs = dup(f.horizontal_bs, nb, C.c_uint8)
         g.qp_y_tab = dup(f.qp_y_tab, n_qp, C.c_int8)
         g.is_pcm = dup(f.is_pcm, n_pu, C.c_uint8)
         g.deblock = dup(f.deblock, n_ctb * C.sizeof(OhDeblockCtb), OhDeblockCtb)
@@ -356,21 +383,27 @@ class FrameCopy:
         g.tu_cross = dup(f.tu_cross, f.n_tu * 4, C.c_uint32)
         g.sao_pending = dup(f.sao_pending, n_ctb, C.c_uint8)
         if f.scaling:
-            buf = np.frombuffer(C.string_at(f.scaling, 4 * 6 * 64 + 12), dtype=np.uint8).copy()
-            self.keep.append(buf)
-            g.scaling = buf.ctypes.data
+            g.scaling = C.cast(dup(f.scaling, 4 * 6 * 64 + 12, C.c_uint8), C.c_void_p).value
         if f.bs_in:
             src = C.cast(f.bs_in, C.POINTER(OhBsInputs)).contents
             bi = OhBsInputs()
             for name, n in (("mvf", n_pu * C.sizeof(OhMvField)), ("cbf_luma", n_tb), ("call_log2", n_tb), ("ctb_flags", n_ctb)):
-                buf = np.frombuffer(C.string_at(getattr(src, name), int(n)), dtype=np.uint8).copy()
-                self.keep.append(buf)
-                setattr(bi, name, buf.ctypes.data)
+                setattr(bi, name, C.cast(dup(getattr(src, name), int(n), C.c_uint8), C.c_void_p).value)
             bi.loop_filter_across_tiles = src.loop_filter_across_tiles
             self.keep.append(bi)
             g.bs_in = C.addressof(bi)
+        if pinned_by is not None:
+            g.flags |= OH_FRAME_PINNED
         self.frame = g
-        self.bytes = sum(b.nbytes for b in self.keep if isinstance(b, np.ndarray))
+        self.bytes = sum(b.nbytes for b in self.keep if isinstance(b, np.ndarray)) + sum(n for _, n in self._pinned)
+
+    def __del__(self):
+        for mem, _ in getattr(self, "_pinned", []):
+            try:
+                self._lib.oh_host_free(C.c_void_p(mem))
+            except Exception:      # noqa: BLE001 - interpreter shutdown
+                pass
+        self._pinned = []
 
     def with_ids(self, cur_pic, ref_pics):
         """header copy whose picture ids are replaced (the arrays are shared)"""

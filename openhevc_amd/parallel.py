@@ -434,9 +434,11 @@ class PictureStore:
         return out + [p.name for p in self.plan.tail]
 
 
-def host_work_lists(params, plan, knobs=None):
+def host_work_lists(params, plan, knobs=None, pinned_by=None):
     """The host side of one GOP: {picture name: frame.FrameCopy} + {name: stats}.  What the reference's CTU loop would have recorded
-    (here: the synthetic generator); picture ids are placeholders, EngineBackend binds them to its own pictures."""
+    (here: the synthetic generator); picture ids are placeholders, EngineBackend binds them to its own pictures.
+    pinned_by: the engine library — the lists are held in page-locked memory from oh_host_alloc, boundary strengths packed, and
+    handed over by DMA (frame.FrameCopy)."""
     from . import frame as F
     knobs = dict(default_synth_knobs(), **(knobs or {}))
     rec = F.Recorder(params)
@@ -445,7 +447,7 @@ def host_work_lists(params, plan, knobs=None):
         sp = F.synth_params(pic.slice_type, pic.seed, n_refs=max(len(pic.refs), 0), **knobs)
         f = rec.synth(sp, 0, list(range(1, 1 + len(pic.refs))))
         stats[pic.name] = frame_stats(f)
-        lists[pic.name] = F.FrameCopy(f)
+        lists[pic.name] = F.FrameCopy(f, pinned_by=pinned_by)
     rec.close()
     return lists, stats
 

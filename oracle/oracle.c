@@ -735,6 +735,21 @@ int oh_or_frame(const OhFrame *f, OhHostPic *pics)
         g.vertical_bs = v; g.horizontal_bs = h; g.bs_size = oh_bs_size(&f->p);
         if (!r) r = oh_or_pass_deblock(&g, pics);
         free(v); free(h);
+    } else if (!r && (f->flags & OH_FRAME_BS_PACKED) && f->p.deblock_enabled && f->vertical_bs && f->horizontal_bs) {
+        /* the grids travel four strengths to the byte (OhFrame.flags): back to the reference's byte grids for the pass */
+        OhFrame g = *f;
+        const size_t n = f->bs_size;
+        uint8_t *v = (uint8_t *)malloc(n ? n : 1), *h = (uint8_t *)malloc(n ? n : 1);
+        if (v && h) {
+            for (size_t i = 0; i < n; i++) {
+                v[i] = (uint8_t)(f->vertical_bs[i >> 2] >> (2 * (i & 3)) & 3);
+                h[i] = (uint8_t)(f->horizontal_bs[i >> 2] >> (2 * (i & 3)) & 3);
+            }
+            g.vertical_bs = v; g.horizontal_bs = h;
+            r = oh_or_pass_deblock(&g, pics);
+        } else
+            r = -1;
+        free(v); free(h);
     } else if (!r) r = oh_or_pass_deblock(f, pics);
     if (!r) r = oh_or_pass_sao(f, pics);
     free(c);

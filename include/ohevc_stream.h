@@ -10,7 +10,8 @@
  * from the syntax, which is the point — the reference decoder (oracle/_ref, built from /root/reference) decodes these
  * streams and is the checker for everything downstream of entropy decoding (tests/test_streams.py).
  *
- * Scope: Main / Main 10 (4:2:0) and the 4:4:4 range-extension profile incl. cross-component prediction, 8 or 10 bit, one layer.  Written from the H.265 syntax (7.3) and CABAC (9.3) clauses.
+ * Scope: Main / Main 10 (4:2:0) and the 4:4:4 range-extension profile incl. cross-component prediction, 8 or 10 bit; one layer, or two (SHVC
+ * spatial scalability: shvc_el_width / shvc_el_height).  Written from the H.265 syntax (7.3) and CABAC (9.3) clauses.
  */
 #ifndef OHEVC_STREAM_H
 #define OHEVC_STREAM_H
@@ -71,6 +72,10 @@ typedef struct OhStreamParams {
     int32_t sao_offset_scale_luma, sao_offset_scale_chroma;   /* log2_sao_offset_scale_* of the pps_range_extension: 0 .. bit_depth - 10 (so: 12 bit only) */
     int32_t log2_min_cb_size;           /* 0 (= 3) or 3..5: smallest coding block (width and height are multiples of it); above 8x8 its inter
                                            partitions include NxN, its min PU / QP / PCM map granularity follows */
+    int32_t shvc_el_width, shvc_el_height;   /* > 0: a TWO-LAYER stream (SHVC spatial scalability, the SHM 4.1 syntax the reference parses): this stream is
+                                           the base layer (8 bit 4:2:0, no window, not gop 3), every access unit also carries an enhancement-layer
+                                           picture of this size (>= the base layer's: x1 = SNR, x1.5, x2 or any ratio) whose P slices predict from the
+                                           up-sampled base-layer picture only (zero motion vectors), plus intra blocks and residuals */
 } OhStreamParams;
 
 /* syntax elements of the slice data as (id, value) pairs in coding order — the writer's side of tests/test_streams.py; the ids are

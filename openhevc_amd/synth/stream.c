@@ -29,6 +29,13 @@ static void put_bit(Bits *b, int v)
     if (v) b->buf[b->n >> 3] |= (uint8_t)(0x80 >> (b->n & 7));
     b->n++;
 }
+static void bits_drain(Bits *to, Bits *from)           /* appends the (byte-aligned) content of `from` to `to` and empties it */
+{
+    const size_t nb = from->n / 8;
+    for (size_t k = 0; k < nb; k++) { bits_reserve(to, 8); to->buf[to->n >> 3] = from->buf[k]; to->n += 8; }
+    if (from->buf) memset(from->buf, 0, nb + 1 <= from->cap ? nb + 1 : from->cap);
+    from->n = 0;
+}
 static void put_bits(Bits *b, uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) put_bit(b, (v >> i) & 1); }
 static void put_ue(Bits *b, uint32_t v)
 {
@@ -43,12 +50,13 @@ static void byte_align_zero(Bits *b) { while (b->n & 7) put_bit(b, 0); }
 static void rbsp_trailing(Bits *b) { put_bit(b, 1); byte_align_zero(b); }
 
 /* one NAL unit: start code, two header bytes, payload with emulation prevention (7.4.2) */
+static int g_layer;                                     /* nuh_layer_id of the NAL units being written (two-layer streams: 0 base, 1 enhancement) */
 static void emit_nal(Bits *out, int type, const uint8_t *rbsp, size_t n)
 {
     byte_align_zero(out);
     put_bits(out, 0, 24); put_bits(out, 1, 8);
-    put_bits(out, (uint32_t)(type << 1), 8);           /* forbidden_zero_bit, nal_unit_type, nuh_layer_id high bit */
-    put_bits(out, 1, 8);                               /* nuh_layer_id low bits, nuh_temporal_id_plus1 = 1 */
+    put_bits(out, (uint32_t)(type << 1) | (uint32_t)(g_layer >> 5), 8);   /* forbidden_zero_bit, nal_unit_type, nuh_layer_id high bit */
+    put_bits(out, (uint32_t)((g_layer & 31) << 3) | 1u, 8);               /* nuh_layer_id low bits, nuh_temporal_id_plus1 = 1 */
     int zeros = 0;
     for (size_t i = 0; i < n; i++) {
         if (zeros >= 2 && rbsp[i] <= 3) { put_bits(out, 3, 8); zeros = 0; }
@@ -267,6 +275,8 @@ typedef struct W {
     int cross_pf, res_scale;                           /* cross-component prediction of the chroma block being coded */
     int tt_pu;                                         /* transform tree: index of the depth-1 block being coded = the partition of an intra NxN coding block */
     int stat_coeff[4];                                 /* StatCoeff (9.3.3.11): reset with the contexts */
+    int el;                                            /* enhancement layer of a two-layer stream: parameter-set ids 1, inter-layer prediction only */
+    int bl_w, bl_h;                                    /* two-layer stream: the base layer's size (VPS rep_format 0) */
     uint8_t wpp_ctx[N_CTX]; int have_wpp;              /* the context states after the second CTB of the last row that had two (wavefront synchronisation) */
     /* SAO parameters of the CTBs (for merge candidates we only need to know that they exist) */
 } W;
@@ -310,6 +320,64 @@ static void write_ptl(Bits *b, const OhStreamParams *p)
     put_bits(b, 186, 8);                                                                  /* level 6.2 */
 }
 
+/* The video parameter set of a TWO-LAYER (SHVC spatial scalability) stream, in the syntax the reference parses (hevc_ps.c:714-1097:
+ * the SHM 4.1 draft its decoder was written against — not the final annex F): base layer 0, enhancement layer 1 directly dependent on
+ * it (sample and motion prediction), one layer set with both, representation formats in the VPS (the EL's SPS carries neither size
+ * nor bit depth: update_rep_format_flag 0).  Every value is the plainest the syntax allows; the comments name the element read at
+ * each step of parse_vps_extension. */
+static void write_vps_two_layers(W *w, int el_w, int el_h)
+{
+    const OhStreamParams *p = w->p;
+    Bits b = { 0 };
+    put_bits(&b, 0, 4); put_bits(&b, 3, 2); put_bits(&b, 1, 6); put_bits(&b, 0, 3); put_bit(&b, 1); put_bits(&b, 0xffff, 16);   /* id, reserved, max_layers_minus1 = 1, sub-layers, nesting, extension offset */
+    write_ptl(&b, p);
+    put_bit(&b, 1);                                        /* sub_layer_ordering_info_present */
+    put_ue(&b, (uint32_t)p->n_refs + 1); put_ue(&b, 0); put_ue(&b, 0);
+    put_bits(&b, 1, 6); put_ue(&b, 1);                     /* vps_max_layer_id = 1, vps_num_layer_sets_minus1 = 1 */
+    put_bit(&b, 1); put_bit(&b, 1);                        /* layer_id_included_flag[1][0..1] */
+    put_bit(&b, 0);                                        /* timing info */
+    put_bit(&b, 1);                                        /* vps_extension_flag */
+    while (b.n & 7) put_bit(&b, 1);                        /* vps_extension_alignment_bit_equal_to_one */
+    /* ---- vps_extension ---- */
+    put_bit(&b, 0); put_bit(&b, 0);                        /* avc_base_layer_flag, splitting_flag */
+    for (int i = 0; i < 16; i++) put_bit(&b, i == 2);      /* scalability_mask: bit 2 = spatial / quality scalability (SCALABILITY_ID, hevc.h:133-137) */
+    put_bits(&b, 0, 3);                                    /* dimension_id_len_minus1[0]: one bit */
+    put_bit(&b, 0);                                        /* vps_nuh_layer_id_present_flag: layer_id_in_nuh[1] = 1 */
+    put_bit(&b, 1);                                        /* dimension_id[1][0] = 1 */
+    put_bits(&b, 0, 4);                                    /* view_id_len_minus1 */
+    put_bit(&b, 0);                                        /* view_id_val[0] (the parser counts one view) */
+    put_bit(&b, 1);                                        /* direct_dependency_flag[1][0] */
+    put_bit(&b, 0);                                        /* vps_sub_layers_max_minus1_present_flag */
+    put_bit(&b, 0);                                        /* max_tid_ref_present_flag */
+    put_bit(&b, 1);                                        /* all_ref_layers_active_flag */
+    put_bits(&b, 1, 10);                                   /* vps_number_layer_sets_minus1 (must equal vps_num_layer_sets - 1) */
+    put_bits(&b, 0, 6);                                    /* vps_num_profile_tier_level_minus1 */
+    put_bit(&b, 0);                                        /* more_output_layer_sets_than_default_flag */
+    put_bit(&b, 1);                                        /* default_one_target_output_layer_flag (numOutputLayerSets = 2 > 1) */
+    put_bit(&b, 0);                                        /* profile_level_tier_idx[1]: one bit */
+    put_bit(&b, 0);                                        /* alt_output_layer_flag */
+    put_bit(&b, 0);                                        /* rep_format_idx_present_flag: a format per layer, vps_rep_format_idx[i] = i */
+    for (int l = 0; l < 2; l++) {                          /* rep_format(): hevc_ps.c:411-467 */
+        put_bit(&b, 1);                                    /* chroma_and_bit_depth_vps_present_flag */
+        put_bits(&b, (uint32_t)(l ? el_w : p->width), 16); put_bits(&b, (uint32_t)(l ? el_h : p->height), 16);
+        put_bits(&b, 1, 2);                                /* chroma_format_idc 4:2:0 */
+        put_bits(&b, (uint32_t)p->bit_depth - 8, 4); put_bits(&b, (uint32_t)p->bit_depth - 8, 4);
+    }
+    put_bit(&b, 1);                                        /* max_one_active_ref_layer_flag */
+    /* poc_lsb_not_present_flag: only for layers without a reference layer — none */
+    put_bit(&b, 0);                                        /* cross_layer_phase_alignment_flag: zero-position-aligned */
+    put_bit(&b, 0);                                        /* sub_layer_flag_info_present_flag[1] */
+    put_ue(&b, (uint32_t)p->n_refs + 1);                   /* max_vps_dec_pic_buffering_minus1[1][0][0] (one sub-DPB) */
+    put_ue(&b, 0); put_ue(&b, 0);                          /* max_vps_num_reorder_pics, max_vps_latency_increase_plus1 */
+    put_ue(&b, 0);                                         /* direct_dep_type_len_minus2 */
+    put_bit(&b, 1); put_bits(&b, 2, 2);                    /* default_direct_dependency_type_flag, type 2: samples and motion */
+    put_bit(&b, 0); put_bit(&b, 0);                        /* single_layer_for_non_irap_flag, higher_layer_irap_skip_flag */
+    put_bit(&b, 0);                                        /* vps_vui_present_flag */
+    rbsp_trailing(&b);
+    emit_nal(&w->out, 32, b.buf, b.n / 8);
+    free(b.buf);
+}
+
 static void write_vps(W *w)
 {
     Bits b = { 0 };
@@ -329,12 +397,20 @@ static void write_sps(W *w)
 {
     const OhStreamParams *p = w->p;
     Bits b = { 0 };
+    if (w->el) {
+        /* the sequence parameter set of the enhancement layer (hevc_ps.c:1520-1760 with nuh_layer_id > 0): no sub-layer count, no
+         * profile / tier / level, no size, no bit depth — the representation format comes from the VPS */
+        put_bits(&b, 0, 4);                                /* vps id */
+        put_ue(&b, 1);                                     /* sps id 1 (the decoder of layer 1 looks for the base layer's SPS at id 0, hevc.c:453) */
+        put_bit(&b, 0);                                    /* update_rep_format_flag */
+    } else {
     put_bits(&b, 0, 4); put_bits(&b, 0, 3); put_bit(&b, 1);                      /* vps id, max_sub_layers_minus1, temporal_id_nesting */
     write_ptl(&b, p);
     put_ue(&b, 0);                                         /* sps id */
     put_ue(&b, (uint32_t)p->chroma_format_idc);            /* 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 */
     if (p->chroma_format_idc == 3) put_bit(&b, 0);         /* separate_colour_plane_flag */
     put_ue(&b, (uint32_t)p->width); put_ue(&b, (uint32_t)p->height);
+    }
     {   /* conformance window, offsets in chroma sample units (4:2:0: two luma samples) */
         const int any = p->conf_win_left | p->conf_win_right | p->conf_win_top | p->conf_win_bottom;
         put_bit(&b, any != 0);
@@ -343,7 +419,7 @@ static void write_sps(W *w)
             put_ue(&b, (uint32_t)p->conf_win_top / 2); put_ue(&b, (uint32_t)p->conf_win_bottom / 2);
         }
     }
-    put_ue(&b, (uint32_t)p->bit_depth - 8); put_ue(&b, (uint32_t)p->bit_depth - 8);
+    if (!w->el) { put_ue(&b, (uint32_t)p->bit_depth - 8); put_ue(&b, (uint32_t)p->bit_depth - 8); }
     put_ue(&b, 4);                                         /* log2_max_poc_lsb = 8 */
     put_bit(&b, 1);
     put_ue(&b, (uint32_t)p->n_refs + 1); put_ue(&b, p->gop == 3 ? 2 : 0); put_ue(&b, 0);
@@ -417,7 +493,7 @@ static void write_pps(W *w)
 {
     const OhStreamParams *p = w->p;
     Bits b = { 0 };
-    put_ue(&b, 0); put_ue(&b, 0);
+    put_ue(&b, (uint32_t)w->el); put_ue(&b, (uint32_t)w->el);      /* pps id, sps id: 0 / 0, the enhancement layer's 1 / 1 */
     put_bit(&b, p->dependent_slices != 0);
     put_bit(&b, 0); put_bits(&b, 0, 3);                    /* output_flag_present, extra slice header bits */
     put_bit(&b, p->sign_data_hiding != 0);
@@ -883,6 +959,8 @@ static void code_mvd(W *w)
         v[k] = rnd(&w->g, 2 * r + 1) - r;
         if (rnd(&w->g, 50) == 0) v[k] = rnd(&w->g, 65536) - 32768;
         if (rnd(&w->g, 4) == 0) v[k] = 0;
+        if (w->el) v[k] = 0;                               /* inter-layer prediction: the motion vector into the up-sampled base-layer picture is zero (H.8.x; the
+                                                              reference up-samples the CTBs under the prediction block, hevc.c:2077-2097) */
         a[k] = abs(v[k]);
     }
     enc_bin(c, C_MVD_GT0, a[0] > 0); enc_bin(c, C_MVD_GT0, a[1] > 0);
@@ -1133,7 +1211,7 @@ static void write_slice_header(W *w, Bits *b, int nal_type, int first, int poc, 
     const Slice *sl = &w->sl;
     put_bit(b, first);
     if (nal_type >= 16 && nal_type <= 23) put_bit(b, 0);   /* no_output_of_prior_pics_flag */
-    put_ue(b, 0);                                          /* pps id */
+    put_ue(b, (uint32_t)w->el);                            /* pps id */
     if (!first) {
         if (p->dependent_slices) put_bit(b, sl->dependent);
         int len = 0;
@@ -1142,6 +1220,8 @@ static void write_slice_header(W *w, Bits *b, int nal_type, int first, int poc, 
     }
     if (!sl->dependent) {
         put_ue(b, (uint32_t)sl->type);
+        if (idr && w->el)
+            put_bits(b, (uint32_t)poc & 255, 8);           /* a picture of layer 1 carries pic_order_cnt_lsb even when it is an IDR picture (hevc.c:728) */
         if (!idr) {
             put_bits(b, (uint32_t)poc & 255, 8);
             put_bit(b, 0);                                 /* short_term_ref_pic_set_sps_flag: the set follows */
@@ -1157,6 +1237,7 @@ static void write_slice_header(W *w, Bits *b, int nal_type, int first, int poc, 
             for (int i = 0; i < np_; i++) { put_ue(b, (uint32_t)(pos[i] - prev - 1)); put_bit(b, 1); prev = pos[i]; }
             if (p->tmvp) put_bit(b, sl->tmvp);
         }
+        if (w->el) put_bit(b, 1);                          /* inter_layer_pred_enabled_flag: the one direct reference layer is active (hevc.c:806-828) */
         if (p->sao) { put_bit(b, sl->sao_luma); put_bit(b, sl->sao_chroma); }
         if (sl->type != SLICE_I) {
             put_bit(b, 1);                                 /* num_ref_idx_active_override_flag */
@@ -1371,6 +1452,50 @@ void oh_stream_defaults(OhStreamParams *p, int width, int height, uint64_t seed)
     p->pcm_pct = 8; p->bypass_pct = 8; p->tskip_pct = 25; p->sao_pct = 50; p->mvd_range = 64; p->coeff_density = 100;
 }
 
+/* the writer's state for one layer (one W per layer of a two-layer stream) */
+static int w_init(W *w, const OhStreamParams *p, int mcb_log2)
+{
+    memset(w, 0, sizeof(*w));
+    w->p = p;
+    g_trace_on = p->trace != 0; g_trace_n = 0;
+    g_lev_on = p->levels != 0 && !p->cu_qp_delta; g_lev_n = 0;
+    g_c444 = p->chroma_format_idc == 3;
+    g_cb_off = p->chroma_qp_offsets ? p->cb_qp_offset : 1; g_cr_off = p->chroma_qp_offsets ? p->cr_qp_offset : -2;
+    if (g_cb_off < -12 || g_cb_off > 12 || g_cr_off < -12 || g_cr_off > 12) return -1;
+    g_c422 = p->chroma_format_idc == 2;
+    w->g.s = p->seed * 0x2545F4914F6CDD1Dull + 77;
+    w->lc = p->log2_ctb_size; w->ctb = 1 << w->lc; w->min_cb_log2 = mcb_log2;
+    w->ctbw = (p->width + w->ctb - 1) >> w->lc; w->ctbh = (p->height + w->ctb - 1) >> w->lc; w->n_ctb = w->ctbw * w->ctbh;
+    w->tcols = p->tile_cols > 1 ? (p->tile_cols < w->ctbw ? p->tile_cols : w->ctbw) : 1;
+    w->trows = p->tile_rows > 1 ? (p->tile_rows < w->ctbh ? p->tile_rows : w->ctbh) : 1;
+    if (p->wpp && (w->tcols > 1 || w->trows > 1))
+        return -1;                                         /* both at once is legal in version 2 only; not produced */
+    w->pic.w4 = (p->width + 3) >> 2; w->pic.h4 = (p->height + 3) >> 2;
+    const size_t cells = (size_t)w->pic.w4 * w->pic.h4;
+    w->pic.skip = (uint8_t *)malloc(cells); w->pic.depth = (uint8_t *)malloc(cells); w->pic.intra = (uint8_t *)malloc(cells);
+    w->pic.ipm = (uint8_t *)malloc(cells); w->pic.pcm = (uint8_t *)malloc(cells);
+    w->slice_of = (int *)calloc((size_t)w->n_ctb, sizeof(int)); w->tile_of = (int *)calloc((size_t)w->n_ctb, sizeof(int));
+    w->rs_of_ts = (int *)calloc((size_t)w->n_ctb + 1, sizeof(int)); w->ts_of_rs = (int *)calloc((size_t)w->n_ctb + 1, sizeof(int));
+    for (int i = 0; i <= w->tcols; i++) w->col_bd[i] = (i * w->ctbw) / w->tcols;
+    for (int i = 0; i <= w->trows; i++) w->row_bd[i] = (i * w->ctbh) / w->trows;
+    {
+        int ts = 0;
+        for (int tr = 0; tr < w->trows; tr++)
+            for (int tc = 0; tc < w->tcols; tc++)
+                for (int y = w->row_bd[tr]; y < w->row_bd[tr + 1]; y++)
+                    for (int x = w->col_bd[tc]; x < w->col_bd[tc + 1]; x++) {
+                        const int rs = y * w->ctbw + x;
+                        w->tile_of[rs] = tr * w->tcols + tc; w->rs_of_ts[ts] = rs; w->ts_of_rs[rs] = ts; ts++;
+                    }
+    }
+    return 0;
+}
+static void w_free(W *w)
+{
+    free(w->pic.skip); free(w->pic.depth); free(w->pic.intra); free(w->pic.ipm); free(w->pic.pcm);
+    free(w->slice_of); free(w->tile_of); free(w->rs_of_ts); free(w->ts_of_rs);
+}
+
 int oh_stream_write(const OhStreamParams *p, OhStream *out)
 {
     if (!p || !out || p->width < 8 || p->height < 8 || (p->width & 7) || (p->height & 7) || (p->bit_depth != 8 && p->bit_depth != 9 && p->bit_depth != 10 && p->bit_depth != 12) ||
@@ -1404,38 +1529,30 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     if (p->gop < 0 || p->gop > 3 || (p->gop == 3 && p->n_refs < 2))
         return -1;                                         /* the hierarchical GOP keeps three pictures beside the current one */
     W w;
-    memset(&w, 0, sizeof(w));
-    w.p = p;
-    g_trace_on = p->trace != 0; g_trace_n = 0;
-    g_lev_on = p->levels != 0 && !p->cu_qp_delta; g_lev_n = 0;
-    g_c444 = p->chroma_format_idc == 3;
-    g_cb_off = p->chroma_qp_offsets ? p->cb_qp_offset : 1; g_cr_off = p->chroma_qp_offsets ? p->cr_qp_offset : -2;
-    if (g_cb_off < -12 || g_cb_off > 12 || g_cr_off < -12 || g_cr_off > 12) return -1;
-    g_c422 = p->chroma_format_idc == 2;
-    w.g.s = p->seed * 0x2545F4914F6CDD1Dull + 77;
-    w.lc = p->log2_ctb_size; w.ctb = 1 << w.lc; w.min_cb_log2 = mcb_log2;
-    w.ctbw = (p->width + w.ctb - 1) >> w.lc; w.ctbh = (p->height + w.ctb - 1) >> w.lc; w.n_ctb = w.ctbw * w.ctbh;
-    w.tcols = p->tile_cols > 1 ? (p->tile_cols < w.ctbw ? p->tile_cols : w.ctbw) : 1;
-    w.trows = p->tile_rows > 1 ? (p->tile_rows < w.ctbh ? p->tile_rows : w.ctbh) : 1;
-    if (p->wpp && (w.tcols > 1 || w.trows > 1))
-        return -1;                                         /* both at once is legal in version 2 only; not produced */
-    w.pic.w4 = (p->width + 3) >> 2; w.pic.h4 = (p->height + 3) >> 2;
-    const size_t cells = (size_t)w.pic.w4 * w.pic.h4;
-    w.pic.skip = (uint8_t *)malloc(cells); w.pic.depth = (uint8_t *)malloc(cells); w.pic.intra = (uint8_t *)malloc(cells);
-    w.pic.ipm = (uint8_t *)malloc(cells); w.pic.pcm = (uint8_t *)malloc(cells);
-    w.slice_of = (int *)calloc((size_t)w.n_ctb, sizeof(int)); w.tile_of = (int *)calloc((size_t)w.n_ctb, sizeof(int));
-    w.rs_of_ts = (int *)calloc((size_t)w.n_ctb + 1, sizeof(int)); w.ts_of_rs = (int *)calloc((size_t)w.n_ctb + 1, sizeof(int));
-    for (int i = 0; i <= w.tcols; i++) w.col_bd[i] = (i * w.ctbw) / w.tcols;
-    for (int i = 0; i <= w.trows; i++) w.row_bd[i] = (i * w.ctbh) / w.trows;
-    {
-        int ts = 0;
-        for (int tr = 0; tr < w.trows; tr++)
-            for (int tc = 0; tc < w.tcols; tc++)
-                for (int y = w.row_bd[tr]; y < w.row_bd[tr + 1]; y++)
-                    for (int x = w.col_bd[tc]; x < w.col_bd[tc + 1]; x++) {
-                        const int rs = y * w.ctbw + x;
-                        w.tile_of[rs] = tr * w.tcols + tc; w.rs_of_ts[ts] = rs; w.ts_of_rs[rs] = ts; ts++;
-                    }
+    if (w_init(&w, p, mcb_log2) != 0)
+        return -1;
+    /* two layers (SHVC spatial scalability): an enhancement layer of shvc_el_width x shvc_el_height on top of this stream as its base
+     * layer.  Every access unit carries a picture of each layer; the enhancement-layer pictures are P slices whose ONE reference is the
+     * up-sampled base-layer picture of the same access unit (inter-layer prediction, zero motion vectors) plus intra blocks and residuals
+     * — the path that reaches the reference's up-sampling slots (hevc.c:2077-2097 ff_upsample_block, hevcdsp_template.c:1834-2162). */
+    const int two = p->shvc_el_width > 0 && p->shvc_el_height > 0;
+    OhStreamParams pe = *p;
+    W we;
+    memset(&we, 0, sizeof(we));
+    if (two) {
+        if (p->bit_depth != 8 || p->chroma_format_idc != 1 || p->gop == 3 || p->shvc_el_width < p->width || p->shvc_el_height < p->height ||
+            (p->shvc_el_width & ((1 << mcb_log2) - 1)) || (p->shvc_el_height & ((1 << mcb_log2) - 1)) || p->trace || p->levels ||
+            p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom) {
+            w_free(&w);
+            return -1;                                     /* the reference's up-sampler is written for 8-bit 4:2:0 (hevc_filter.c:34); the writer keeps the window empty */
+        }
+        pe.width = p->shvc_el_width; pe.height = p->shvc_el_height;
+        pe.gop = 1; pe.n_refs = 1; pe.tmvp = 0; pe.pcm = 0; pe.scaling_list = 0; pe.weighted_pred = 0; pe.n_slices = 1; pe.tile_cols = pe.tile_rows = 1;
+        pe.dependent_slices = 0; pe.idr_period = p->idr_period; pe.shvc_el_width = pe.shvc_el_height = 0;
+        pe.seed = p->seed ^ 0x5348564300000001ull;
+        if (w_init(&we, &pe, mcb_log2) != 0) { w_free(&w); return -1; }
+        we.el = 1;
+        g_trace_on = 0; g_lev_on = 0;
     }
     out->au_offset = (size_t *)calloc((size_t)p->n_pictures + 1, sizeof(size_t));
     Dpb dpb = { { 0 }, 0 };
@@ -1444,6 +1561,12 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
         byte_align_zero(&w.out);
         out->au_offset[i] = w.out.n / 8;
         const int idr = i == 0 || (p->idr_period > 0 && i % p->idr_period == 0);
+        if (idr && two) {
+            write_vps_two_layers(&w, pe.width, pe.height); write_sps(&w); write_pps(&w);
+            g_layer = 1; write_sps(&we); write_pps(&we); g_layer = 0;
+            bits_drain(&w.out, &we.out);
+            dpb.n = 0; poc = 0;
+        } else
         if (idr) { write_vps(&w); write_sps(&w); write_pps(&w); dpb.n = 0; poc = 0; }
         if (idr) idr_at = i;
         const int type = idr || p->gop == 0 ? SLICE_I : (p->gop == 1 ? SLICE_P : SLICE_B);
@@ -1468,6 +1591,14 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
             continue;
         }
         write_picture(&w, i, poc, type, &dpb, idr, 0);
+        if (two) {                                         /* the enhancement layer's picture of the same access unit */
+            Dpb none = { { 0 }, 0 };
+            g_layer = 1;
+            write_picture(&we, i, poc, SLICE_P, &none, idr, 0);
+            g_layer = 0;
+            byte_align_zero(&we.out);
+            bits_drain(&w.out, &we.out);
+        }
         /* every picture is a reference; the newest n_refs are kept */
         for (int k = dpb.n < p->n_refs ? dpb.n : p->n_refs - 1; k > 0; k--) dpb.poc[k] = dpb.poc[k - 1];
         dpb.poc[0] = poc;
@@ -1477,8 +1608,8 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     byte_align_zero(&w.out);
     out->au_offset[p->n_pictures] = w.out.n / 8;
     out->data = w.out.buf; out->size = w.out.n / 8; out->n_pictures = p->n_pictures;
-    free(w.pic.skip); free(w.pic.depth); free(w.pic.intra); free(w.pic.ipm); free(w.pic.pcm);
-    free(w.slice_of); free(w.tile_of); free(w.rs_of_ts); free(w.ts_of_rs);
+    w_free(&w);
+    if (two) { w_free(&we); free(we.out.buf); }
     return 0;
 }
 

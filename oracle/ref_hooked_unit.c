@@ -42,7 +42,9 @@ void oh_tables_untranslated_by_family(int out[8]);
 
 /* per decoding THREAD: the main thread (no threads, or slice / wavefront threads: it starts and ends every picture), or each of the
  * reference's frame threads (pthread_frame.c: a worker keeps its own HEVCContext and decodes whole pictures) */
-static __thread struct {
+/* one state per LAYER decoder: the wrapper runs the base-layer and the enhancement-layer decoder of an SHVC stream one after the other
+ * on the same thread (openHevcWrapper.c:112-133), each with its own picture geometry and recorder */
+static __thread struct HookState {
     HEVCContext *s;                   /* the context whose picture is being recorded on this thread */
     OhRecorder *rec;
     OhPicParams p;
@@ -53,7 +55,17 @@ static __thread struct {
     OhScalingList scaling;
     int last_engine_pic;              /* engine build: the engine picture the last submitted work list reconstructs */
     unsigned long long seq;           /* engine build: position of the picture in decode order (hand-over order) */
-} H;
+    /* engine build: the host buffers of the picture and of its references as they were when the picture started (an inter-layer
+     * reference is released as soon as the last CTB is parsed, hevc.c:3471-3474 — before the hand-over) */
+    const uint8_t *cur_base, *ref_base[OH_MAX_REFS];
+    int cur_ls, ref_ls[OH_MAX_REFS];
+    int ilr_slot;                     /* position of the inter-layer reference picture in the reference list, -1: none */
+    const uint8_t *bl_base;           /* the base layer's picture it is the up-sampled version of (host buffer; DPB slot of the base layer's decoder) */
+    int bl_id;
+    OhUpsample up;
+} HH[2];
+static __thread int h_idx;            /* which of the two is current: set where a picture starts (and by the engine build's decode callback) */
+#define H HH[h_idx]
 
 static int g_bs_from_motion;          /* ref_hooked_bs_from_motion(): the work lists carry the boundary-strength INPUTS */
 static __thread uint8_t *g_bs_call;   /* per min-TB cell: log2 size ff_hevc_deblocking_boundary_strengths was called with there, 0 = never */
@@ -107,6 +119,11 @@ static int frame_rps_and_bind(HEVCContext *s)
     int ret = ff_hevc_frame_rps(s);
     if (ret < 0)
         return ret;
+    if (s->decoder_id > 1 || (s->decoder_id && (s->threads_type & FF_THREAD_FRAME))) {
+        av_log(s->avctx, AV_LOG_ERROR, "recording hooks: an enhancement layer is decoded without frame threads, and there is one\n");
+        return AVERROR_PATCHWELCOME;
+    }
+    h_idx = s->decoder_id;
     const HEVCSPS *sps = s->sps;
     OhPicParams p;
     memset(&p, 0, sizeof(p));
@@ -129,13 +146,30 @@ static int frame_rps_and_bind(HEVCContext *s)
     H.cur_id = (int)(s->ref - s->DPB);
     /* the pictures this one may reference: its reference picture set (hevc_refs.c:391-470), slot = position in this list */
     H.n_refs = 0;
-    static const int lists[3] = { ST_CURR_BEF, ST_CURR_AFT, LT_CURR };
-    for (int l = 0; l < 3; l++)
-        for (int i = 0; i < s->rps[lists[l]].nb_refs && H.n_refs < OH_MAX_REFS; i++)
+    /* ... plus, in an enhancement layer, the inter-layer reference pictures (hevc_refs.c:738-756): the up-sampled base-layer picture */
+    static const int lists[5] = { ST_CURR_BEF, ST_CURR_AFT, LT_CURR, IL_REF0, IL_REF1 };
+    H.ilr_slot = -1;
+    for (int l = 0; l < 5; l++)
+        for (int i = 0; i < s->rps[lists[l]].nb_refs && H.n_refs < OH_MAX_REFS; i++) {
+            if (l >= 3 && s->rps[lists[l]].ref[i] == s->inter_layer_ref) H.ilr_slot = H.n_refs;
             H.ref_ids[H.n_refs++] = (int)(s->rps[lists[l]].ref[i] - s->DPB);
+        }
     int32_t ids[OH_MAX_REFS];
     for (int i = 0; i < H.n_refs; i++) ids[i] = H.ref_ids[i];
     oh_rec_begin(H.rec, H.cur_id, ids, H.n_refs);
+    H.bl_base = NULL;
+    if (H.ilr_slot >= 0 && s->BL_frame && s->BL_frame->frame) {
+        /* what hevc.c:3241 hands to the up-sampling slot: the filter set-up of the SPS (hevc.c:446-501) and the scaled reference layer window */
+        const HEVCWindow *win = &s->sps->scaled_ref_layer_window[s->vps->m_refLayerId[s->nuh_layer_id][0]];
+        H.bl_base = s->BL_frame->frame->data[0];
+        H.bl_id = (int)(s->BL_frame - ((HEVCContext *)((AVCodecContext *)s->avctx->BL_avcontext)->priv_data)->DPB);
+        H.up.add_x_lum = s->up_filter_inf.addXLum; H.up.add_y_lum = s->up_filter_inf.addYLum;
+        H.up.scale_x_lum = s->up_filter_inf.scaleXLum; H.up.scale_y_lum = s->up_filter_inf.scaleYLum;
+        H.up.add_x_cr = s->up_filter_inf.addXCr; H.up.add_y_cr = s->up_filter_inf.addYCr;
+        H.up.scale_x_cr = s->up_filter_inf.scaleXCr; H.up.scale_y_cr = s->up_filter_inf.scaleYCr;
+        H.up.idx = s->up_filter_inf.idx;
+        H.up.win_left = win->left_offset; H.up.win_right = win->right_offset; H.up.win_top = win->top_offset; H.up.win_bottom = win->bottom_offset;
+    }
     if (g_bs_from_motion) {
         const size_t n_tb = (size_t)sps->min_tb_width * sps->min_tb_height;
         if (g_bs_call_n != n_tb) { free(g_bs_call); g_bs_call = (uint8_t *)malloc(n_tb); g_bs_call_n = g_bs_call ? n_tb : 0; }
@@ -143,6 +177,10 @@ static int frame_rps_and_bind(HEVCContext *s)
     }
 #ifdef OH_WITH_ENGINE
     H.seq = next_picture_seq();       /* frame starts are serialised by the frame-thread protocol (ff_thread_finish_setup): decode order */
+    H.cur_base = s->frame->data[0]; H.cur_ls = s->frame->linesize[0];
+    for (int i = 0; i < H.n_refs; i++) {
+        H.ref_base[i] = s->DPB[H.ref_ids[i]].frame->data[0]; H.ref_ls[i] = s->DPB[H.ref_ids[i]].frame->linesize[0];
+    }
 #endif
     oh_tables_set_intra_accessor(intra_from_hevc);
     oh_tables_bind(H.rec, s->frame->data, s->frame->linesize);
@@ -214,6 +252,16 @@ __attribute__((visibility("default"))) const OhFrame *ref_hooked_finish(int *cur
         memcpy(H.scaling.sl_dc, sl->sl_dc, sizeof(H.scaling.sl_dc));
     }
     return oh_rec_finish(H.rec);
+}
+
+/* two-layer streams: which layer's picture the next ref_hooked_finish / ref_hooked_inter_layer speak about (0 base, 1 enhancement) */
+__attribute__((visibility("default"))) void ref_hooked_select_layer(int layer) { h_idx = layer == 1; }
+/* the inter-layer reference of the enhancement-layer picture that was just recorded: its position in the work list's reference list
+ * (-1: the picture has none), the DPB slot of the base layer's picture it is resampled from, and the resampling set-up */
+__attribute__((visibility("default"))) int ref_hooked_inter_layer(int *bl_id, OhUpsample *up)
+{
+    if (H.ilr_slot >= 0 && H.bl_base) { *bl_id = H.bl_id; *up = H.up; }
+    return H.bl_base ? H.ilr_slot : -1;
 }
 
 /* which picture an OUTPUT frame is: `luma` = plane 0 of the frame libOpenHevcGetOutput hands out, i.e. a DPB frame's data[0] moved
@@ -343,18 +391,18 @@ static int same_geometry(const OhPicParams *a, const OhPicParams *b)
     return a->width == b->width && a->height == b->height && a->bit_depth == b->bit_depth && a->chroma_format_idc == b->chroma_format_idc;
 }
 /* the engine picture of a decoder frame (created on first sight, re-created when the buffer comes back with another geometry) */
-static int engine_pic_of(const AVFrame *fr, const OhPicParams *p)
+static int engine_pic_of(const uint8_t *base, int linesize, const OhPicParams *p)
 {
     OhEngine *e = the_engine();
-    if (!e || !fr || !fr->data[0]) return -1;
+    if (!e || !base) return -1;
     int slot = -1;
     for (int i = 0; i < E.n; i++)
-        if (E.pic[i].base == fr->data[0]) { slot = i; break; }
+        if (E.pic[i].base == base) { slot = i; break; }
     if (slot >= 0 && same_geometry(&E.pic[slot].p, p))
         return E.pic[slot].id;
     if (slot < 0) {
         /* a NEW buffer: whatever the map still holds inside its range belongs to buffers the frame pool has freed since */
-        const uint8_t *lo = fr->data[0], *hi = lo + (size_t)fr->linesize[0] * (size_t)p->height;
+        const uint8_t *lo = base, *hi = lo + (size_t)linesize * (size_t)p->height;
         for (int i = 0; i < E.n; ) {
             if (E.pic[i].base < hi && E.pic[i].base + E.pic[i].span > lo) {
                 oh_pic_free(e, E.pic[i].id);
@@ -369,7 +417,7 @@ static int engine_pic_of(const AVFrame *fr, const OhPicParams *p)
     }
     int id = -1;
     if (oh_pic_alloc(e, p, &id) != OH_OK) { fprintf(stderr, "libopenhevc_hip: %s\n", oh_engine_last_error(e)); E.n -= (slot == E.n - 1); return -1; }
-    E.pic[slot].base = fr->data[0]; E.pic[slot].span = (size_t)fr->linesize[0] * (size_t)p->height; E.pic[slot].id = id; E.pic[slot].p = *p;
+    E.pic[slot].base = base; E.pic[slot].span = (size_t)linesize * (size_t)p->height; E.pic[slot].id = id; E.pic[slot].p = *p;
     return id;
 }
 
@@ -398,15 +446,26 @@ static int finish_and_submit(HEVCContext *s)
     int rc = e ? 0 : -1;
     OhFrame g = *f;
     if (!rc) {
-        g.cur_pic = engine_pic_of(s->DPB[cur].frame, &f->p);
+        g.cur_pic = engine_pic_of(H.cur_base, H.cur_ls, &f->p);
         if (g.cur_pic < 0) rc = -1;
         for (int r = 0; r < OH_MAX_REFS && !rc; r++) {
             g.ref_pics[r] = -1;
-            if (f->ref_pics[r] >= 0) {
-                g.ref_pics[r] = engine_pic_of(s->DPB[f->ref_pics[r]].frame, &f->p);
+            if (f->ref_pics[r] >= 0 && r < H.n_refs) {
+                g.ref_pics[r] = engine_pic_of(H.ref_base[r], H.ref_ls[r], &f->p);
                 if (g.ref_pics[r] < 0) rc = -1;
             }
         }
+    }
+    if (!rc && H.ilr_slot >= 0) {
+        /* SHVC: the inter-layer reference picture is the base layer's picture of this access unit (submitted a moment ago, decode order
+         * is execution order) resampled to this layer's size — the reference's up-sampling slots (hevcdsp_template.c:1834-2438), which
+         * it drives per CTB from ff_upsample_block (hevc_filter.c:1370-1426); here ONE launch pair over the whole picture, before the
+         * work list whose motion compensation reads it */
+        int bl = -1;
+        for (int i = 0; i < E.n; i++)
+            if (E.pic[i].base == H.bl_base) bl = E.pic[i].id;
+        if (bl < 0 || g.ref_pics[H.ilr_slot] < 0) { fprintf(stderr, "libopenhevc_hip: picture poc %d: the base layer's picture is not in the engine\n", poc); rc = -1; }
+        else if (oh_pic_upsample(e, g.ref_pics[H.ilr_slot], bl, &H.up) != OH_OK) { fprintf(stderr, "libopenhevc_hip: picture poc %d: %s\n", poc, oh_engine_last_error(e)); rc = -1; }
     }
     if (!rc && H.scaling_on && g.sparse) g.scaling = &H.scaling;
     if (!rc && oh_frame_submit(e, &g) != OH_OK) { fprintf(stderr, "libopenhevc_hip: picture poc %d: %s\n", poc, oh_engine_last_error(e)); rc = -1; }
@@ -554,6 +613,7 @@ static void hooked_row_progress(HEVCContext *s, int x_ctb, int y_ctb, int ctb_si
 static int hooked_decode_frame(AVCodecContext *avctx, void *data, int *got_output, AVPacket *avpkt)
 {
     tls_s = avctx->priv_data;
+    h_idx = tls_s->decoder_id == 1;
     tls_md5_plane = 0;
     const double t_d0 = hook_now();
     tls_t_entry = t_d0;

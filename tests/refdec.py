@@ -94,7 +94,8 @@ def parsed_trace(data):
 def split_access_units(data):
     """the byte ranges of the access units of an Annex-B stream in the sense of hevc_parser.c:40-87: a new access unit starts at
     the first VPS / SPS / PPS / AUD / prefix SEI NAL unit that follows a VCL NAL unit, or at a VCL NAL unit whose
-    first_slice_segment_in_pic_flag is set"""
+    first_slice_segment_in_pic_flag is set — NAL units of nuh_layer_id 0 only (hevc_parser.c:62,71: the pictures of the higher
+    layers of an SHVC stream stay in the access unit of their base-layer picture)"""
     starts = []
     i, n = 0, len(data)
     while i + 3 < n:
@@ -106,16 +107,17 @@ def split_access_units(data):
     aus, cur, seen_vcl = [], 0, False
     for k, s in enumerate(starts):
         t = (data[s] >> 1) & 63
+        layer = ((data[s] & 1) << 5) | (data[s + 1] >> 3)
         sc = s - 3 - (1 if s >= 4 and data[s - 4] == 0 else 0)     # include the leading zero of a 4-byte start code
         new_au = False
         if t in (32, 33, 34, 35, 39) or 41 <= t <= 44 or 48 <= t <= 55:
-            new_au = seen_vcl
+            new_au = seen_vcl and layer == 0
         elif t <= 9 or 16 <= t <= 21:
-            new_au = seen_vcl and bool(data[s + 2] & 0x80)
+            new_au = seen_vcl and bool(data[s + 2] & 0x80) and layer == 0
         if new_au:
             aus.append((cur, sc))
             cur, seen_vcl = sc, False
-        if t <= 9 or 16 <= t <= 21:
+        if (t <= 9 or 16 <= t <= 21) and layer == 0:
             seen_vcl = True
     aus.append((cur, n))
     return aus
@@ -226,6 +228,8 @@ def hooked_lib():
         L.ref_hooked_finish.restype = C.POINTER(F.OhFrame)
         L.ref_hooked_finish.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ref_hooked_scaling_list.argtypes = [C.c_void_p]
+        L.ref_hooked_select_layer.argtypes = [C.c_int]
+        L.ref_hooked_inter_layer.argtypes = [C.POINTER(C.c_int), C.POINTER(F.OhUpsample)]
         _hlib = L
     return _hlib
 
@@ -276,6 +280,37 @@ def record_work_lists(data, on_picture, threads=1, thread_type=1, bs_from_motion
             n += 1
     L.libOpenHevcClose(h)
     L.ref_hooked_bs_from_motion(0)
+    return n
+
+
+def record_layer_work_lists(data, on_picture, threads=1, thread_type=1):
+    """record_work_lists for a TWO-LAYER (SHVC) stream: the wrapper runs the base-layer and the enhancement-layer decoder on every access
+    unit, each records its own picture.  on_picture(layer, frame, cur_id, poc, inter_layer) per picture, base layer first; inter_layer is
+    None, or (slot, bl_id, OhUpsample): frame.ref_pics[slot] is the inter-layer reference picture = the base layer's picture bl_id (a slot
+    of the BASE layer decoder's DPB) resampled with that set-up (what hevc.c:2077-2097 / hevc_filter.c:1370-1426 do CTB by CTB)"""
+    from openhevc_amd import frame as F
+    L = hooked_lib()
+    h = C.c_void_p(L.libOpenHevcInit(threads, thread_type))
+    assert L.libOpenHevcStartDecoder(h) == 1
+    n = [0, 0]
+    try:
+        for k, (a, b) in enumerate(split_access_units(data)):
+            if L.libOpenHevcDecode(h, bytes(data[a:b]) + PAD, b - a, k) < 0:
+                raise RuntimeError(f"hooked reference decoder failed on access unit {k}")
+            for layer in (0, 1):
+                L.ref_hooked_select_layer(layer)
+                cur, poc, bad = C.c_int(), C.c_int(), C.c_int()
+                f = L.ref_hooked_finish(C.byref(cur), C.byref(poc), C.byref(bad))
+                if not f:
+                    continue
+                assert bad.value == 0, f"{bad.value} slot calls of layer {layer} picture {n[layer]} could not be translated into work-list items"
+                bl, up = C.c_int(-1), F.OhUpsample()
+                slot = L.ref_hooked_inter_layer(C.byref(bl), C.byref(up))
+                on_picture(layer, f.contents, cur.value, poc.value, (slot, bl.value, up) if slot >= 0 else None)
+                n[layer] += 1
+    finally:
+        L.ref_hooked_select_layer(0)
+        L.libOpenHevcClose(h)
     return n
 
 

@@ -11,7 +11,7 @@ _FIELDS = ("width", "height", "bit_depth", "log2_ctb_size", "log2_min_tb_size", 
            "coeff_density")
 
 
-_REXT = ("tskip_rotation", "tskip_context", "implicit_rdpcm", "explicit_rdpcm", "intra_smoothing_disabled", "persistent_rice", "log2_max_tskip_size", "pcm_loop_filter", "chroma_qp_offsets", "cb_qp_offset", "cr_qp_offset", "sao_offset_scale_luma", "sao_offset_scale_chroma", "log2_min_cb_size")
+_REXT = ("tskip_rotation", "tskip_context", "implicit_rdpcm", "explicit_rdpcm", "intra_smoothing_disabled", "persistent_rice", "log2_max_tskip_size", "pcm_loop_filter", "chroma_qp_offsets", "cb_qp_offset", "cr_qp_offset", "sao_offset_scale_luma", "sao_offset_scale_chroma", "log2_min_cb_size", "shvc_el_width", "shvc_el_height")
 
 
 class OhStreamParams(C.Structure):

@@ -284,3 +284,90 @@ def test_random_small_ctb_streams():
         if kw["gop"] == 3:
             kw.update(n_pictures=5)
         test_hooked_ctu_loop_reproduces_the_reference_decoder(("sweep", w, h, rng.randint(1, 10 ** 6), kw))
+
+
+# ---- SHVC: two-layer streams (SURVEY.md 8 row a30 on real streams) ----
+SHVC_CASES = [
+    ("x2", 96, 64, 192, 128, 61, dict(n_pictures=4, gop=2)),
+    ("x1_5", 96, 64, 144, 96, 62, dict(n_pictures=4, gop=2, amp=1, transform_skip=1)),
+    ("snr", 96, 64, 96, 64, 63, dict(n_pictures=3, gop=1)),
+    ("ratios_1_33_by_1_75", 96, 64, 128, 112, 64, dict(n_pictures=3, gop=2)),
+    ("x2_idr_period", 64, 64, 128, 128, 65, dict(n_pictures=7, gop=2, idr_period=3, n_refs=2, tmvp=1)),
+]
+
+
+def test_two_layer_writer_refuses_what_the_up_sampler_cannot_do():
+    for kw in (dict(bit_depth=10), dict(chroma_format_idc=3), dict(gop=3), dict(conf_win_left=2)):
+        with pytest.raises(ValueError):
+            streamgen.write_stream(64, 64, 1, n_pictures=2, shvc_el_width=128, shvc_el_height=128, **kw)
+    with pytest.raises(ValueError):                           # an enhancement layer smaller than the base layer
+        streamgen.write_stream(64, 64, 1, n_pictures=2, shvc_el_width=32, shvc_el_height=64)
+    with pytest.raises(ValueError):                           # not a multiple of the smallest coding block
+        streamgen.write_stream(64, 64, 1, n_pictures=2, shvc_el_width=100, shvc_el_height=128)
+
+
+@pytest.mark.parametrize("case", SHVC_CASES, ids=[c[0] for c in SHVC_CASES])
+def test_two_layer_stream_is_what_the_reference_decodes(case):
+    """every access unit holds a base-layer and an enhancement-layer picture (nuh_layer_id 0 / 1: the access-unit splitter keeps them
+    together); the reference decodes both layers without complaint and releases the enhancement layer's pictures"""
+    _, w, h, ew, eh, seed, kw = case
+    data, aus = streamgen.write_stream(w, h, seed, shvc_el_width=ew, shvc_el_height=eh, **kw)
+    assert [tuple(a) for a in refdec.split_access_units(data)] == [tuple(a) for a in aus]
+    layers = []
+    for a, b in aus:
+        au, ls, i = data[a:b], [], 0
+        while (i := au.find(b"\x00\x00\x01", i)) >= 0:
+            if (au[i + 3] >> 1) & 63 < 32:                    # a slice segment: its nuh_layer_id
+                ls.append(((au[i + 3] & 1) << 5) | (au[i + 4] >> 3))
+            i += 3
+        layers.append(ls)
+    assert all(ls == [0, 1] for ls in layers), layers
+    with refdec.captured_stderr() as cap:
+        pics = refdec.decode(data)
+    assert "rror" not in cap.text.replace("Could not find ref with POC", ""), cap.text[-1500:]
+    # the wrapper exposes the highest layer that released a picture (openHevcWrapper.c:139-152): the enhancement layer's, every time
+    assert [p[0].shape for p in pics] == [(eh, ew)] * kw["n_pictures"]
+
+
+def decode_layers_through_hooks(data):
+    """both layers' pictures reconstructed by the CHECKER from the work lists of the hooked reference decoder, in decode order:
+    [(layer, poc, planes)].  The inter-layer reference picture is made with the checker's whole-picture up-sampling
+    (oracle.c oh_or_upsample_frame) from the base layer's reconstructed picture before the enhancement layer's work list runs."""
+    from test_upsample_vs_ref import host_pic
+    pics, out = ({}, {}), []
+
+    def on_picture(layer, f, cur, poc, il):
+        mine = pics[layer]
+        for i in [cur] + [f.ref_pics[k] for k in range(F.OH_MAX_REFS) if f.ref_pics[k] >= 0]:
+            if i not in mine or (mine[i].params.width, mine[i].params.height) != (f.p.width, f.p.height):
+                mine[i] = F.HostPic(f.p)
+        assert (il is not None) == (layer == 1)
+        if il is not None:
+            slot, bl_id, up = il
+            assert f.n_pu > 0 and all(f.pu[k].ref[0] == slot and f.pu[k].mv[0][0] == 0 and f.pu[k].mv[0][1] == 0 for k in range(min(f.n_pu, 50)))     # inter-layer prediction is what its PUs do
+            bl, ilr = pics[0][bl_id], mine[f.ref_pics[slot]]
+            hb, he = host_pic(bl.params, bl.planes), host_pic(ilr.params, ilr.planes)
+            assert oracle().oh_or_upsample_frame(C.byref(hb), C.byref(he), C.byref(up)) == 0
+        assert oracle().oh_or_frame(C.byref(f), host_pic_array(mine)) == 0
+        out.append((layer, poc, [mine[cur].visible(c).copy() for c in range(3)]))
+    n = refdec.record_layer_work_lists(data, on_picture)
+    return n, out
+
+
+@pytest.mark.parametrize("case", SHVC_CASES, ids=[c[0] for c in SHVC_CASES])
+def test_hooked_ctu_loops_of_both_layers_reproduce_the_reference_decoder(case):
+    """the reference's two decoders with the RECORDING slots: the base layer's and the enhancement layer's work lists, the inter-layer
+    reference picture made by the checker's up-sampling, give the pictures the plain reference library outputs for both layers"""
+    _, w, h, ew, eh, seed, kw = case
+    data, _ = streamgen.write_stream(w, h, seed, shvc_el_width=ew, shvc_el_height=eh, **kw)
+    with refdec.captured_stderr():
+        want = refdec.decode(data)
+        n, got = decode_layers_through_hooks(data)
+    assert n == [kw["n_pictures"], kw["n_pictures"]]
+    base, _ = streamgen.write_stream(w, h, seed, **kw)       # the same base layer as a one-layer stream: what the base-layer decoder reconstructs
+    for layer, theirs in ((0, refdec.decode(base)), (1, want)):
+        mine = [p for l, _, p in got if l == layer]
+        assert len(mine) == len(theirs) == kw["n_pictures"]
+        for k, (t, m) in enumerate(zip(theirs, mine)):       # low delay: output order = decode order
+            for c in range(3):
+                assert t[c].shape == m[c].shape and np.array_equal(t[c], m[c]), (case[0], "layer", layer, "picture", k, "plane", c)

@@ -73,6 +73,51 @@ def test_wrapper_loop_matches_the_reference_library(name, w, h, seed, kw, thread
             assert np.array_equal(a[c], b[c]), f"{name}: output picture {k} plane {c} differs from the reference library's"
 
 
+# SHVC: two-layer streams as the reference parses them (SHM 4.1 draft syntax).  The wrapper runs one decoder per
+# layer on every access unit (openHevcWrapper.c:112-133); the enhancement layer's pictures predict from the base layer's picture of the
+# same access unit resampled to their size — ff_upsample_block and the upsample_filter_block_* slots in the reference
+# (hevc_filter.c:1370-1426, hevcdsp_template.c:1834-2162), oh_pic_upsample on the engine's pictures here.
+SHVC = [
+    ("x2", 416, 240, 832, 480, 51, dict(n_pictures=5, gop=2), 1, 1),
+    ("x1_5", 416, 240, 624, 360, 52, dict(n_pictures=5, gop=2, amp=1, transform_skip=1), 1, 1),
+    ("snr_x1", 416, 240, 416, 240, 53, dict(n_pictures=4, gop=1), 1, 1),
+    ("any_ratio", 416, 240, 560, 400, 54, dict(n_pictures=4, gop=2), 1, 1),                   # the slots' generic ("DEFAULT") filter path, different ratios per axis
+    ("x2_idr_period_hier_bl", 192, 128, 384, 256, 55, dict(n_pictures=9, gop=2, idr_period=4, n_refs=2, tmvp=1), 1, 1),
+    ("x2_wavefront_slice_threads", 416, 240, 832, 480, 56, dict(n_pictures=4, gop=2, wpp=1), 4, 2),
+    ("x1_5_tiny_ctb16", 96, 64, 144, 96, 57, dict(n_pictures=4, gop=2, log2_ctb_size=4), 1, 1),
+]
+
+
+@pytest.mark.gpu
+@need_lib
+@pytest.mark.parametrize("name,w,h,ew,eh,seed,kw,threads,ttype", SHVC, ids=[s[0] for s in SHVC])
+def test_two_layer_streams_match_the_reference_library(name, w, h, ew, eh, seed, kw, threads, ttype):
+    """the same harness loop over a two-layer stream: the pictures the wrapper releases (it exposes the highest layer that has one,
+    openHevcWrapper.c:139-152) are the reference library's, plane for plane — base-layer AND enhancement-layer pictures"""
+    data, _ = streamgen.write_stream(w, h, seed, shvc_el_width=ew, shvc_el_height=eh, **kw)
+    with refdec.captured_stderr():
+        want = refdec.decode(data)
+    got = refdec.decode(data, threads=threads, thread_type=ttype, L=refdec.hip_lib())
+    assert len(got) == len(want) and len(want) > 0, (len(got), len(want))
+    assert sum(p[0].shape == (eh, ew) for p in want) >= kw["n_pictures"] - 1, [p[0].shape for p in want]
+    for k, (a, b) in enumerate(zip(want, got)):
+        for c in range(3):
+            assert a[c].shape == b[c].shape and a[c].dtype == b[c].dtype, (name, k, c, a[c].shape, b[c].shape)
+            assert np.array_equal(a[c], b[c]), f"{name}: output picture {k} plane {c} ({a[c].shape}) differs from the reference library's"
+
+
+@pytest.mark.gpu
+@need_lib
+def test_an_enhancement_layer_with_frame_threads_is_refused():
+    """the recording hooks bind one picture per thread and layer; the reference's frame threads for an enhancement layer need its
+    inter-layer progress protocol (pthread_frame.c ff_thread_await_il_progress), which the hooks do not carry: a clean decode error"""
+    data, _ = streamgen.write_stream(192, 128, 58, n_pictures=3, shvc_el_width=384, shvc_el_height=256)
+    with refdec.captured_stderr() as cap:
+        with pytest.raises(RuntimeError):
+            refdec.decode(data, threads=2, thread_type=1, L=refdec.hip_lib())
+    assert "enhancement layer" in cap.text
+
+
 @pytest.mark.gpu
 @need_lib
 def test_the_decoders_own_md5_check_judges_the_engines_pictures():

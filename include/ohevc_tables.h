@@ -27,7 +27,8 @@
  *                                                        accessor registered with oh_tables_set_intra_accessor()
  *   hevc_*_loop_filter_*, sao_*                       no-ops: passes 4-5 run from the BS/QP/SAO arrays
  *   put_pcm                                           reads the samples (get_bits) and records OH_TU_PCM blocks
- *   upsample_*                                        left untouched (oh_pic_upsample replaces them)
+ *   upsample_*                                        do nothing: the inter-layer reference picture is resampled in HBM by
+ *                                                     oh_pic_upsample, issued by the decoder's hand-over
  */
 #ifndef OHEVC_TABLES_H
 #define OHEVC_TABLES_H

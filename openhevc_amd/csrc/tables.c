@@ -404,6 +404,15 @@ static void s_sao_edge(uint8_t *d, uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, struc
                        uint8_t *ve, uint8_t *he, uint8_t *de)
 { (void)d; (void)s; (void)sd; (void)ss; (void)sao; (void)b; (void)w; (void)h; (void)c; (void)ve; (void)he; (void)de; }
 
+static void s_up_h(int16_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride, int x_EL, int x_BL, int block_w, int block_h, int widthEL,
+                   const struct HEVCWindow *Enhscal, struct UpsamplInf *up_info)
+{ (void)dst; (void)dststride; (void)src; (void)srcstride; (void)x_EL; (void)x_BL; (void)block_w; (void)block_h; (void)widthEL; (void)Enhscal; (void)up_info; }
+static void s_up_v(uint8_t *dst, ptrdiff_t dststride, int16_t *src, ptrdiff_t srcstride, int y_BL, int x_EL, int y_EL, int block_w, int block_h, int widthEL,
+                   int heightEL, const struct HEVCWindow *Enhscal, struct UpsamplInf *up_info)
+{ (void)dst; (void)dststride; (void)src; (void)srcstride; (void)y_BL; (void)x_EL; (void)y_EL; (void)block_w; (void)block_h; (void)widthEL; (void)heightEL; (void)Enhscal; (void)up_info; }
+static void s_up_frame(struct AVFrame *FrameEL, struct AVFrame *FrameBL, short *Buffer[3], const struct HEVCWindow *Enhscal, struct UpsamplInf *up_info, int channel)
+{ (void)FrameEL; (void)FrameBL; (void)Buffer; (void)Enhscal; (void)up_info; (void)channel; }
+
 /* ---- the hooks ---- */
 void ff_hevcdsp_init_hip(HEVCDSPContext *c, const int bit_depth)
 {
@@ -429,7 +438,17 @@ void ff_hevcdsp_init_hip(HEVCDSPContext *c, const int bit_depth)
     c->hevc_h_loop_filter_chroma = c->hevc_v_loop_filter_chroma = s_lf_chroma;
     c->hevc_h_loop_filter_chroma_c = c->hevc_v_loop_filter_chroma_c = s_lf_chroma;
     c->put_pcm = s_put_pcm;
-    /* the SHVC upsample_* slots keep whatever ff_hevc_dsp_init() installed: oh_pic_upsample replaces their caller */
+    /* SHVC: the enhancement-layer decoder up-samples its inter-layer reference picture CTB by CTB where prediction units read it
+     * (ff_upsample_block, hevc_filter.c:1370-1426 -> upsample_block_luma / upsample_block_mc -> these four slot families).  With the
+     * engine that picture is resampled in HBM (oh_pic_upsample, issued by the decoder's hand-over before the picture's work list,
+     * INTEGRATION.md section 8); the slots do nothing, and ff_upsample_block keeps the part that is host work: is_upsampled[] and the
+     * scaled motion field (ff_upscale_mv_block).  upsample_base_layer_frame (the whole-picture variant of builds without
+     * ACTIVE_PU_UPSAMPLING, hevc.c:3241) is replaced the same way. */
+    for (int i = 0; i < 3; i++) {
+        c->upsample_filter_block_luma_h[i] = s_up_h; c->upsample_filter_block_cr_h[i] = s_up_h;
+        c->upsample_filter_block_luma_v[i] = s_up_v; c->upsample_filter_block_cr_v[i] = s_up_v;
+    }
+    c->upsample_base_layer_frame = s_up_frame;
 }
 
 void ff_hevcpred_init_hip(HEVCPredContext *c, const int bit_depth)

@@ -521,6 +521,7 @@ static void write_pps(W *w)
     put_bit(&b, p->deblocking_override != 0);
     put_bit(&b, 0);                                        /* pps_deblocking_filter_disabled */
     put_se(&b, 1); put_se(&b, -1);                         /* beta_offset_div2, tc_offset_div2 */
+    if (w->el) put_bit(&b, 0);                             /* pps_infer_scaling_list_flag: a layer-1 PPS carries it (hevc_ps.c:2380-2385) */
     put_bit(&b, 0);                                        /* scaling list data */
     put_bit(&b, 0);                                        /* lists modification */
     put_ue(&b, 0);                                         /* log2_parallel_merge_level 2 */

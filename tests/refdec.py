@@ -143,13 +143,18 @@ def sse_lib():
     return _slib
 
 
-def decode(data, threads=1, thread_type=1, check_md5=False, L=None, keep=True):
+def decode(data, threads=1, thread_type=1, check_md5=False, L=None, keep=True, active_decoders=None):
     """decodes an Annex-B stream access unit by access unit through the libOpenHevc* API; returns the output pictures as lists of
     numpy planes (cropped, packed) in output order (keep=False: only None per output picture — timing runs)"""
     L = L or lib()
     h = C.c_void_p(L.libOpenHevcInit(threads, thread_type))
     assert L.libOpenHevcStartDecoder(h) == 1
     L.libOpenHevcSetCheckMD5(h, int(check_md5))
+    if active_decoders is not None:                            # SHVC: the highest layer that is decoded (openHevcWrapper.c:405-414), 0 = the base layer only
+        L.libOpenHevcSetActiveDecoders.argtypes = [C.c_void_p, C.c_int]
+        L.libOpenHevcSetViewLayers.argtypes = [C.c_void_p, C.c_int]
+        L.libOpenHevcSetActiveDecoders(h, active_decoders)
+        L.libOpenHevcSetViewLayers(h, active_decoders)
     pics = []
 
     def grab():

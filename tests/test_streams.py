@@ -293,6 +293,7 @@ SHVC_CASES = [
     ("snr", 96, 64, 96, 64, 63, dict(n_pictures=3, gop=1)),
     ("ratios_1_33_by_1_75", 96, 64, 128, 112, 64, dict(n_pictures=3, gop=2)),
     ("x2_idr_period", 64, 64, 128, 128, 65, dict(n_pictures=7, gop=2, idr_period=3, n_refs=2, tmvp=1)),
+    ("x1_5_ctb16", 96, 64, 144, 96, 66, dict(n_pictures=3, gop=2, log2_ctb_size=4, log2_max_tb_size=4)),
 ]
 
 

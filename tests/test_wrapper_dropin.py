@@ -84,7 +84,7 @@ SHVC = [
     ("any_ratio", 416, 240, 560, 400, 54, dict(n_pictures=4, gop=2), 1, 1),                   # the slots' generic ("DEFAULT") filter path, different ratios per axis
     ("x2_idr_period_hier_bl", 192, 128, 384, 256, 55, dict(n_pictures=9, gop=2, idr_period=4, n_refs=2, tmvp=1), 1, 1),
     ("x2_wavefront_slice_threads", 416, 240, 832, 480, 56, dict(n_pictures=4, gop=2, wpp=1), 4, 2),
-    ("x1_5_tiny_ctb16", 96, 64, 144, 96, 57, dict(n_pictures=4, gop=2, log2_ctb_size=4), 1, 1),
+    ("x1_5_tiny_ctb16", 96, 64, 144, 96, 57, dict(n_pictures=4, gop=2, log2_ctb_size=4, log2_max_tb_size=4), 1, 1),
 ]
 
 
@@ -109,13 +109,23 @@ def test_two_layer_streams_match_the_reference_library(name, w, h, ew, eh, seed,
 @pytest.mark.gpu
 @need_lib
 def test_an_enhancement_layer_with_frame_threads_is_refused():
-    """the recording hooks bind one picture per thread and layer; the reference's frame threads for an enhancement layer need its
-    inter-layer progress protocol (pthread_frame.c ff_thread_await_il_progress), which the hooks do not carry: a clean decode error"""
-    data, _ = streamgen.write_stream(192, 128, 58, n_pictures=3, shvc_el_width=384, shvc_el_height=256)
+    """the reference's frame threads for an enhancement layer synchronise with the base layer's through its inter-layer progress protocol
+    (pthread_frame.c ff_thread_await_il_progress), which hands host pictures between the two thread pools; the recording hooks keep one
+    picture per thread and layer: libOpenHevcDecode returns the API's error value for such an access unit — and the base layer alone
+    (libOpenHevcSetActiveDecoders(h, 0)) decodes under frame threads as any one-layer stream does"""
+    kw = dict(n_pictures=6, gop=2)
+    data, _ = streamgen.write_stream(192, 128, 58, shvc_el_width=384, shvc_el_height=256, **kw)
     with refdec.captured_stderr() as cap:
         with pytest.raises(RuntimeError):
             refdec.decode(data, threads=2, thread_type=1, L=refdec.hip_lib())
     assert "enhancement layer" in cap.text
+    base, _ = streamgen.write_stream(192, 128, 58, **kw)
+    want = refdec.decode(base)
+    got = refdec.decode(data, threads=3, thread_type=1, L=refdec.hip_lib(), active_decoders=0)
+    assert len(got) == len(want) == 6
+    for a, b in zip(want, got):
+        for c in range(3):
+            assert np.array_equal(a[c], b[c])
 
 
 @pytest.mark.gpu

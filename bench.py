@@ -242,6 +242,32 @@ def end_to_end(n_pictures=60):
             if isinstance(v, dict) and v.get("fps"):
                 v["Mpixels_per_s"] = round(v["fps"] * w * h / 1e6, 1)
         out["streams"][name] = rec
+    # SHVC: a two-layer stream, 1080p base layer + 2160p enhancement layer (x2 spatial scalability, 8 bit 4:2:0 — what
+    # the reference's up-sampler is written for); both layers' pictures go through the engine, the inter-layer reference picture is resampled in
+    # HBM (oh_pic_upsample).  Slice / wavefront threads (the recording hooks refuse an enhancement layer under frame threads); fps counts the
+    # released (enhancement-layer) pictures, every one standing for a base-layer picture as well
+    try:
+        t0 = time.perf_counter()
+        data, _ = streamgen.write_stream(1920, 1080 + 8, 6, n_pictures=n_pictures, gop=2, wpp=1, shvc_el_width=3840, shvc_el_height=2160 + 16)
+        rec = dict(pictures=n_pictures, layers="1920x1088 -> 3840x2176, x2", stream_MB=round(len(data) / 1e6, 1), written_in_s=round(time.perf_counter() - t0, 1))
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as fh:
+            fh.write(data)
+            path = fh.name
+        del data
+        try:
+            rec["dropin_slice_threads"] = run(libs["dropin"], path, 2)
+            rec["dropin_slice_threads_with_output"] = run(libs["dropin"], path, 2, ("-g",))
+            for k in ("reference_sse", "reference_c"):
+                if os.path.exists(libs[k]):
+                    rec[k + "_slice_threads"] = run(libs[k], path, 2)
+        finally:
+            os.unlink(path)
+        for k, v in rec.items():
+            if isinstance(v, dict) and v.get("fps"):
+                v["Mpixels_per_s_both_layers"] = round(v["fps"] * (1920 * 1088 + 3840 * 2176) / 1e6, 1)
+        out["streams"]["shvc_1080p_to_2160p"] = rec
+    except Exception as ex:                                    # the figure is an extra: never the reason a bench run fails
+        out["streams"]["shvc_1080p_to_2160p"] = dict(error=repr(ex)[:300])
     r8 = out["streams"].get("4320p_main10", {})
     fps8 = (r8.get("dropin_frame_threads") or {}).get("fps")
     fps8o = (r8.get("dropin_frame_threads_with_output") or {}).get("fps")
@@ -695,6 +721,8 @@ def main():
                                     if exchange is not None else "one RCCL all-gather of the finished reference pictures per wave and stream, on the stream's own exchange stream"),
                        "exchange_per_rank": decode_exchange if world > 1 else None,
                        "ranks": ranks_info,
+                       "shvc": "8-bit 4:2:0 only, as reference (its up-sampler, hevc_filter.c:34 / hevcdsp_template.c:1834-2438); not part of this workload: "
+                               "a two-layer stream is decoded in end_to_end.streams.shvc_1080p_to_2160p, parity in tests/test_wrapper_dropin.py",
                        "generator": dict(gen, seed=hex(plan_kwargs["seed"]), ctb=64, min_cb=8, tu="4-32")},
             "roofline": head["roofline"],
             "check": check,

@@ -84,6 +84,8 @@ SHVC = [
     ("any_ratio", 416, 240, 560, 400, 54, dict(n_pictures=4, gop=2), 1, 1),                   # the slots' generic ("DEFAULT") filter path, different ratios per axis
     ("x2_idr_period_hier_bl", 192, 128, 384, 256, 55, dict(n_pictures=9, gop=2, idr_period=4, n_refs=2, tmvp=1), 1, 1),
     ("x2_wavefront_slice_threads", 416, 240, 832, 480, 56, dict(n_pictures=4, gop=2, wpp=1), 4, 2),
+    # full size: a 4K base layer under an 8K enhancement layer (SURVEY.md 8 configs[4]'s SHVC half, 8 bit 4:2:0 as the reference's up-sampler)
+    ("uhd_to_8k_x2", 3840, 2160, 7680, 4320, 59, dict(n_pictures=3, gop=2, wpp=1), 8, 2),
     ("x1_5_tiny_ctb16", 96, 64, 144, 96, 57, dict(n_pictures=4, gop=2, log2_ctb_size=4, log2_max_tb_size=4), 1, 1),
 ]
 
@@ -96,7 +98,7 @@ def test_two_layer_streams_match_the_reference_library(name, w, h, ew, eh, seed,
     openHevcWrapper.c:139-152) are the reference library's, plane for plane — base-layer AND enhancement-layer pictures"""
     data, _ = streamgen.write_stream(w, h, seed, shvc_el_width=ew, shvc_el_height=eh, **kw)
     with refdec.captured_stderr():
-        want = refdec.decode(data)
+        want = refdec.decode(data, threads=threads, thread_type=ttype) if ew > 4000 else refdec.decode(data)      # (slice threads do not change its output: test_streams.py)
     got = refdec.decode(data, threads=threads, thread_type=ttype, L=refdec.hip_lib())
     assert len(got) == len(want) and len(want) > 0, (len(got), len(want))
     assert sum(p[0].shape == (eh, ew) for p in want) >= kw["n_pictures"] - 1, [p[0].shape for p in want]

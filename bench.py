@@ -206,14 +206,25 @@ def end_to_end(n_pictures=60):
                     "next to the reference's own library on the same file, the same loop and the same clock",
                front_end_threads=threads, cpu_model=cpu_model(), streams={})
 
-    def run(lib, path, ttype, extra=()):
-        r = subprocess.run([harness, "-i", path, "-F", lib, "-c", "-n", "-p", str(threads), "-f", str(ttype), *extra], capture_output=True, text=True, timeout=600)
-        last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    def run(lib, path, ttype, extra=(), passes=3):
+        """one child process; passes > 1: the file is decoded that many times in a row through the same decoder (ohevc_dec -l): the first pass
+        is a cold start (the decoder's frame-buffer pools are empty: every picture's host buffers are new memory, page-faulted in on first
+        touch — for the drop-in library and the reference alike), the later ones are the steady state of a long stream"""
+        r = subprocess.run([harness, "-i", path, "-F", lib, "-c", "-n", "-p", str(threads), "-f", str(ttype), "-l", str(passes), *extra],
+                           capture_output=True, text=True, timeout=900)
+        lines = r.stdout.strip().splitlines()
+        last = lines[-1] if lines else ""
         if r.returncode != 0 or not last.startswith("frame= "):
             return dict(error=(r.stdout[-300:] + r.stderr[-300:]).strip())
         f = last.split()
         n, t = int(f[1]), float(f[5])
-        return dict(frames=n, seconds=t, fps=round(n / t, 2) if t > 0 else None)
+        rec = dict(frames=n, seconds=t, fps=round(n / t, 2) if t > 0 else None, passes=passes)
+        per = [ln.split() for ln in lines if ln.startswith("pass ")]          # "pass k: N pictures released in T s = F fps"
+        if len(per) >= 2:
+            rec["fps_first_pass_cold"] = float(per[0][-2])
+            steady_n = sum(int(q[2]) for q in per[1:]); steady_t = sum(float(q[6]) for q in per[1:])
+            rec["fps_steady"] = round(steady_n / steady_t, 2) if steady_t > 0 else None
+        return rec
 
     for name, (w, h) in (("2160p_main10", (3840, 2160)), ("4320p_main10", (7680, 4320))):
         t0 = time.perf_counter()
@@ -224,7 +235,7 @@ def end_to_end(n_pictures=60):
             path = fh.name
         del data
         try:
-            run(libs["dropin"], path, 1)                                              # warm-up: library load, file cache
+            run(libs["dropin"], path, 1, passes=1)                                    # warm-up: library load, file cache
             # decode only: pictures stay in HBM (as `hevc -n` never looks at them); _with_output: every released picture fetched into
             # host planes (libOpenHevcGetOutput).  Front end on the reference's FRAME threads (every worker records its own picture;
             # recording needs no reference samples, so its motion-compensation waits fall away) and on its slice / wavefront threads
@@ -235,12 +246,12 @@ def end_to_end(n_pictures=60):
             for k in ("reference_sse", "reference_c"):
                 if os.path.exists(libs[k]):
                     rec[k + "_slice_threads"] = run(libs[k], path, 2)
-                    rec[k + "_frame_threads"] = run(libs[k], path, 1)
+                    rec[k + "_frame_threads"] = run(libs[k], path, 1, passes=1)      # an order of magnitude behind its slice threads: one pass
         finally:
             os.unlink(path)
         for k, v in rec.items():
             if isinstance(v, dict) and v.get("fps"):
-                v["Mpixels_per_s"] = round(v["fps"] * w * h / 1e6, 1)
+                v["Mpixels_per_s"] = round((v.get("fps_steady") or v["fps"]) * w * h / 1e6, 1)
         out["streams"][name] = rec
     # SHVC: a two-layer stream, 1080p base layer + 2160p enhancement layer (x2 spatial scalability, 8 bit 4:2:0 — what
     # the reference's up-sampler is written for); both layers' pictures go through the engine, the inter-layer reference picture is resampled in
@@ -264,17 +275,22 @@ def end_to_end(n_pictures=60):
             os.unlink(path)
         for k, v in rec.items():
             if isinstance(v, dict) and v.get("fps"):
-                v["Mpixels_per_s_both_layers"] = round(v["fps"] * (1920 * 1088 + 3840 * 2176) / 1e6, 1)
+                v["Mpixels_per_s_both_layers"] = round((v.get("fps_steady") or v["fps"]) * (1920 * 1088 + 3840 * 2176) / 1e6, 1)
         out["streams"]["shvc_1080p_to_2160p"] = rec
     except Exception as ex:                                    # the figure is an extra: never the reason a bench run fails
         out["streams"]["shvc_1080p_to_2160p"] = dict(error=repr(ex)[:300])
     r8 = out["streams"].get("4320p_main10", {})
-    fps8 = (r8.get("dropin_frame_threads") or {}).get("fps")
-    fps8o = (r8.get("dropin_frame_threads_with_output") or {}).get("fps")
-    out["north_star_8K60"] = dict(target_fps=60, measured_fps_decode=fps8, measured_fps_with_every_picture_fetched_to_host=fps8o,
-                                  met_decode=bool(fps8 and fps8 >= 60), met_with_output=bool(fps8o and fps8o >= 60),
-                                  note="end to end on ONE stream the host front end (the reference's CABAC / syntax / motion derivation on slice threads) sets the pace: "
-                                       "the GPU passes of a picture take a fraction of its parse time (compare the headline: thousands of pictures per second over work lists)")
+    d8, o8 = r8.get("dropin_frame_threads") or {}, r8.get("dropin_frame_threads_with_output") or {}
+    out["north_star_8K60"] = dict(target_fps=60,
+                                  steady_fps_decode=d8.get("fps_steady"), steady_fps_with_every_picture_fetched_to_host=o8.get("fps_steady"),
+                                  cold_start_fps_decode=d8.get("fps_first_pass_cold"), cold_start_fps_with_every_picture_fetched_to_host=o8.get("fps_first_pass_cold"),
+                                  met_decode=bool(d8.get("fps_steady") and d8["fps_steady"] >= 60), met_with_output=bool(o8.get("fps_steady") and o8["fps_steady"] >= 60),
+                                  met_decode_cold_start=bool(d8.get("fps_first_pass_cold") and d8["fps_first_pass_cold"] >= 60),
+                                  met_with_output_cold_start=bool(o8.get("fps_first_pass_cold") and o8["fps_first_pass_cold"] >= 60),
+                                  note="steady = passes 2-3 of the 60-picture stream decoded three times in a row through one decoder; cold start = the first pass, in which every "
+                                       "picture's host frame buffers (100 MB at 8K Main 10) are new memory. End to end on ONE stream the host front end (the reference's CABAC / syntax / "
+                                       "motion derivation on its frame threads) sets the pace: the GPU passes of a picture take a fraction of its parse time (compare the headline: "
+                                       "thousands of pictures per second over work lists)")
     return out
 
 

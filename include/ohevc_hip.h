@@ -89,6 +89,16 @@ int oh_pic_download(OhEngine *e, int pic_id, uint8_t *const planes[3], const ptr
  * The copy goes through a pinned staging buffer of the engine. */
 typedef struct OhWindow { int32_t left, right, top, bottom; } OhWindow;     /* luma samples, as HEVCWindow after hevc_ps.c scaled it */
 int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *win, uint8_t *const planes[3], const ptrdiff_t strides[3]);
+/* The same fetch in two halves, for a decoder whose threads share one engine behind a lock (an engine is driven by one thread at a
+ * time): oh_pic_download_start — under that lock, microseconds — enqueues the device-to-host copies behind the batch that finished the
+ * picture; oh_download_finish may then run on ANY thread WITHOUT the lock, while other threads hand pictures over: it waits for the
+ * copies, moves the rows into the caller's planes (OHEVC_FETCH_THREADS copy helpers, default 3, plus the calling thread) and returns
+ * the staging buffer.  Every started download must be finished (also to release it: planes = NULL gives OH_E_ARG after the wait).
+ * With frame threads this takes the fetch of a released picture off the decoder's serial path (openHevcWrapper.c:338-398 is called
+ * between two libOpenHevcDecode calls while the workers keep decoding). */
+typedef struct OhDownload OhDownload;
+int oh_pic_download_start(OhEngine *e, int pic_id, const OhWindow *win, OhDownload **out);
+int oh_download_finish(OhEngine *e, OhDownload *d, uint8_t *const planes[3], const ptrdiff_t strides[3]);
 
 /* MD5 of the three planes of n finished pictures computed on the GPU — the digests of the decoded-picture-hash SEI (hevc.c:4146-4162,
  * calc_md5 hevc.c:4623-4638: whole coded planes, rows packed, little-endian samples).  digests: n x 3 x 16 bytes.  Waits for the engine. */

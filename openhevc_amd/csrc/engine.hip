@@ -181,6 +181,14 @@ struct OhEngine {
     uint32_t   *tickets = nullptr;
     uint64_t    ticket_seq = 0;
     CopyPool   *copiers = nullptr;      /* created with the first hand-over (OHEVC_COPY_THREADS helpers, default 2) */
+    /* output fetch (oh_pic_download_start / oh_download_finish): its own pinned buffers and copy helpers, usable while another thread
+     * drives the engine */
+    std::mutex  dl_mu, dl_copy_mu;
+    std::vector<Stage *> dl_stages;
+    CopyPool   *dl_copiers = nullptr;   /* created with the first fetch (OHEVC_FETCH_THREADS helpers, default 3) */
+    std::vector<CopyJob> dl_jobs;
+    double      dl_wait_ms = 0, dl_copy_ms = 0;     /* OHEVC_FETCH_TIMING: where the time of the fetches went (printed when the engine is destroyed) */
+    uint64_t    dl_count = 0;
     std::vector<CopyJob> copy_jobs;
     uint32_t   *kerr = nullptr;
     uint32_t    spin_limit = 1u << 22;   /* polls (with s_sleep between them, ~1 s in all) before a waiting workgroup gives up; OHEVC_SPIN_LIMIT */
@@ -411,7 +419,12 @@ extern "C" void oh_engine_destroy(OhEngine *e)
     for (auto &a : e->arenas) { if (a.free_ev) (void)hipEventDestroy(a.free_ev); (void)hipFree(a.p); }
     for (auto &ev : e->sync_events) (void)hipEventDestroy(ev);
     for (void *b : e->sum_pool) (void)hipHostFree(b);
+    if (e->dl_count && getenv("OHEVC_FETCH_TIMING"))
+        fprintf(stderr, "ohevc engine: %llu output fetches, per fetch %.2f ms waiting for the picture's passes and its device-to-host copy, %.2f ms moving the rows into the caller's planes\n",
+                (unsigned long long)e->dl_count, e->dl_wait_ms / e->dl_count, e->dl_copy_ms / e->dl_count);
     delete e->copiers;
+    delete e->dl_copiers;
+    for (auto *c : e->dl_stages) { (void)hipEventDestroy(c->done); (void)hipHostFree(c->p); delete c; }
     if (e->kerr) (void)hipHostFree(e->kerr);
     if (e->tickets) (void)hipFree(e->tickets);
     for (auto &ev : e->batch_ev) if (ev) (void)hipEventDestroy(ev);
@@ -734,10 +747,25 @@ static OhEngine::Stage *stage_acquire(OhEngine *e, size_t bytes)
  * plane pointers advanced by (left >> hshift, top >> vshift)) followed by libOpenHevcGetOutputCpy's packed row copies
  * (openHevcWrapper.c:353-398: `height >> vshift` rows of `(width >> hshift) << pixel_shift` bytes, width / height = the cropped
  * size).  One strided device-to-pinned copy per plane, one wait, then the rows go to the caller's pitches. */
-extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *win, uint8_t *const planes[3], const ptrdiff_t strides[3])
+/* The output fetch in two halves, for a decoder whose threads share ONE engine behind a lock (the drop-in library: frame-thread
+ * workers hand pictures over while the application's thread fetches the one that was released):
+ *   oh_pic_download_start   (under the caller's engine lock, microseconds) validates, takes a pinned DOWNLOAD staging buffer — a list
+ *                           of its own, guarded by its own mutex — and enqueues the strided device-to-host copies behind the batch
+ *                           that finished the picture (download stream), then records an event;
+ *   oh_download_finish      (NO engine lock needed, any thread) waits for that event, copies the rows into the caller's planes with
+ *                           the download copy helpers, and gives the staging buffer back.
+ * oh_pic_download_window is the two in a row. */
+struct OhDownload {
+    OhEngine::Stage *sg;
+    size_t row[3], rows[3], off[3];
+    int np;
+};
+
+extern "C" int oh_pic_download_start(OhEngine *e, int pic_id, const OhWindow *win, OhDownload **out)
 {
-    if (!e || !win || !planes || !strides)
+    if (!e || !win || !out)
         return OH_E_ARG;
+    *out = nullptr;
     Pic *p = get_pic(e, pic_id);
     if (!p)
         FAIL(e, OH_E_ARG, "oh_pic_download_window: unknown picture %d", pic_id);
@@ -747,18 +775,32 @@ extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *w
              p->p.width, p->p.height);
     HIPCHK(e, hipSetDevice(e->device));
     const size_t bpp = p->p.bit_depth > 8 ? 2 : 1;
-    const int np = p->p.chroma_format_idc ? 3 : 1;
-    size_t row[3], rows[3], off[3], total = 0;
-    for (int c = 0; c < np; c++) {
+    OhDownload d;
+    d.np = p->p.chroma_format_idc ? 3 : 1;
+    size_t total = 0;
+    for (int c = 0; c < d.np; c++) {
         const int hs = oh_hshift(&p->p, c), vs = oh_vshift(&p->p, c);
-        row[c] = (size_t)(W >> hs) * bpp; rows[c] = (size_t)(H >> vs);
-        if ((ptrdiff_t)row[c] > strides[c] || !planes[c])
-            FAIL(e, OH_E_ARG, "oh_pic_download_window: plane %d pitch %td < %zu bytes", c, strides[c], row[c]);
-        off[c] = total; total += align_up(row[c] * rows[c], 256);
+        d.row[c] = (size_t)(W >> hs) * bpp; d.rows[c] = (size_t)(H >> vs);
+        d.off[c] = total; total += align_up(d.row[c] * d.rows[c], 256);
     }
-    OhEngine::Stage *sg = stage_acquire(e, total);
-    if (!sg)
-        FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", total);
+    {   /* a free download buffer that fits, else a new one (a decoder has one or two fetches in flight) */
+        std::lock_guard<std::mutex> lk(e->dl_mu);
+        d.sg = nullptr;
+        for (auto *c : e->dl_stages)
+            if (!c->busy && c->bytes >= total && (!d.sg || c->bytes < d.sg->bytes)) d.sg = c;
+        if (!d.sg) {
+            OhEngine::Stage *c = new OhEngine::Stage();
+            c->bytes = align_up(total, (size_t)4 << 20); c->busy = false; c->p = nullptr; c->done = nullptr;
+            if (hipHostMalloc(&c->p, c->bytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+                if (c->p) (void)hipHostFree(c->p);
+                delete c;
+                FAIL(e, OH_E_NOMEM, "hipHostMalloc(%zu) failed", total);
+            }
+            e->dl_stages.push_back(c);
+            d.sg = c;
+        }
+        d.sg->busy = true;
+    }
     /* a picture a batch of this engine finished, and whose event is still in the ring: the copies run on the download stream behind
      * THAT batch; anything else (uploaded, up-sampled, received from another GPU, long ago): behind everything on the engine stream */
     hipStream_t dl = e->stream;
@@ -767,21 +809,84 @@ extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *w
         HIPCHK(e, hipStreamWaitEvent(e->dl_stream, e->batch_ev[p->done_seq % OhEngine::BATCH_RING], 0));
         dl = e->dl_stream;
     }
-    for (int c = 0; c < np; c++) {
+    hipError_t he = hipSuccess;
+    for (int c = 0; c < d.np && he == hipSuccess; c++) {
         const int hs = oh_hshift(&p->p, c), vs = oh_vshift(&p->p, c);
         const uint8_t *src = (const uint8_t *)(p->final_b ? p->b[c] : p->a[c]) + ((size_t)(win->top >> vs) * p->stride[c] + (size_t)(win->left >> hs)) * bpp;
-        HIPCHK(e, hipMemcpy2DAsync((char *)sg->p + off[c], row[c], src, (size_t)p->stride[c] * bpp, row[c], rows[c], hipMemcpyDeviceToHost, dl));
+        he = hipMemcpy2DAsync((char *)d.sg->p + d.off[c], d.row[c], src, (size_t)p->stride[c] * bpp, d.row[c], d.rows[c], hipMemcpyDeviceToHost, dl);
     }
-    HIPCHK(e, hipStreamSynchronize(dl));
-    { const int ke = kernel_error(e); if (ke) return ke; }     /* a kernel that gave up: these samples are not the picture */
-    for (int c = 0; c < np; c++) {
-        const char *s = (const char *)sg->p + off[c];
-        if ((size_t)strides[c] == row[c])
-            memcpy(planes[c], s, row[c] * rows[c]);
-        else
-            for (size_t y = 0; y < rows[c]; y++) memcpy(planes[c] + (ptrdiff_t)y * strides[c], s + y * row[c], row[c]);
+    if (he == hipSuccess) he = hipEventRecord(d.sg->done, dl);
+    if (he != hipSuccess) {
+        std::lock_guard<std::mutex> lk(e->dl_mu);
+        d.sg->busy = false;
+        FAIL(e, OH_E_HIP, "oh_pic_download_window: %s", hipGetErrorString(he));
     }
+    *out = new OhDownload(d);
     return OH_OK;
+}
+
+extern "C" int oh_download_finish(OhEngine *e, OhDownload *d, uint8_t *const planes[3], const ptrdiff_t strides[3])
+{
+    if (!e || !d)
+        return OH_E_ARG;
+    int rc = OH_OK;
+    if (!planes || !strides)
+        rc = OH_E_ARG;
+    for (int c = 0; c < d->np && !rc; c++)
+        if (!planes[c] || (ptrdiff_t)d->row[c] > strides[c])
+            rc = OH_E_ARG;
+    const auto t_w0 = std::chrono::steady_clock::now();
+    const hipError_t he = hipEventSynchronize(d->sg->done);    /* also when the arguments are bad: the buffer goes back only after its copy */
+    const auto t_w1 = std::chrono::steady_clock::now();
+    if (!rc && he != hipSuccess) rc = OH_E_HIP;
+    if (!rc) rc = kernel_error(e);                             /* a kernel that gave up: these samples are not the picture */
+    if (!rc) {
+        std::lock_guard<std::mutex> lk(e->dl_copy_mu);         /* one fetch at a time uses the helpers */
+        if (!e->dl_copiers) {
+            const char *v = getenv("OHEVC_FETCH_THREADS");
+            const int n = v ? atoi(v) : 3;
+            e->dl_copiers = new CopyPool();
+            e->dl_copiers->start(n < 0 ? 0 : (n > 15 ? 15 : n));
+        }
+        /* pieces of at most 1 MiB (packed planes) or single rows (pitched planes), dealt round-robin to the helpers and this thread */
+        std::vector<CopyJob> &jobs = e->dl_jobs;
+        jobs.clear();
+        for (int c = 0; c < d->np; c++) {
+            const char *src = (const char *)d->sg->p + d->off[c];
+            if ((size_t)strides[c] == d->row[c]) {
+                const size_t n = d->row[c] * d->rows[c], piece = (size_t)1 << 20;
+                for (size_t o = 0; o < n; o += piece) jobs.push_back(CopyJob{ (char *)planes[c] + o, src + o, n - o < piece ? n - o : piece, false });
+            } else {
+                for (size_t y = 0; y < d->rows[c]; y++) jobs.push_back(CopyJob{ (char *)planes[c] + (ptrdiff_t)y * strides[c], src + y * d->row[c], d->row[c], false });
+            }
+        }
+        e->dl_copiers->run(jobs);
+        e->dl_wait_ms += std::chrono::duration<double, std::milli>(t_w1 - t_w0).count();
+        e->dl_copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w1).count();
+        e->dl_count++;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->dl_mu);
+        d->sg->busy = false;
+    }
+    delete d;
+    return rc;
+}
+
+extern "C" int oh_pic_download_window(OhEngine *e, int pic_id, const OhWindow *win, uint8_t *const planes[3], const ptrdiff_t strides[3])
+{
+    if (!e || !win || !planes || !strides)
+        return OH_E_ARG;
+    OhDownload *d = nullptr;
+    const int rc = oh_pic_download_start(e, pic_id, win, &d);
+    if (rc)
+        return rc;
+    const int rc2 = oh_download_finish(e, d, planes, strides);
+    if (rc2 == OH_E_ARG)
+        FAIL(e, OH_E_ARG, "oh_pic_download_window: a destination plane is missing or its pitch is smaller than a row");
+    if (rc2 == OH_E_HIP)
+        FAIL(e, OH_E_HIP, "oh_pic_download_window: the device-to-host copy failed");
+    return rc2;
 }
 
 /* Picture hash on the GPU: the three plane digests of the reference's SEI check (hevc.c:4146-4162 over calc_md5,

@@ -59,13 +59,14 @@ static struct {
 
 static void usage(const char *prog)
 {
-    printf("%s: -i <file> -F <library> [-b] [-c] [-f <type>] [-g] [-n] [-o <output file>] [-p <threads>] [-s <num>]\n", prog);
+    printf("%s: -i <file> -F <library> [-b] [-c] [-f <type>] [-g] [-l <passes>] [-n] [-o <output file>] [-p <threads>] [-s <num>]\n", prog);
     printf("     -b : boundary strengths on the GPU (drop-in library)\n");
     printf("     -c : no check md5\n");
     printf("     -f <thread type> (1: frame, 2: slice, 4: frameslice)\n");
     printf("     -F <shared object exporting the libOpenHevc* API (openHevcWrapper.h)>\n");
     printf("     -g : get every released picture (libOpenHevcGetOutput)\n");
     printf("     -i <input file>\n");
+    printf("     -l <passes> : decode the file that many times in a row (fps per pass)\n");
     printf("     -n : no display (there is none)\n");
     printf("     -o <output file>\n");
     printf("     -p <number of threads> \n");
@@ -118,11 +119,11 @@ static void log_capture_end(void)
 int main(int argc, char **argv)
 {
     const char *input = NULL, *library = NULL, *output = NULL;
-    int check_md5 = 1, num_frames = 0, nb_pthreads = 1, thread_type = 1, bs_on_gpu = 0, get_output = 0;
+    int check_md5 = 1, num_frames = 0, nb_pthreads = 1, thread_type = 1, bs_on_gpu = 0, get_output = 0, loops = 1;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         if (a[0] != '-' || !a[1] || a[2]) { usage(argv[0]); return 2; }
-        const int need = strchr("iFospf", a[1]) != NULL;
+        const int need = strchr("iFospfl", a[1]) != NULL;
         if (need && i + 1 >= argc) { usage(argv[0]); return 2; }
         switch (a[1]) {
         case 'b': bs_on_gpu = 1; break;
@@ -135,6 +136,7 @@ int main(int argc, char **argv)
         case 's': num_frames = atoi(argv[++i]); break;
         case 'p': nb_pthreads = atoi(argv[++i]); break;
         case 'f': thread_type = atoi(argv[++i]); break;
+        case 'l': loops = atoi(argv[++i]); if (loops < 1) loops = 1; break;
         default: usage(argv[0]); return 2;
         }
     }
@@ -183,9 +185,20 @@ int main(int argc, char **argv)
     memset(&cpy, 0, sizeof(cpy));
     int nb_frame = 0, width = -1, height = -1, stop = 0;
     const double t0 = now_s();
-    for (long k = 0; !stop; k++) {                           /* k >= n_au: flushing with empty packets (main.c:225) */
-        const int flushing = k >= n_au;
-        const int got_picture = api.Decode(h, flushing ? NULL : data + au[k], flushing ? 0 : (int)(au[k + 1] - au[k]), k);
+    /* -l N: the file is decoded N times in a row through the same decoder, as if concatenated (a stream opens with an IDR picture and its
+     * parameter sets): the passes after the first show the decoder with its buffer pools filled */
+    const long n_total = n_au * loops;
+    double t_pass = t0;
+    int frames_pass = 0;
+    for (long k = 0; !stop; k++) {                           /* k >= n_total: flushing with empty packets (main.c:225) */
+        const int flushing = k >= n_total;
+        const long ka = flushing ? 0 : k % n_au;
+        if (loops > 1 && k > 0 && k <= n_total && k % n_au == 0) {
+            const double tn = now_s();
+            printf("pass %ld: %d pictures released in %.3f s = %.1f fps\n", k / n_au, nb_frame - frames_pass, tn - t_pass, (nb_frame - frames_pass) / (tn - t_pass));
+            t_pass = tn; frames_pass = nb_frame;
+        }
+        const int got_picture = api.Decode(h, flushing ? NULL : data + au[ka], flushing ? 0 : (int)(au[ka + 1] - au[ka]), k);
         if (got_picture < 0) { fprintf(stderr, "decoder failed on access unit %ld\n", k); rc = 1; break; }
         if (got_picture > 0) {
             api.GetPictureInfo(h, &frame.frameInfo);

@@ -511,25 +511,28 @@ __attribute__((visibility("default"))) int oh_hooked_fetch_output(AVFrame *out)
         const ptrdiff_t off = out->data[0] - E.pic[i].base;
         if (off >= 0 && (size_t)off < E.pic[i].span) hit = i;
     }
-    for (int i = hit; i >= 0 && i == hit && E.e; i++) {
-        const ptrdiff_t off = out->data[0] - E.pic[i].base;
-        if (out->linesize[0] <= 0)
-            break;
-        const OhPicParams *p = &E.pic[i].p;
+    OhDownload *dl = NULL;
+    ptrdiff_t strides[3] = { out->linesize[0], out->linesize[1], out->linesize[2] };
+    uint8_t *planes[3] = { out->data[0], out->data[1], out->data[2] };
+    if (hit >= 0 && E.e && out->linesize[0] > 0) {
+        const ptrdiff_t off = out->data[0] - E.pic[hit].base;
+        const OhPicParams *p = &E.pic[hit].p;
         const int ps = p->bit_depth > 8;
         const int y = (int)(off / out->linesize[0]), x = (int)(off % out->linesize[0]) >> ps;
         const OhWindow win = { x, p->width - x - out->width, y, p->height - y - out->height };
-        ptrdiff_t strides[3] = { out->linesize[0], out->linesize[1], out->linesize[2] };
-        uint8_t *planes[3] = { out->data[0], out->data[1], out->data[2] };
         if (win.right < 0 || win.bottom < 0)
             fprintf(stderr, "libopenhevc_hip: output window %dx%d+%d+%d leaves the %dx%d picture\n", out->width, out->height, x, y, p->width, p->height);
-        else if (oh_pic_download_window(E.e, E.pic[i].id, &win, planes, strides) != OH_OK)
+        else if (oh_pic_download_start(E.e, E.pic[hit].id, &win, &dl) != OH_OK)     /* the copies are enqueued behind the picture's batch ... */
             fprintf(stderr, "libopenhevc_hip: %s\n", oh_engine_last_error(E.e));
-        else
-            rc = 0;
-        break;
     }
+    OhEngine *eng = E.e;
     pthread_mutex_unlock(&E.lock);
+    /* ... and waited for WITHOUT the engine lock: the frame-thread workers keep handing their pictures over meanwhile */
+    if (dl) {
+        const int drc = oh_download_finish(eng, dl, planes, strides);
+        if (drc != OH_OK) fprintf(stderr, "libopenhevc_hip: fetching the output picture failed (%d)\n", drc);
+        else rc = 0;
+    }
     HT.fetch += hook_now() - t_g0;
     return rc;
 }

@@ -6,8 +6,8 @@ R=$PWD
 O=$R/gpurun_out/pmc
 mkdir -p $O
 cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/p_insts -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $O/bench_insts.json 2> $O/rocprof_insts.log
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_busy -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $O/bench_busy.json 2> $O/rocprof_busy.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/p_insts -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-end-to-end > $O/bench_insts.json 2> $O/rocprof_insts.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_busy -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-end-to-end > $O/bench_busy.json 2> $O/rocprof_busy.log
 python3 - <<PY
 import csv, glob, collections, os
 for d in ("/tmp/p_insts", "/tmp/p_busy"):

@@ -326,8 +326,9 @@ def main():
     ap.add_argument("--bs-from-motion", action="store_true", help="work lists carry the motion field instead of finished boundary-strength grids; "
                     "the engine derives the grids at upload (bs_kernel: inside the timed region in decode mode)")
     ap.add_argument("--pinned-lists", action="store_true", help="experiment: keep the host work lists in page-locked blocks from oh_host_alloc (OH_FRAME_PINNED, "
-                    "boundary strengths packed): the engine copies them by DMA from where they lie, array by array, instead of staging them on the host "
-                    "thread.  Measured SLOWER (fifteen small DMAs per picture keep the copy queue busy: 47 against 82 Gpixels/s): the default is ordinary host "
+                    "boundary strengths packed): the GPU pulls them over PCIe from where they lie (prep_pull, one launch per picture) instead of the host "
+                    "staging them.  Measured SLOWER: the host's share falls to 0.10 ms per picture, but beside the passes of the other batches the pull moves "
+                    "~30 GB/s where the copy engines move 41 (58-62 against 83 Gpixels/s; one DMA request per array: 47): the default is ordinary host "
                     "memory, staged into one pinned block by the calling thread and the engine's copy helpers, ONE DMA per picture")
     ap.add_argument("--host-threads", type=int, default=0, help="1: a single host thread enqueues every stream (default: one thread per stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -727,7 +728,7 @@ def main():
                                f"non-reference B pictures): {n_chains} GOPs per GPU and step",
                        "chains_in_flight_per_gpu": n_chains, "chains_asked_per_gpu": chains_asked, "streams_per_gpu": n_streams,
                        "host_work_lists": f"{n_host} distinct GOPs, {round(host_bytes / n_host / P.pictures_per_step(plan) / 1e6, 2)} MB per picture on average, held in "
-                                          + ("page-locked blocks lent by the engine (oh_host_alloc), boundary strengths packed four to the byte: handed over by DMA from where they lie"
+                                          + ("page-locked blocks lent by the engine (oh_host_alloc), boundary strengths packed four to the byte: pulled by the GPU from where they lie (prep_pull)"
                                              if args.pinned_lists else "ordinary host memory (staged into one pinned block by the calling thread + the engine's 2 copy helpers, one DMA per picture)"),
                        "batching": f"picture k of the {n_chains // n_streams} chains of a stream is one batch: one launch per pass",
                        "gop": args.gop,

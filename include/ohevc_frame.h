@@ -199,10 +199,11 @@ typedef struct OhFrame {
     uint32_t flags;                   /* OH_FRAME_*: how the arrays are held (0: ordinary host memory, byte grids) */
 } OhFrame;
 /* OhFrame.flags.
- * OH_FRAME_PINNED     every array the list points at lies in memory from oh_host_alloc() (ohevc_hip.h): the engine copies them to the
- *                     GPU by DMA straight from where they lie — no staging copy on the host.  They must stay untouched until the
- *                     list's copy has completed (oh_frames_execute of the list, or any wait on the engine, is behind it).  This is
- *                     the hand-over of a recorder that writes its lists into blocks the engine lent it.
+ * OH_FRAME_PINNED     every array the list points at lies in memory from oh_host_alloc() (ohevc_hip.h): the GPU pulls them over PCIe
+ *                     straight from where they lie (one kernel, prep.hip prep_pull) — no staging copy on the host, no DMA request
+ *                     per array.  They must stay untouched until the list's copy has completed (oh_frames_execute of the list, or
+ *                     any wait on the engine, is behind it).  This is the hand-over of a recorder that writes its lists into blocks
+ *                     the engine lent it.
  * OH_FRAME_BS_PACKED  vertical_bs / horizontal_bs hold the strengths FOUR TO THE BYTE (entry i in bits 2 (i & 3) of byte i >> 2,
  *                     (bs_size + 3) / 4 bytes each): the form they travel in and live in on the GPU (a strength is 0..2).  A
  *                     recorder packs them while it copies the decoder's byte grids (oh_pack_bs). */

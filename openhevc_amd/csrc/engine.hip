@@ -283,7 +283,7 @@ static int engine_create(OhEngine **out, int device, hipStream_t ext, bool use_e
         ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
     }
     if (ok)
-        ok = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        ok = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) == hipSuccess;     /* (highest priority for this stream: measured, no difference) */
     if (!ok || ohk_init() != 0) {
         fprintf(stderr, "ohevc_hip: device %d initialisation failed\n", device);
         delete e;
@@ -1264,7 +1264,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
      * where it lies, segment by segment: only what this function made itself (the header, the PU block offsets) is staged */
     auto t_alloc = tnow();
     const bool direct = (f->flags & OH_FRAME_PINNED) != 0 && !(has_db && !bsi && !bs_packed_in);     /* byte grids still have to be packed on the way */
-    const size_t own_bytes = align_up(sizeof(DevFrame), 256) + align_up(2 * ((size_t)f->n_pu + 1) * sizeof(uint32_t), 256);
+    const size_t own_bytes = align_up(sizeof(DevFrame), 256) + align_up(2 * ((size_t)f->n_pu + 1) * sizeof(uint32_t), 256) + 64 * sizeof(OhPullSeg);
     OhEngine::Stage *sg;
     { HostTimer t(e, OH_HT_UPLOAD_STAGE_WAIT);
     sg = stage_acquire(e, direct ? own_bytes : copy_bytes);   /* a pinned buffer whose previous copy has completed */
@@ -1280,20 +1280,29 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
     hipStream_t cs = e->copy_stream;
     hipError_t hrc = hipSuccess;
     if (direct) {
-        /* the two segments made here go through the staging buffer (they lie side by side at the head of the arena: one copy),
-         * every other one straight from the caller's pinned memory */
+        /* the GPU pulls the list: the two segments made here (header, PU block offsets) and the table of segments stand in the staging
+         * buffer, every other segment is read from the caller's pinned memory where it lies — ONE kernel launch (prep_pull), no host
+         * copy of the lists and no DMA request per array (fifteen of those per picture cost the host as much as the copy they replaced) */
+        OhPullSeg *tab;
+        int nt = 0;
+        size_t pulled = 0;
         { HostTimer t(e, OH_HT_UPLOAD_MEMCPY);
-        memcpy((char *)stage + seg[s_hdr].off, seg[s_hdr].src, seg[s_hdr].bytes);
+        char *sp = (char *)stage;
+        memcpy(sp, seg[s_hdr].src, seg[s_hdr].bytes);
+        char *po = sp + align_up(sizeof(DevFrame), 256);
+        if (seg[s_puoff].bytes) memcpy(po, seg[s_puoff].src, seg[s_puoff].bytes);
+        tab = (OhPullSeg *)(po + align_up(seg[s_puoff].bytes, 256));
+        tab[nt++] = OhPullSeg{ sp, (char *)df->arena, seg[s_hdr].bytes };
+        if (seg[s_puoff].bytes) tab[nt++] = OhPullSeg{ po, (char *)df->arena + seg[s_puoff].off, seg[s_puoff].bytes };
+        for (int i = 0; i < ns; i++)
+            if (i != s_hdr && i != s_puoff && seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes) {
+                tab[nt++] = OhPullSeg{ seg[i].src, (char *)df->arena + seg[i].off, seg[i].bytes };
+                pulled += seg[i].bytes;
+            }
         }
         HostTimer t_enq(e, OH_HT_UPLOAD_ENQUEUE);
-        hrc = hipMemcpyAsync(df->arena, stage, align_up(sizeof(DevFrame), 256), hipMemcpyHostToDevice, cs);
-        if (hrc == hipSuccess && seg[s_puoff].bytes) {
-            memcpy((char *)stage + align_up(sizeof(DevFrame), 256), seg[s_puoff].src, seg[s_puoff].bytes);
-            hrc = hipMemcpyAsync((char *)df->arena + seg[s_puoff].off, (char *)stage + align_up(sizeof(DevFrame), 256), seg[s_puoff].bytes, hipMemcpyHostToDevice, cs);
-        }
-        for (int i = 0; i < ns && hrc == hipSuccess; i++)
-            if (i != s_hdr && i != s_puoff && seg[i].bytes && seg[i].src && seg[i].off + seg[i].bytes <= copy_bytes)
-                hrc = hipMemcpyAsync((char *)df->arena + seg[i].off, seg[i].src, seg[i].bytes, hipMemcpyHostToDevice, cs);
+        ohk_pull(tab, nt, pulled, cs);
+        hrc = hipGetLastError();
     } else {
         { HostTimer t(e, OH_HT_UPLOAD_MEMCPY);
         if (!e->copiers) {

@@ -29,6 +29,9 @@ void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t ma
 void ohk_deblock(const OhBatch *B, int n, const OhPicParams *p, int horiz, hipStream_t st);
 void ohk_upsample_plane(const OhUpPlane *a, int taps, int tw, int th, const uint32_t *list, int n_list, hipStream_t st);
 void ohk_sao(const OhBatch *B, int n, const OhPicParams *p, hipStream_t st);
+/* one array of a page-locked work list: where it lies on the host, where it goes in the arena */
+struct OhPullSeg { const void *src; void *dst; uint64_t bytes; };
+void ohk_pull(const OhPullSeg *segs, int nseg, size_t total_bytes, hipStream_t st);
 void ohk_prepare(const OhBatch *B, int nb, const OhPrepCounts *max_counts, uint32_t max_mc_runs, uint32_t max_cross, hipStream_t st);
 void ohk_bs_derive(const OhPicParams *p, const void *mvf, const void *cbf, const void *call_log2, const void *ctb_flags,
                    int across_tiles, void *vbs, void *hbs, hipStream_t st);

@@ -627,6 +627,55 @@ __global__ __launch_bounds__(64) void prep_finish(const OhBatch B)
 /* =========================================================================================
  * launcher: everything for ONE work list, enqueued on `st` (the engine's copy stream, behind the list's H2D copy)
  * ======================================================================================= */
+/* ---- the hand-over of a work list that lies in page-locked host memory (OH_FRAME_PINNED): the GPU PULLS it.  A table of segments
+ * (host source, device destination, bytes) stands in the engine's pinned staging block; the workgroups copy them over PCIe in 16-byte
+ * units (a kernel reads pinned host memory at the copy engines' rate: 55-57 GB/s on this box, tools/pull_rate.hip) — one launch
+ * instead of one DMA request per array, and no staging copy on the host.  MEASURED: the host's share of the hand-over falls from 0.30 to
+ * 0.10 ms per 4K picture, but beside the passes of the other batches the pull's workgroups get few wave slots and move ~30 GB/s where
+ * the copy engines move 41: the bench decodes 58-62 Gpixels/s this way against 83 with the staged copy (fifteen DMA requests per
+ * picture: 47).  The staged copy stays the default; this is the path of OH_FRAME_PINNED lists. ---- */
+typedef unsigned int pull_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void prep_pull(const OhPullSeg *__restrict__ segs, const int nseg)
+{
+    for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
+        const OhPullSeg g = segs[s];
+        const unsigned stride = gridDim.x * 256u, first = blockIdx.x * 256u + threadIdx.x;
+        if ((((uintptr_t)g.src | (uintptr_t)g.dst) & 15) == 0) {
+            const pull_u4 *__restrict__ src = (const pull_u4 *)g.src;
+            pull_u4 *__restrict__ dst = (pull_u4 *)g.dst;
+            const unsigned n = (unsigned)(g.bytes >> 4);
+            /* four loads in flight per lane: the link's latency (microseconds) is what has to be covered, by few resident waves when the
+             * passes of other batches hold most of the wave slots */
+            unsigned i = first;
+            for (; i + 3 * stride < n; i += 4 * stride) {
+                const pull_u4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+                const pull_u4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+                dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+            }
+            for (; i < n; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+            for (unsigned k = (n << 4) + first; k < g.bytes; k += stride) ((uint8_t *)g.dst)[k] = ((const uint8_t *)g.src)[k];
+        } else if ((((uintptr_t)g.src | (uintptr_t)g.dst) & 3) == 0) {
+            const uint32_t *__restrict__ src = (const uint32_t *)g.src;
+            uint32_t *__restrict__ dst = (uint32_t *)g.dst;
+            const unsigned n = (unsigned)(g.bytes >> 2);
+            for (unsigned i = first; i < n; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+            for (unsigned i = (n << 2) + first; i < g.bytes; i += stride) ((uint8_t *)g.dst)[i] = ((const uint8_t *)g.src)[i];
+        } else {
+            for (unsigned i = first; i < g.bytes; i += stride) ((uint8_t *)g.dst)[i] = ((const uint8_t *)g.src)[i];
+        }
+    }
+}
+extern "C" void ohk_pull(const OhPullSeg *segs, int nseg, size_t total_bytes, hipStream_t st)
+{
+    if (nseg <= 0)
+        return;
+    /* 64 workgroups: alone on the chip even 8 x 32 workgroups fill the link (tools/pull_rate.hip: 55-57 GB/s); beside the passes of the
+     * batches in flight the pull gets ~30 GB/s whatever the grid (4 / 16 / 64 columns: 61.7 / 58.2 / 53.7 Gpixels/s in the bench) */
+    const unsigned gx = 4, gy = nseg < 16 ? (unsigned)nseg : 16;
+    (void)total_bytes;
+    hipLaunchKernelGGL(prep_pull, dim3(gx, gy), dim3(256), 0, st, segs, nseg);
+}
+
 extern "C" void ohk_prepare(const OhBatch *B, int nb, const OhPrepCounts *n, uint32_t max_mc_runs, uint32_t max_cross, hipStream_t st)
 {
     /* n: the LARGEST count of the batch per kind (every kernel bounds its index by the list's own count) */

@@ -125,6 +125,32 @@ def test_picture_parity(eng, case):
     rec.close()
 
 
+PINNED_CASES = ("i8", "b8_weighted", "b8_ctb16", "b12", "b10_444", "i8_mono", "b8_422_pcm_bypass", "tiny", "b10_cip_pcm", "b10_sparse_lists",
+                "i10_444_ccp_sparse", "b10_bs_from_motion", "b10_ctb16_slices", "b10_tiles_slices")
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in PINNED_CASES], ids=[c[0] for c in CASES if c[0] in PINNED_CASES])
+def test_pinned_lists_are_pulled_by_the_gpu(eng, case):
+    """OH_FRAME_PINNED: the same pictures with every array of the work list in page-locked memory from oh_host_alloc (boundary strengths
+    packed four to the byte): no staging copy on the host — prep_pull reads the arrays over PCIe from where they lie (odd sizes, tails
+    and every optional array included)"""
+    name, w, h, bd, chroma, lc, st, knobs = case
+    pcm = "pcm" in name
+    p = F.pic_params(w, h, bit_depth=bd, chroma_format_idc=chroma, log2_ctb_size=lc,
+                     pcm_loop_filter_disable=int(pcm), transquant_bypass_enable=int(pcm), constrained_intra_pred=int("cip" in name),
+                     cb_qp_offset=2 if "weighted" in name else 0, cr_qp_offset=-3 if "weighted" in name else 0)
+    rec = F.Recorder(p)
+    f = rec.synth(F.synth_params(st, 4100, **knobs), 2, [0, 1])
+    fc = F.FrameCopy(f, pinned_by=eng.L)
+    assert fc.frame.flags & F.OH_FRAME_PINNED
+    rng = np.random.default_rng(41)
+    pics = {0: F.HostPic(p, rng=rng), 1: F.HostPic(p, rng=rng), 2: F.HostPic(p, rng=rng)}
+    want, got = run_both(eng, p, fc.frame, pics)
+    assert_same(want, got, f"{name} pinned")
+    del fc
+    rec.close()
+
+
 @pytest.mark.parametrize("flavour", ["no_filters", "deblock_only", "sao_only"])
 def test_pass_switches(eng, flavour):
     """each in-loop filter can be switched off per picture (slice_deblocking_filter_disabled /

@@ -140,7 +140,11 @@ int oh_frame_release(OhEngine *e, OhDevFrame *df);
  * OhFrame.bs_in — the ones the engine derived from the motion field at upload (hevc_filter.c:584-941).
  * bytes: size of each destination, at most oh_bs_size() is copied */
 int oh_frame_download_bs(OhEngine *e, OhDevFrame *df, uint8_t *vbs, uint8_t *hbs, size_t bytes);
-int oh_frame_submit(OhEngine *e, const OhFrame *f);     /* upload + execute + deferred free */
+int oh_frame_submit(OhEngine *e, const OhFrame *f);     /* upload + execute + release in stream order: nothing of the list stays behind */
+/* what the engine holds for work lists: out[0] device arenas alive (pooled or holding a list), [1] their bytes, [2] of them free in the pool,
+ * [3] pinned staging buffers, [4] their bytes, [5] work lists waiting for a deferred free.  A decoder that submits and forgets one list
+ * per picture sees all of them level off after a few pictures, however long the stream. */
+int oh_engine_memory(OhEngine *e, uint64_t out[6]);
 
 /* per-pass device time of the executes since the last reset, measured with HIP events on the
  * engine stream (enable = 1 costs two event records per pass; enable = 2 additionally brackets every

@@ -73,8 +73,8 @@ typedef struct OhStreamParams {
     int32_t log2_min_cb_size;           /* 0 (= 3) or 3..5: smallest coding block (width and height are multiples of it); above 8x8 its inter
                                            partitions include NxN, its min PU / QP / PCM map granularity follows */
     int32_t shvc_el_width, shvc_el_height;   /* > 0: a TWO-LAYER stream (SHVC spatial scalability, the SHM 4.1 syntax the reference parses): this stream is
-                                           the base layer (8 bit 4:2:0, no window, not gop 3), every access unit also carries an enhancement-layer
-                                           picture of this size (>= the base layer's: x1 = SNR, x1.5, x2 or any ratio) whose P slices predict from the
+                                           the base layer (8 bit 4:2:0, no window, not gop 3, no range extensions), every access unit also carries an enhancement-layer
+                                           picture of this size (the base layer's to twice the base layer's, and more than one CTB + 16 samples each way: x1 = SNR, x1.5, x2 or any ratio between) whose P slices predict from the
                                            up-sampled base-layer picture only (zero motion vectors), plus intra blocks and residuals */
 } OhStreamParams;
 

@@ -159,6 +159,7 @@ struct OhEngine {
     hipStream_t copy_stream = nullptr;
     struct Arena { void *p; size_t bytes; hipEvent_t free_ev; };
     std::vector<Arena> arenas;               /* free device arenas */
+    uint64_t    arenas_alive = 0, arena_bytes_alive = 0;      /* device arenas allocated and not freed (pooled or holding a work list): oh_engine_memory */
     std::vector<hipEvent_t> sync_events;     /* pool of timing-disabled events (ready / free_ev) */
     std::vector<void *> sum_pool;            /* pinned OH_SUMMARY_BLOCK-byte blocks */
     double      host_ms[OH_N_HOST_TIMES] = {};   /* where the host time of the hand-over path goes (oh_engine_host_times) */
@@ -340,6 +341,17 @@ extern "C" int oh_engine_create_on_stream(OhEngine **out, int device, void *hip_
     return engine_create(out, device, (hipStream_t)hip_stream, true);
 }
 
+extern "C" int oh_engine_memory(OhEngine *e, uint64_t out[6])
+{
+    if (!e || !out)
+        return OH_E_ARG;
+    uint64_t sb = 0;
+    for (auto &c : e->stages) sb += c.bytes;
+    out[0] = e->arenas_alive; out[1] = e->arena_bytes_alive; out[2] = e->arenas.size();
+    out[3] = e->stages.size(); out[4] = sb; out[5] = e->deferred.size();
+    return OH_OK;
+}
+
 extern "C" const char *oh_engine_last_error(const OhEngine *e) { return e ? e->err.c_str() : "no engine"; }
 extern "C" void *oh_engine_stream(OhEngine *e) { return e ? (void *)e->stream : nullptr; }
 
@@ -380,6 +392,7 @@ static void free_dev_frame(OhEngine *e, OhDevFrame *df, bool in_flight = false)
         } else {
             if (in_flight) (void)hipStreamSynchronize(e->stream);
             (void)hipFree(df->arena);
+            if (e) { e->arenas_alive--; e->arena_bytes_alive -= df->arena_bytes; }
         }
     }
     delete df;
@@ -1172,6 +1185,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
         total += align_up(oh_sao_stale_index(&p, 3, 0, 0) * sizeof(uint16_t), 256);
 
     auto t_lists = tnow();
+    bool best_was_new = false;
     OhDevFrame *df = new OhDevFrame();
     {   /* a pooled arena that fits (within 2x), else a new one rounded up to 1 MiB */
         HostTimer t(e, OH_HT_UPLOAD_ARENA);
@@ -1179,6 +1193,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
          * need not wait for the engine stream; the most recently released one would stall the copy stream behind the passes
          * of the batch that just let go of it */
         int best = -1;
+        best_was_new = false;
         for (size_t i = 0; i < e->arenas.size() && best < 0; i++)
             if (e->arenas[i].bytes >= total && e->arenas[i].bytes <= 2 * total + (1u << 20))
                 best = (int)i;
@@ -1192,10 +1207,11 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             }
             e->arenas.erase(e->arenas.begin() + best);
         } else {
+            best_was_new = true;
             df->arena_bytes = align_up(total, (size_t)1 << 20);
             if (hipMalloc(&df->arena, df->arena_bytes) != hipSuccess) {
                 (void)hipStreamSynchronize(e->stream);
-                for (auto &a : e->arenas) { sync_event_put(e, a.free_ev); (void)hipFree(a.p); }      /* the pool may be what is in the way */
+                for (auto &a : e->arenas) { sync_event_put(e, a.free_ev); (void)hipFree(a.p); e->arenas_alive--; e->arena_bytes_alive -= a.bytes; }      /* the pool may be what is in the way */
                 e->arenas.clear();
                 if (hipMalloc(&df->arena, df->arena_bytes) != hipSuccess) {
                     df->arena = nullptr;
@@ -1205,6 +1221,7 @@ static int upload_one(OhEngine *e, const OhFrame *f, OhDevFrame **out)
             }
         }
     }
+    if (best_was_new) { e->arenas_alive++; e->arena_bytes_alive += df->arena_bytes; }
     char *base = (char *)df->arena;
     hd.pp = p;
     fill_planes(&hd.cur, cur, false);

@@ -72,6 +72,7 @@ def lib():
         L.oh_engine_pass_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
         L.oh_engine_intra_launch_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I]
         L.oh_engine_host_times.argtypes = [V, C.POINTER(C.c_double), C.POINTER(C.c_uint64), I, I]
+        L.oh_engine_memory.argtypes = [V, C.POINTER(C.c_uint64)]
         L.oh_engine_upload_bytes.argtypes = [V, I]
         L.oh_engine_upload_bytes.restype = C.c_uint64
         L.oh_engine_stream.argtypes = [V]
@@ -192,6 +193,12 @@ class Engine:
     def pic_upsample(self, dst_pid, src_pid, u):
         """SHVC inter-layer reference: resample picture src_pid into dst_pid (u: frame.upsample_setup)"""
         self._chk(self.L.oh_pic_upsample(self.h, dst_pid, src_pid, C.byref(u)), "oh_pic_upsample")
+
+    def memory(self):
+        """oh_engine_memory: what the engine holds for work lists (arenas alive, their bytes, free in the pool, staging buffers, their bytes, deferred lists)"""
+        out = (C.c_uint64 * 6)()
+        self._chk(self.L.oh_engine_memory(self.h, out), "oh_engine_memory")
+        return dict(zip(("arenas", "arena_bytes", "arenas_free", "stages", "stage_bytes", "deferred"), map(int, out)))
 
     # ---- work lists ----
     def pic_upsample_ctbs(self, dst_pid, src_pid, u, log2_ctb_size, ctb_addrs):

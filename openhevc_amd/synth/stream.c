@@ -1541,7 +1541,15 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
     W we;
     memset(&we, 0, sizeof(we));
     if (two) {
-        if (p->bit_depth != 8 || p->chroma_format_idc != 1 || p->gop == 3 || p->shvc_el_width < p->width || p->shvc_el_height < p->height ||
+        /* refused beyond the obvious: (1) the range extensions — the reference parses the extension bits of a layer-1 PPS / SPS as something
+         * else ("PPS extension flag is partially implemented"), the enhancement layer would be decoded out of step; (2) an enhancement layer
+         * of a single CTB row or column — the reference's block up-sampler emulates ONE picture edge per block and direction
+         * (videodsp_template.c:110-116, 141-151 return after the left / top edge), a block that touches both reads samples nobody wrote;
+         * (3) ratios above 2 — the reference's CTB path and its whole-picture slot then produce different chroma rows at the picture's
+         * bottom (the engine follows the whole-picture slot: tests/test_upsample_vs_ref.py), so there is no single reference output */
+        const int ctb = 1 << (p->log2_ctb_size ? p->log2_ctb_size : 6);
+        if (rext_profile(p) || p->shvc_el_width < ctb + 16 || p->shvc_el_height < ctb + 16 || p->shvc_el_width > 2 * p->width || p->shvc_el_height > 2 * p->height ||
+            p->bit_depth != 8 || p->chroma_format_idc != 1 || p->gop == 3 || p->shvc_el_width < p->width || p->shvc_el_height < p->height ||
             (p->shvc_el_width & ((1 << mcb_log2) - 1)) || (p->shvc_el_height & ((1 << mcb_log2) - 1)) || p->trace || p->levels ||
             p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom) {
             w_free(&w);

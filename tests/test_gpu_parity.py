@@ -185,6 +185,37 @@ def test_golden_pictures(eng):
         rec.close()
 
 
+def test_submit_and_forget_keeps_the_engines_memory_bounded():
+    """a decoder hands one work list per picture to oh_frame_submit and forgets it: over a long stream the device arenas, the pinned
+    staging buffers and the deferred lists level off (stream-ordered release into the pools), and the last picture is still right"""
+    from openhevc_amd.engine import Engine, remap_frame
+    e = Engine(0)
+    p = F.pic_params(416, 240)
+    rec = F.Recorder(p)
+    rng = np.random.default_rng(3)
+    host = {k: F.HostPic(p, rng=rng) for k in range(3)}
+    ids = {k: e.pic_alloc(p) for k in host}
+    for k in (0, 1):
+        e.pic_upload(ids[k], host[k])
+    lists = [F.FrameCopy(rec.synth(F.synth_params(2 if k % 4 else 0, 700 + k), 2, [0, 1])) for k in range(6)]
+    seen = []
+    for n in range(400):
+        e.frame_submit(remap_frame(lists[n % len(lists)].frame, ids))
+        if n in (99, 199, 399):
+            seen.append(e.memory())
+    e.sync()
+    m = e.memory()
+    assert m["deferred"] == 0 and all(s["deferred"] == 0 for s in seen), seen
+    assert seen[2]["arenas"] <= max(seen[0]["arenas"], 8) + 2 and seen[2]["arenas"] <= 64, seen           # no arena per picture
+    assert seen[2]["stages"] <= max(seen[0]["stages"], 8) + 2 and seen[2]["stages"] <= 64, seen
+    got = e.pic_download(ids[2], p)
+    want = {k: v.copy() for k, v in host.items()}
+    assert oracle().oh_or_frame(C.byref(lists[399 % len(lists)].frame), host_pic_array(want)) == 0
+    assert_same(want[2], got, "picture 400")
+    e.close()
+    rec.close()
+
+
 def test_reference_chain_and_reexecute(eng):
     """a picture decoded by the engine is used as reference by the next one without leaving HBM;
     executing an uploaded work list twice gives the same picture (coefficients are not consumed)"""

@@ -290,7 +290,7 @@ def test_random_small_ctb_streams():
 SHVC_CASES = [
     ("x2", 96, 64, 192, 128, 61, dict(n_pictures=4, gop=2)),
     ("x1_5", 96, 64, 144, 96, 62, dict(n_pictures=4, gop=2, amp=1, transform_skip=1)),
-    ("snr", 96, 64, 96, 64, 63, dict(n_pictures=3, gop=1)),
+    ("snr", 160, 96, 160, 96, 63, dict(n_pictures=3, gop=1, log2_ctb_size=5)),
     ("ratios_1_33_by_1_75", 96, 64, 128, 112, 64, dict(n_pictures=3, gop=2)),
     ("x2_idr_period", 64, 64, 128, 128, 65, dict(n_pictures=7, gop=2, idr_period=3, n_refs=2, tmvp=1)),
     ("x1_5_ctb16", 96, 64, 144, 96, 66, dict(n_pictures=3, gop=2, log2_ctb_size=4, log2_max_tb_size=4)),
@@ -298,11 +298,16 @@ SHVC_CASES = [
 
 
 def test_two_layer_writer_refuses_what_the_up_sampler_cannot_do():
-    for kw in (dict(bit_depth=10), dict(chroma_format_idc=3), dict(gop=3), dict(conf_win_left=2)):
+    for kw in (dict(bit_depth=10), dict(chroma_format_idc=3), dict(gop=3), dict(conf_win_left=2), dict(transform_skip=1, log2_max_tskip_size=4),
+               dict(implicit_rdpcm=1)):
         with pytest.raises(ValueError):
             streamgen.write_stream(64, 64, 1, n_pictures=2, shvc_el_width=128, shvc_el_height=128, **kw)
     with pytest.raises(ValueError):                           # an enhancement layer smaller than the base layer
         streamgen.write_stream(64, 64, 1, n_pictures=2, shvc_el_width=32, shvc_el_height=64)
+    with pytest.raises(ValueError):                           # more than twice the base layer: the reference's two up-sampling paths disagree
+        streamgen.write_stream(64, 64, 1, n_pictures=2, shvc_el_width=144, shvc_el_height=128)
+    with pytest.raises(ValueError):                           # a single CTB row: the reference's block up-sampler emulates one picture edge per block
+        streamgen.write_stream(64, 32, 1, n_pictures=2, shvc_el_width=128, shvc_el_height=64)
     with pytest.raises(ValueError):                           # not a multiple of the smallest coding block
         streamgen.write_stream(64, 64, 1, n_pictures=2, shvc_el_width=100, shvc_el_height=128)
 

@@ -2,7 +2,9 @@
 """Random sweep of the stream writer's parameter space through the reference decoder (container only: needs oracle/_ref):
 every stream is decoded by the unmodified reference and by the hooked reference + CPU checker; any difference is printed with
 the parameters that reproduce it.  usage: sweep_streams.py [count] [seed]   |   sweep_streams.py --harness [count] [seed]  (GPU box: engine vs reference)
-   |   sweep_streams.py --sparse | --sparse-engine [count] [seed]   (the sparse hand-over through the checker / the engine)"""
+   |   sweep_streams.py --sparse | --sparse-engine [count] [seed]   (the sparse hand-over through the checker / the engine)
+   |   sweep_streams.py --harness-frame-threads | --harness-shvc | --harness-shvc-threads [count] [seed]   (the drop-in library under the
+       reference's frame threads; two-layer streams)"""
 import os
 import random
 import sys
@@ -94,7 +96,28 @@ def draw(rng):
     return fit_window(dim(2, 40), dim(2, 30)) + (rng.randint(1, 10 ** 6), kw)
 
 
-def harness_sweep(count, seed, extra=(), min_ctb=4):
+def two_layers(rng, w, h, kw):
+    """turns a drawn parameter set into a two-layer (SHVC) one: what the writer's enhancement layer allows (8 bit 4:2:0, no window, not
+    hierarchical B) and an enhancement-layer size at a ratio of 1 (SNR), 1.5, 2 or anything between 1 and 2.5 per axis"""
+    kw = dict(kw, bit_depth=8, chroma_format_idc=1)
+    for k in ("conf_win_left", "conf_win_right", "conf_win_top", "conf_win_bottom", "sao_offset_scale_luma", "sao_offset_scale_chroma",
+              "tskip_rotation", "tskip_context", "implicit_rdpcm", "explicit_rdpcm", "intra_smoothing_disabled", "log2_max_tskip_size",
+              "persistent_rice", "cross_component_pred"):
+        kw.pop(k, None)                                             # (the range extensions: the reference reads a layer-1 PPS extension as something else)
+    if kw.get("gop") == 3:
+        kw["gop"] = 2
+    m = 1 << kw.get("log2_min_cb_size", 3)
+    # the ratios the reference has its own slot variants for: x1 (SNR), x1.5, x2.  For other ratios its CTB path and its whole-picture slot
+    # can differ in the last chroma row of a CTB row (tests/test_upsample_vs_ref.py records it): there is no single reference output
+    r = rng.choice([1, 1.5, 2, 2])
+    if r == 1.5 and ((w * 3) % (2 * m) or (h * 3) % (2 * m)):
+        r = 2
+    ew, eh = int(w * r), int(h * r)                             # (the writer refuses what is too small: one CTB row / column)
+    kw.update(shvc_el_width=ew, shvc_el_height=eh)
+    return kw
+
+
+def harness_sweep(count, seed, extra=(), min_ctb=4, shvc=False):
     """the same sweep with the ENGINE on the other side (GPU box; oracle/_ref travels there): ohevc_dec -o against the reference's output"""
     import subprocess
     import tempfile
@@ -106,10 +129,24 @@ def harness_sweep(count, seed, extra=(), min_ctb=4):
             w, h, s, kw = draw(rng)
             if kw["log2_ctb_size"] < min_ctb:
                 kw["log2_ctb_size"] = min_ctb
-            data, _ = streamgen.write_stream(w, h, s, **kw)
+            if shvc:
+                kw = two_layers(rng, w, h, kw)
+            if "-p" in extra and shvc:                             # (tiles under slice threads: the reference's own output depends on the thread count)
+                kw.update(tile_cols=1, tile_rows=1)
+            if "-p" in extra and extra[extra.index("-f") + 1] == "1":
+                kw.update(pcm=0, transquant_bypass=0)              # (its PCM / bypass flags are per frame-thread context and never cleared: hevc.c:147, 1440)
+            try:
+                data, _ = streamgen.write_stream(w, h, s, **kw)
+            except ValueError:
+                continue                                            # (a combination the two-layer writer refuses)
             # the reference's own output depends on its threading in places (tiles: its filters then run at the end of the picture in
-            # raster order, hevc.c:2967-3003): the unmodified decoder runs with the same threads as the front end
-            pics = refdec.decode(data, threads=4, thread_type=2) if "-p" in extra else refdec.decode(data)
+            # raster order, hevc.c:2967-3003; PCM / bypass flags per frame-thread context): the unmodified decoder runs with the same
+            # threads as the front end
+            with refdec.captured_stderr():
+                # FRAME threads: against the reference's SINGLE-threaded output — under its own frame threads the reference differs from itself on
+                # ~2 % of these streams (and not always the same way twice: profiles/r03_stream_sweep.txt), the drop-in library does not
+                slice_threads = "-p" in extra and extra[extra.index("-f") + 1] == "2"
+                pics = refdec.decode(data, threads=int(extra[extra.index("-p") + 1]), thread_type=2) if slice_threads else refdec.decode(data)
             open(os.path.join(tmp, "s.bin"), "wb").write(data)
             for old in os.listdir(tmp):
                 if old.startswith("o_"):
@@ -212,6 +249,12 @@ def main():
         return threads_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):
         return sparse_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1, sys.argv[1] == "--sparse-engine")
+    if len(sys.argv) > 1 and sys.argv[1] in ("--harness-frame-threads", "--harness-shvc", "--harness-shvc-threads"):
+        # the drop-in library under the reference's FRAME threads; two-layer streams (single thread / 4 slice threads)
+        mode = sys.argv[1]
+        return harness_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1,
+                             ("-p", "3", "-f", "1") if mode == "--harness-frame-threads" else ("-p", "4", "-f", "2") if mode == "--harness-shvc-threads" else (),
+                             5 if mode == "--harness-shvc-threads" else 4, shvc=mode != "--harness-frame-threads")
     if len(sys.argv) > 1 and sys.argv[1] in ("--harness", "--harness-bs", "--harness-threads"):
         # -bs: boundary strengths derived on the GPU (ohevc_dec -b); -threads: the front end on 4 slice / wavefront threads (32x32 CTBs and
         # larger: with 16x16 CTBs the reference's own output depends on its thread count)

@@ -258,8 +258,7 @@ def end_to_end(n_pictures=60):
         out["streams"][name] = rec
     # SHVC: a two-layer stream, 1080p base layer + 2160p enhancement layer (x2 spatial scalability, 8 bit 4:2:0 — what
     # the reference's up-sampler is written for); both layers' pictures go through the engine, the inter-layer reference picture is resampled in
-    # HBM (oh_pic_upsample).  Slice / wavefront threads (the recording hooks refuse an enhancement layer under frame threads); fps counts the
-    # released (enhancement-layer) pictures, every one standing for a base-layer picture as well
+    # HBM (oh_pic_upsample).  fps counts the released (enhancement-layer) pictures, every one standing for a base-layer picture as well
     try:
         t0 = time.perf_counter()
         data, _ = streamgen.write_stream(1920, 1080 + 8, 6, n_pictures=n_pictures, gop=2, wpp=1, shvc_el_width=3840, shvc_el_height=2160 + 16)
@@ -269,8 +268,9 @@ def end_to_end(n_pictures=60):
             path = fh.name
         del data
         try:
+            rec["dropin_frame_threads"] = run(libs["dropin"], path, 1)
+            rec["dropin_frame_threads_with_output"] = run(libs["dropin"], path, 1, ("-g",))
             rec["dropin_slice_threads"] = run(libs["dropin"], path, 2)
-            rec["dropin_slice_threads_with_output"] = run(libs["dropin"], path, 2, ("-g",))
             for k in ("reference_sse", "reference_c"):
                 if os.path.exists(libs[k]):
                     rec[k + "_slice_threads"] = run(libs[k], path, 2)

@@ -74,7 +74,7 @@ typedef struct OhStreamParams {
                                            partitions include NxN, its min PU / QP / PCM map granularity follows */
     int32_t shvc_el_width, shvc_el_height;   /* > 0: a TWO-LAYER stream (SHVC spatial scalability, the SHM 4.1 syntax the reference parses): this stream is
                                            the base layer (8 bit 4:2:0, no window, not gop 3, no range extensions), every access unit also carries an enhancement-layer
-                                           picture of this size (the base layer's to twice the base layer's, and more than one CTB + 16 samples each way: x1 = SNR, x1.5, x2 or any ratio between) whose P slices predict from the
+                                           picture of this size (the base layer's to twice the base layer's, and more than one CTB + 16 samples each way: x1 = SNR, x1.5 — up to 2048 columns and rows —, x2 or any ratio between) whose P slices predict from the
                                            up-sampled base-layer picture only (zero motion vectors), plus intra blocks and residuals */
 } OhStreamParams;
 

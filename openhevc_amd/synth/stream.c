@@ -1546,9 +1546,13 @@ int oh_stream_write(const OhStreamParams *p, OhStream *out)
          * of a single CTB row or column — the reference's block up-sampler emulates ONE picture edge per block and direction
          * (videodsp_template.c:110-116, 141-151 return after the left / top edge), a block that touches both reads samples nobody wrote;
          * (3) ratios above 2 — the reference's CTB path and its whole-picture slot then produce different chroma rows at the picture's
-         * bottom (the engine follows the whole-picture slot: tests/test_upsample_vs_ref.py), so there is no single reference output */
+         * bottom (the engine follows the whole-picture slot: tests/test_upsample_vs_ref.py), so there is no single reference output;
+         * (4) x1.5 beyond 2048 enhancement-layer columns or rows — the x1.5 block slots position by exact thirds ((x << 1) / 3, x % 3:
+         * hevcdsp_template.c:2073-2077), the whole-picture slot by the 16.16 fixed-point scale 43691, whose rounding reaches a sixteenth
+         * of a sample at x = 2048: the two paths pick different filter phases from there on */
         const int ctb = 1 << (p->log2_ctb_size ? p->log2_ctb_size : 6);
-        if (rext_profile(p) || p->shvc_el_width < ctb + 16 || p->shvc_el_height < ctb + 16 || p->shvc_el_width > 2 * p->width || p->shvc_el_height > 2 * p->height ||
+        const int x1_5 = 2 * p->shvc_el_width == 3 * p->width || 2 * p->shvc_el_height == 3 * p->height;
+        if (rext_profile(p) || (x1_5 && (p->shvc_el_width > 2048 || p->shvc_el_height > 2048)) || p->shvc_el_width < ctb + 16 || p->shvc_el_height < ctb + 16 || p->shvc_el_width > 2 * p->width || p->shvc_el_height > 2 * p->height ||
             p->bit_depth != 8 || p->chroma_format_idc != 1 || p->gop == 3 || p->shvc_el_width < p->width || p->shvc_el_height < p->height ||
             (p->shvc_el_width & ((1 << mcb_log2) - 1)) || (p->shvc_el_height & ((1 << mcb_log2) - 1)) || p->trace || p->levels ||
             p->conf_win_left || p->conf_win_right || p->conf_win_top || p->conf_win_bottom) {

@@ -119,8 +119,8 @@ static int frame_rps_and_bind(HEVCContext *s)
     int ret = ff_hevc_frame_rps(s);
     if (ret < 0)
         return ret;
-    if (s->decoder_id > 1 || (s->decoder_id && (s->threads_type & FF_THREAD_FRAME))) {
-        av_log(s->avctx, AV_LOG_ERROR, "recording hooks: an enhancement layer is decoded without frame threads, and there is one\n");
+    if (s->decoder_id > 1) {
+        av_log(s->avctx, AV_LOG_ERROR, "recording hooks: one enhancement layer (the wrapper allocates two decoders, openHevcWrapper.c:28)\n");
         return AVERROR_PATCHWELCOME;
     }
     h_idx = s->decoder_id;

@@ -61,28 +61,8 @@ int libOpenHevcStartDecoder(OpenHevc_Handle openHevcHandle)
     return rc;
 }
 
-/* a slice segment of a layer above the base layer in the access unit (NAL header: nal_unit_type < 32, nuh_layer_id > 0) */
-static int carries_a_higher_layer(const unsigned char *b, int n)
-{
-    const unsigned char *p = b, *end = b + n;
-    while (p + 2 < end && (p = memchr(p + 2, 1, (size_t)(end - p - 2))) != NULL) {           /* the 01 of a start code 00 00 01 */
-        if (p[-1] == 0 && p[-2] == 0 && p + 2 < end && ((p[1] >> 1) & 63) < 32 && (((p[1] & 1) << 5) | (p[2] >> 3)) > 0)
-            return 1;
-        p -= 1;                                                 /* next search starts behind this byte */
-    }
-    return 0;
-}
-
 int libOpenHevcDecode(OpenHevc_Handle openHevcHandle, const unsigned char *buff, int au_len, int64_t pts)
 {
-    OpenHevcWrapperContexts *ctxs = (OpenHevcWrapperContexts *)openHevcHandle;
-    if (ctxs->active_layer > 0 && buff && au_len > 4 && (ctxs->wraper[0]->c->active_thread_type & FF_THREAD_FRAME) && carries_a_higher_layer(buff, au_len)) {
-        /* the enhancement layer's decoder under frame threads synchronises with the base layer's through the reference's inter-layer
-         * progress protocol (pthread_frame.c ff_thread_await_il_progress / report_il_progress), which hands HOST pictures between the
-         * two thread pools; the recording hooks keep one picture per thread and layer.  Refused, not decoded wrongly. */
-        fprintf(stderr, "libopenhevc_hip: an enhancement layer is decoded without frame threads (thread type 2, or one thread); or decode the base layer only: libOpenHevcSetActiveDecoders(h, 0)\n");
-        return -1;
-    }
     g_fetched = NULL;                            /* the frame exposed so far is released by this call (openHevcWrapper.h: valid until the next Decode) */
     const int got = oh_host_Decode(openHevcHandle, buff, au_len, pts);
     if (got == 0 && au_len == 0 && oh_hooked_engine_sync() != 0)      /* flushed: nothing is left to output, and nothing is left running */

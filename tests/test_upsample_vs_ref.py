@@ -162,6 +162,20 @@ def test_reference_paths_disagree_for_some_generic_ratios():
             assert np.array_equal(want.visible(c), got.visible(c))
 
 
+def test_reference_paths_disagree_for_x1_5_beyond_2048_columns():
+    """Recorded fact: the x1.5 block slots position by exact thirds ((x << 1) / 3, x % 3, hevcdsp_template.c:2073-2077), the whole-picture slot
+    by the fixed-point scale 43691 / 65536, whose rounding reaches a sixteenth of a sample at x = 2048: from that enhancement-layer column on
+    the reference's two paths pick different luma filter phases (chroma, half as wide, agrees).  Found by the two-layer sweep with pictures
+    up to 1920 x 1088 in the base layer; the GPU pass and the oracle follow the whole-picture slot."""
+    u, bl, want, got = run_frame_both((1376, 64), (2064, 96), (0, 0, 0, 0), 91)
+    el = run_block_path(u, bl, (1376, 64), (2064, 96), 5)
+    xs = np.unique(np.nonzero(want.visible(0) != el.visible(0))[1])
+    assert len(xs) and xs.min() == 2048
+    for c in range(3):
+        assert np.array_equal(want.visible(c), got.visible(c))
+        assert c == 0 or np.array_equal(want.visible(c), el.visible(c))
+
+
 def test_frame_slot_random_geometries():
     """the whole-picture slot over a seeded sweep of geometries (ratios 1 .. 2, offsets, phase alignment): checker == reference.
     tests/test_gpu_parity.py runs the engine against the checker on the same kind of sweep"""

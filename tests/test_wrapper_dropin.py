@@ -108,19 +108,41 @@ def test_two_layer_streams_match_the_reference_library(name, w, h, ew, eh, seed,
             assert np.array_equal(a[c], b[c]), f"{name}: output picture {k} plane {c} ({a[c].shape}) differs from the reference library's"
 
 
+SHVC_FRAME_THREADS = [
+    ("x2", 416, 240, 832, 480, 61, dict(n_pictures=9, gop=2), 4),
+    ("x1_5_idr_period", 416, 240, 624, 360, 62, dict(n_pictures=10, gop=2, idr_period=4, amp=1), 3),
+    ("snr", 416, 240, 416, 240, 63, dict(n_pictures=7, gop=1), 5),
+    ("hd_to_uhd_wavefront_syntax", 1920, 1080 + 8, 3840, 2160 + 16, 64, dict(n_pictures=8, gop=2, wpp=1), 8),
+]
+
+
 @pytest.mark.gpu
 @need_lib
-def test_an_enhancement_layer_with_frame_threads_is_refused():
-    """the reference's frame threads for an enhancement layer synchronise with the base layer's through its inter-layer progress protocol
-    (pthread_frame.c ff_thread_await_il_progress), which hands host pictures between the two thread pools; the recording hooks keep one
-    picture per thread and layer: libOpenHevcDecode returns the API's error value for such an access unit — and the base layer alone
-    (libOpenHevcSetActiveDecoders(h, 0)) decodes under frame threads as any one-layer stream does"""
+@pytest.mark.parametrize("name,w,h,ew,eh,seed,kw,threads", SHVC_FRAME_THREADS, ids=[s[0] for s in SHVC_FRAME_THREADS])
+def test_two_layer_streams_under_frame_threads(name, w, h, ew, eh, seed, kw, threads):
+    """both layers' decoders on the reference's FRAME threads (pthread_frame.c: the enhancement layer's workers wait for the base layer's picture
+    of their access unit through ff_thread_await_il_progress, and for the base-layer rows whose motion field they scale): every worker records
+    its own picture per layer, pictures reach the engine in frame-start order (a base-layer picture before the enhancement-layer picture that
+    up-samples it).  Against the reference library on ONE thread, three runs"""
+    data, _ = streamgen.write_stream(w, h, seed, shvc_el_width=ew, shvc_el_height=eh, **kw)
+    with refdec.captured_stderr():
+        want = refdec.decode(data)
+    assert [p[0].shape for p in want] == [(eh, ew)] * kw["n_pictures"]
+    for run in range(3):
+        with refdec.captured_stderr():
+            got = refdec.decode(data, threads=threads, thread_type=1, L=refdec.hip_lib())
+        assert len(got) == len(want), (run, len(got), len(want))
+        for k, (a, b) in enumerate(zip(want, got)):
+            for c in range(3):
+                assert a[c].shape == b[c].shape and np.array_equal(a[c], b[c]), f"{name}: run {run}, output picture {k} plane {c} differs from the reference library's"
+
+
+@pytest.mark.gpu
+@need_lib
+def test_base_layer_alone_of_a_two_layer_stream():
+    """libOpenHevcSetActiveDecoders(h, 0): only the base layer is decoded (openHevcWrapper.c:405-414) — under frame threads too"""
     kw = dict(n_pictures=6, gop=2)
     data, _ = streamgen.write_stream(192, 128, 58, shvc_el_width=384, shvc_el_height=256, **kw)
-    with refdec.captured_stderr() as cap:
-        with pytest.raises(RuntimeError):
-            refdec.decode(data, threads=2, thread_type=1, L=refdec.hip_lib())
-    assert "enhancement layer" in cap.text
     base, _ = streamgen.write_stream(192, 128, 58, **kw)
     want = refdec.decode(base)
     got = refdec.decode(data, threads=3, thread_type=1, L=refdec.hip_lib(), active_decoders=0)

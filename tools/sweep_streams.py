@@ -3,7 +3,7 @@
 every stream is decoded by the unmodified reference and by the hooked reference + CPU checker; any difference is printed with
 the parameters that reproduce it.  usage: sweep_streams.py [count] [seed]   |   sweep_streams.py --harness [count] [seed]  (GPU box: engine vs reference)
    |   sweep_streams.py --sparse | --sparse-engine [count] [seed]   (the sparse hand-over through the checker / the engine)
-   |   sweep_streams.py --harness-frame-threads | --harness-shvc | --harness-shvc-threads [count] [seed]   (the drop-in library under the
+   |   sweep_streams.py --harness-frame-threads | --harness-shvc | --harness-shvc-threads | --harness-shvc-frame-threads [count] [seed]   (the drop-in library under the
        reference's frame threads; two-layer streams)"""
 import os
 import random
@@ -249,6 +249,8 @@ def main():
         return threads_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] in ("--sparse", "--sparse-engine"):
         return sparse_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1, sys.argv[1] == "--sparse-engine")
+    if len(sys.argv) > 1 and sys.argv[1] == "--harness-shvc-frame-threads":
+        return harness_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 1, ("-p", "3", "-f", "1"), 4, shvc=True)
     if len(sys.argv) > 1 and sys.argv[1] in ("--harness-frame-threads", "--harness-shvc", "--harness-shvc-threads"):
         # the drop-in library under the reference's FRAME threads; two-layer streams (single thread / 4 slice threads)
         mode = sys.argv[1]

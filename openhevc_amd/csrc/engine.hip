@@ -1661,11 +1661,8 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
             if (nd || nsd)
                 ohk_intra_dag_reset(&all, nb, max_ictu_all, tk, st);
             if (a) HIPCHK(e, hipEventRecord(a, st));
-            /* persistent workers: as many as the chip holds at once (OHEVC_INTRA_WORKERS scales it: experiments) */
-            static const char *wkenv = getenv("OHEVC_INTRA_WORKERS");
-            const double wk_scale = wkenv ? atof(wkenv) : 1.0;
             if (nd)
-                ohk_intra_direct(&bd, nd, p, max_ictu_d, (uint32_t)std::max(1.0, wk_scale * 32.0 * e->n_cu), tk, e->spin_limit, st);
+                ohk_intra_direct(&bd, nd, p, max_ictu_d, tk, e->spin_limit, st);
             if (nsd) {
                 OhIntraLaunch IL;
                 /* residual spans in LDS only while the chip holds the whole launch (a picture alone); else the blocks fetch theirs a sub-level ahead */
@@ -1684,8 +1681,7 @@ extern "C" int oh_frames_execute(OhEngine *e, OhDevFrame *const *dfs, int n)
                 IL.off_res = (uint32_t)off;   off = align_up(off + (size_t)(IL.staged ? max_res : 0) * sizeof(int16_t), 16);
                 IL.off_wave = (uint32_t)off;  off += (size_t)IL.waves * OH_INTRA_WAVE_LDS;
                 IL.lds_bytes = (uint32_t)off;
-                const uint32_t by_lds = std::max<uint32_t>(1u, (160u * 1024u) / std::max<uint32_t>(IL.lds_bytes, 1024u)), by_waves = std::max<uint32_t>(1u, 24u / IL.waves);
-                ohk_intra_dag(&bs, nsd, p, &IL, max_ictu_s, (uint32_t)std::max(1.0, wk_scale * std::min(by_lds, by_waves) * e->n_cu), tk + OH_MAX_BATCH * 32, e->spin_limit, st);
+                ohk_intra_dag(&bs, nsd, p, &IL, max_ictu_s, tk + OH_MAX_BATCH * 32, e->spin_limit, st);
             }
             if (b) {
                 HIPCHK(e, hipEventRecord(b, st));

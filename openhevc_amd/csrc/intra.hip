@@ -1099,12 +1099,11 @@ extern "C" void ohk_intra_dag_reset(const OhBatch *B, int n, uint32_t max_ictu, 
 }
 
 /* n pictures, each one's whole schedule, staged form: l = the LDS carve-up that fits every CTU of all of them (l->level unused) */
-extern "C" void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ictu, uint32_t workers, uint32_t *ticket,
+extern "C" void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ictu, uint32_t *ticket,
                               uint32_t spin_limit, hipStream_t st)
 {
     if (n <= 0 || !max_ictu) return;
     const uint32_t total = max_ictu * (uint32_t)n;
-    (void)workers;
     dim3 g(total), b(64 * l->waves);
 #define DAG_LAUNCH(PX, CIP, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(intra_dag_kernel<PX, CIP, ST>), g, b, l->lds_bytes, st, *B, *l, n, total, ticket, spin_limit)
 #define DAG_BY_FLAGS(PX)                                                                       \
@@ -1118,11 +1117,10 @@ extern "C" void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, con
 }
 
 /* n pictures, each one's whole schedule, a wave per CTU straight on the picture in HBM */
-extern "C" void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_ictu, uint32_t workers, uint32_t *ticket, uint32_t spin_limit, hipStream_t st)
+extern "C" void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_ictu, uint32_t *ticket, uint32_t spin_limit, hipStream_t st)
 {
     if (n <= 0 || !max_ictu) return;
     const uint32_t total = max_ictu * (uint32_t)n;
-    (void)workers;
     dim3 g(total), b(64);
     static const char *xenv = getenv("OHEVC_EXP");           /* experiments only: 1 no waits, 2 no publishing (wrong pictures) */
     const int exp = xenv ? atoi(xenv) : 0;

@@ -23,9 +23,9 @@ void ohk_cross(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_cross
 void ohk_intra_level(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ctu, hipStream_t st);
 void ohk_intra_rows(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t spin_limit, hipStream_t st);
 void ohk_intra_dag_reset(const OhBatch *B, int n, uint32_t max_ictu, uint32_t *tickets, hipStream_t st);
-void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ictu, uint32_t workers, uint32_t *ticket,
+void ohk_intra_dag(const OhBatch *B, int n, const OhPicParams *p, const OhIntraLaunch *l, uint32_t max_ictu, uint32_t *ticket,
                    uint32_t spin_limit, hipStream_t st);
-void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_ictu, uint32_t workers, uint32_t *ticket, uint32_t spin_limit, hipStream_t st);
+void ohk_intra_direct(const OhBatch *B, int n, const OhPicParams *p, uint32_t max_ictu, uint32_t *ticket, uint32_t spin_limit, hipStream_t st);
 void ohk_deblock(const OhBatch *B, int n, const OhPicParams *p, int horiz, hipStream_t st);
 void ohk_upsample_plane(const OhUpPlane *a, int taps, int tw, int th, const uint32_t *list, int n_list, hipStream_t st);
 void ohk_sao(const OhBatch *B, int n, const OhPicParams *p, hipStream_t st);

@@ -291,7 +291,8 @@ def end_to_end(n_pictures=60):
                                   met_decode_cold_start=bool(d8.get("fps_first_pass_cold") and d8["fps_first_pass_cold"] >= 60),
                                   met_with_output_cold_start=bool(o8.get("fps_first_pass_cold") and o8["fps_first_pass_cold"] >= 60),
                                   note="steady = passes 2-3 of the 60-picture stream decoded three times in a row through one decoder; cold start = the first pass, in which every "
-                                       "picture's host frame buffers (100 MB at 8K Main 10) are new memory. End to end on ONE stream the host front end (the reference's CABAC / syntax / "
+                                       "picture's host frame buffers (100 MB at 8K Main 10) are new memory, every worker's decoder context and recorder are built, and the 16-deep "
+                                       "frame-thread pipeline fills (a picture takes ~190 ms on its worker: 16 workers x 60 pictures leave little steady state inside one pass). End to end on ONE stream the host front end (the reference's CABAC / syntax / "
                                        "motion derivation on its frame threads) sets the pace: the GPU passes of a picture take a fraction of its parse time (compare the headline: "
                                        "thousands of pictures per second over work lists)")
     return out

@@ -567,6 +567,13 @@ __attribute__((visibility("default"))) void oh_hooked_engine_close(void)
             fprintf(stderr, " bytes over PCIe per picture %.2f MB\n", (double)oh_engine_upload_bytes(E.e, 0) / HT.pictures / 1e6);
         }
     }
+    if (getenv("OHEVC_HOOK_TIMING") && HT.pictures && E.e) {
+        uint64_t m[6];
+        if (oh_engine_memory(E.e, m) == OH_OK)
+            fprintf(stderr, "   engine memory after %d pictures: %llu work-list arenas alive (%.1f MB, %llu of them free in the pool), %llu pinned staging buffers (%.1f MB), "
+                            "%llu lists awaiting a deferred free, %d engine pictures\n", HT.pictures, (unsigned long long)m[0], m[1] / 1e6, (unsigned long long)m[2],
+                    (unsigned long long)m[3], m[4] / 1e6, (unsigned long long)m[5], E.n);
+    }
     memset(&HT, 0, sizeof(HT));
     pthread_mutex_lock(&SEQ.mu); SEQ.next = SEQ.turn = 0; pthread_mutex_unlock(&SEQ.mu);
     pthread_mutex_lock(&E.lock);

@@ -139,6 +139,19 @@ def test_splitter_on_written_streams():
             assert sum(1 for u in units if u[5]) == 1                        # one first slice segment per access unit
 
 
+def test_splitter_keeps_the_layers_of_an_access_unit_together():
+    """two-layer (SHVC) streams: the enhancement layer's NAL units (nuh_layer_id 1: its parameter sets, its slice segments whose
+    first_slice_segment_in_pic_flag is set too) stay in the access unit of their base-layer picture (hevc_parser.c:62, 71 test nuh_layer_id)"""
+    for kw in (dict(), dict(n_slices=2), dict(wpp=1), dict(idr_period=2)):
+        data, aus = streamgen.write_stream(192, 128, 78, n_pictures=5, gop=2, shvc_el_width=384, shvc_el_height=256, **kw)
+        got = A.split(data)
+        assert len(got) == 5 and [a for a, _ in got][1:] == [a + 1 for a, _ in aus][1:] and got[-1][1] == len(data)
+        for a, b in got:
+            units = A.nal_units(data[a:b])
+            assert sorted({u[3] for u in units if u[2] < 32}) == [0, 1]      # slice segments of both layers
+            assert sum(1 for u in units if u[5] and u[3] == 0) == 1 and sum(1 for u in units if u[5] and u[3] == 1) == 1
+
+
 @need_ref
 def test_hashes_read_from_the_stream_are_what_the_reference_checks():
     """digests written into SEI messages come back through oh_sei_picture_hash; they are the MD5s of the reference's output planes;

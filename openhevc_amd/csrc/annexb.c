@@ -16,39 +16,52 @@ void oh_au_scanner_init(OhAuScanner *sc)
 }
 
 static int is_vcl(int nut) { return nut <= NAL_RASL_R || (nut >= NAL_BLA_W_LP && nut <= NAL_CRA_NUT); }
-static int opens_au(int nut)
+
+/* what a NAL unit type means for the access-unit boundary (7.4.2.4.4: the first of VPS .. AUD, prefix SEI, the reserved / unspecified ranges
+ * 41..44 and 48..55 after the last VCL NAL unit of a picture starts a new access unit; a VCL NAL unit does when it is a first slice segment) */
+enum { CLS_NEUTRAL = 0, CLS_OPENS_AU = 1, CLS_VCL = 2 };
+static int nal_class(int nut)
 {
-    return (nut >= NAL_VPS && nut <= NAL_AUD) || nut == NAL_SEI_PREFIX || (nut >= 41 && nut <= 44) || (nut >= 48 && nut <= 55);
+    static uint8_t cls[64];
+    static int built;
+    if (!built) {                                             /* (idempotent: concurrent first calls write the same values) */
+        for (int t = 0; t < 64; t++)
+            cls[t] = is_vcl(t) ? CLS_VCL : ((t >= NAL_VPS && t <= NAL_AUD) || t == NAL_SEI_PREFIX || (t >= 41 && t <= 44) || (t >= 48 && t <= 55)) ? CLS_OPENS_AU : CLS_NEUTRAL;
+        built = 1;
+    }
+    return cls[nut & 63];
+}
+
+/* one NAL unit header seen by the scanner: returns 1 when the access unit that was open ENDS in front of this unit.  Only units of the base
+ * layer move the state (hevc_parser.c:62, 71): the pictures of higher layers belong to the access unit of their base-layer picture. */
+static int au_step(OhAuScanner *sc, int cls, int layer_id, int first_slice_segment)
+{
+    if (layer_id != 0 || cls == CLS_NEUTRAL || (cls == CLS_VCL && !first_slice_segment))
+        return 0;
+    if (!sc->frame_start_found) {                             /* no picture open: a first slice segment opens one, anything else waits */
+        sc->frame_start_found = cls == CLS_VCL;
+        return 0;
+    }
+    sc->frame_start_found = 0;                                /* a picture was open: this unit belongs to the next access unit */
+    return 1;
 }
 
 long oh_au_find_frame_end(OhAuScanner *sc, const uint8_t *buf, size_t size)
 {
-    uint64_t st = sc->state64;
+    /* the history holds the last eight bytes across calls (the parser's state64): a header is complete when the byte BEHIND its two bytes
+     * arrives — that byte carries first_slice_segment_in_pic_flag — i.e. when bytes -5 .. -3 of the history are the start code 00 00 01 */
+    uint64_t hist = sc->state64;
     for (size_t i = 0; i < size; i++) {
-        st = (st << 8) | buf[i];
-        if (((st >> 24) & 0xFFFFFF) != 1)                     /* bytes i-5 .. i-3 are 00 00 01; i-2, i-1 the NAL header; i its first payload byte */
+        hist = (hist << 8) | buf[i];
+        if ((hist & 0xFFFFFF000000ull) != 0x000001000000ull)
             continue;
-        const int nut = (int)(st >> 17) & 0x3F;
-        const int layer_id = (int)(((st >> 16) & 1) << 5) + (int)(((st >> 8) & 0xF8) >> 3);
-        if (opens_au(nut)) {
-            if (sc->frame_start_found && !layer_id) {
-                sc->frame_start_found = 0;
-                sc->state64 = st;
-                return (long)i - 5;
-            }
-        } else if (is_vcl(nut)) {
-            if ((buf[i] >> 7) && !layer_id) {                 /* first_slice_segment_in_pic_flag */
-                if (!sc->frame_start_found)
-                    sc->frame_start_found = 1;
-                else {
-                    sc->frame_start_found = 0;
-                    sc->state64 = st;
-                    return (long)i - 5;
-                }
-            }
+        const unsigned h0 = (unsigned)(hist >> 16) & 0xFF, h1 = (unsigned)(hist >> 8) & 0xFF;      /* the two header bytes */
+        if (au_step(sc, nal_class((int)(h0 >> 1) & 0x3F), (int)((h0 & 1) << 5 | h1 >> 3), buf[i] >> 7)) {
+            sc->state64 = hist;
+            return (long)i - 5;                               /* the cut lies in front of the start code (three bytes) + header (two) */
         }
     }
-    sc->state64 = st;
+    sc->state64 = hist;
     return OH_AU_END_NOT_FOUND;
 }
 

@@ -57,6 +57,8 @@ def lib():
         L.oh_pic_upload.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download.argtypes = [V, I, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_download_window.argtypes = [V, I, C.POINTER(OhWindow), C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
+        L.oh_pic_download_start.argtypes = [V, I, C.POINTER(OhWindow), C.POINTER(C.c_void_p)]
+        L.oh_download_finish.argtypes = [V, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t)]
         L.oh_pic_upsample_ctbs.argtypes = [V, I, I, C.c_void_p, I, C.POINTER(C.c_uint32), I]
         L.oh_pics_md5.argtypes = [V, C.POINTER(C.c_int), I, C.POINTER(C.c_uint8)]
         L.oh_frame_upload.argtypes = [V, C.POINTER(F.OhFrame), PP]
@@ -157,6 +159,32 @@ class Engine:
         d, s = self._plane_args(hp)
         self._chk(self.L.oh_pic_download(self.h, pid, d, s), "oh_pic_download")
         return hp
+
+    def pic_download_start(self, pid, left=0, right=0, top=0, bottom=0):
+        """first half of the output fetch (oh_pic_download_start): the copies are enqueued behind the picture's batch; returns the handle
+        oh_download_finish takes — on any thread, while this one keeps driving the engine"""
+        d = C.c_void_p()
+        win = OhWindow(left, right, top, bottom)
+        self._chk(self.L.oh_pic_download_start(self.h, pid, C.byref(win), C.byref(d)), "oh_pic_download_start")
+        return d
+
+    def download_finish(self, handle, params, left=0, right=0, top=0, bottom=0, planes=True):
+        """second half (oh_download_finish): waits for the copies, returns the packed planes; planes=False: hands no destination over
+        (the call must return OH_E_ARG and still release the staging buffer) and returns the error code"""
+        dt = np.uint8 if params.bit_depth <= 8 else np.uint16
+        W, H = params.width - left - right, params.height - top - bottom
+        if not planes:
+            return self.L.oh_download_finish(self.h, handle, None, None)
+        out = []
+        for c in range(F.n_planes(params)):
+            hs = 1 if c and params.chroma_format_idc in (1, 2) else 0
+            vs = 1 if c and params.chroma_format_idc == 1 else 0
+            out.append(np.zeros((H >> vs, W >> hs), dt))
+        n = len(out)
+        d = (C.c_void_p * 3)(*[pl.ctypes.data for pl in out] + [None] * (3 - n))
+        s = (C.c_ssize_t * 3)(*[pl.strides[0] for pl in out] + [0] * (3 - n))
+        self._chk(self.L.oh_download_finish(self.h, handle, d, s), "oh_download_finish")
+        return out
 
     def pic_download_window(self, pid, params, left=0, right=0, top=0, bottom=0, pad=0):
         """the picture inside its conformance window as packed numpy planes (pad: extra bytes per destination row, to

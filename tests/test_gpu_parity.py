@@ -185,6 +185,44 @@ def test_golden_pictures(eng):
         rec.close()
 
 
+def test_output_fetch_in_two_halves(eng):
+    """oh_pic_download_start / oh_download_finish: started on the engine's thread behind the picture's passes, finished on ANOTHER thread while
+    this one keeps handing pictures over; the planes are those of oh_pic_download_window; a finish without destination planes returns
+    OH_E_ARG and gives the staging buffer back (the next fetch works)"""
+    import threading
+    from openhevc_amd.engine import remap_frame
+    p = F.pic_params(416, 240, bit_depth=10)
+    rec = F.Recorder(p)
+    rng = np.random.default_rng(8)
+    host = {k: F.HostPic(p, rng=rng) for k in range(4)}
+    ids = {k: eng.pic_alloc(p) for k in host}
+    for k in (0, 1):
+        eng.pic_upload(ids[k], host[k])
+    fa = F.FrameCopy(rec.synth(F.synth_params(2, 801), 2, [0, 1]))
+    fb = F.FrameCopy(rec.synth(F.synth_params(2, 802), 3, [0, 1]))
+    eng.frame_submit(remap_frame(fa.frame, ids))
+    h = eng.pic_download_start(ids[2], left=8, right=16, top=4, bottom=8)       # enqueued behind picture 2's passes
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("win", eng.download_finish(h, p, left=8, right=16, top=4, bottom=8)))
+    t.start()
+    for _ in range(20):                                       # meanwhile this thread keeps the engine busy with other pictures
+        eng.frame_submit(remap_frame(fb.frame, ids))
+    t.join()
+    eng.sync()
+    want = eng.pic_download_window(ids[2], p, left=8, right=16, top=4, bottom=8)
+    for c in range(3):
+        assert np.array_equal(want[c], got["win"][c]), c
+    full = eng.pic_download(ids[2], p)
+    assert np.array_equal(want[0], full.visible(0)[4:240 - 8, 8:416 - 16])
+    h2 = eng.pic_download_start(ids[2])
+    assert eng.download_finish(h2, p, planes=False) == -2     # OH_E_ARG; the buffer is free again:
+    again = eng.download_finish(eng.pic_download_start(ids[2]), p)
+    assert np.array_equal(again[0], full.visible(0))
+    for v in ids.values():
+        eng.pic_free(v)
+    rec.close()
+
+
 def test_submit_and_forget_keeps_the_engines_memory_bounded():
     """a decoder hands one work list per picture to oh_frame_submit and forgets it: over a long stream the device arenas, the pinned
     staging buffers and the deferred lists level off (stream-ordered release into the pools), and the last picture is still right"""
